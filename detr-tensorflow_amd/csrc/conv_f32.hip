@@ -1,0 +1,579 @@
+// conv_f32.hip -- ResNet backbone convolution kernels (NHWC / HWIO, fp32) for gfx950:
+//   * 3x3 implicit-GEMM convolution forward / dgrad / wgrad on the MFMA tile engine
+//     (no im2col buffer: the A-operand loader gathers input pixels, zero-filling the halo);
+//   * stem helpers: 7x7/s2 im2col (Ci = 3 is too thin for an implicit loader), 3x3/s2 max pool
+//     over the zero-padded map + its backward, stride-2 subsample gather/scatter.
+// Reference: detr_tf/networks/resnet_backbone.py:11-32,98-137 (see include/detr_hip.h).
+#include "gemm_core.h"
+
+namespace detr {
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad : rows = destination pixels, K = 9 taps x source channels
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    int N, Hs, Ws, Cs;  // source tensor (A operand): fwd x[N,Hi,Wi,Ci]; dgrad dy[N,Ho,Wo,Co]
+    int Hd, Wd, Cd;     // destination tensor: fwd y[N,Ho,Wo,Co]; dgrad dx[N,Hi,Wi,Ci]
+    int stride, pad;
+    int Ci, Co;
+    int M;
+    const float *src;
+    const float *w;
+    float *dst;
+    int tiles_m, tiles_n;
+    EpiArgs e;
+};
+
+template <int BM, bool DGRAD>
+struct LoaderConvA {
+    static constexpr int NV = BM / 64;
+    int n_[NV], h_[NV], w_[NV];
+    bool ok[NV];
+    int kq, tid;
+
+    __device__ __forceinline__ void init(const ConvArgs &a, int m0, int tid_) {
+        tid = tid_;
+        kq = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int m = m0 + (tid >> 2) + 64 * i;
+            ok[i] = m < a.M;
+            const int mm = ok[i] ? m : 0;
+            const int wd = mm % a.Wd;
+            const int t = mm / a.Wd;
+            const int hd = t % a.Hd;
+            n_[i] = t / a.Hd;
+            if (DGRAD) {
+                h_[i] = hd + a.pad;
+                w_[i] = wd + a.pad;
+            } else {
+                h_[i] = hd * a.stride - a.pad;
+                w_[i] = wd * a.stride - a.pad;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
+        const int tap = kt / cpt;
+        const int c0 = (kt - tap * cpt) * GEMM_BK + kq;
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int hs, ws;
+            bool v = ok[i];
+            if (DGRAD) {
+                const int th = h_[i] - kh, tw = w_[i] - kw;
+                v = v && th >= 0 && tw >= 0;
+                if (a.stride == 2) {
+                    v = v && ((th & 1) == 0) && ((tw & 1) == 0);
+                    hs = th >> 1;
+                    ws = tw >> 1;
+                } else {
+                    hs = th;
+                    ws = tw;
+                }
+                v = v && hs < a.Hs && ws < a.Ws;
+            } else {
+                hs = h_[i] + kh;
+                ws = w_[i] + kw;
+                v = v && hs >= 0 && ws >= 0 && hs < a.Hs && ws < a.Ws;
+            }
+            if (v) {
+                const long long off = (((long long)n_[i] * a.Hs + hs) * a.Ws + ws) * a.Cs + c0;
+                r[i] = *reinterpret_cast<const float4 *>(a.src + off);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    template <int LD>
+    __device__ __forceinline__ void store(float (*S)[LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            S[kq + 0][row] = r[i].x;
+            S[kq + 1][row] = r[i].y;
+            S[kq + 2][row] = r[i].z;
+            S[kq + 3][row] = r[i].w;
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ GemmSmem<BM, BN> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = id % a.tiles_n, tm = id / a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int cpt = a.Cs / GEMM_BK;  // K tiles per tap
+    const int nkt = 9 * cpt;
+    const long long tapstride = (long long)a.Ci * a.Co;
+
+    LoaderConvA<BM, DGRAD> la;
+    la.init(a, m0, tid);
+    // B operand per tap: fwd  B[k=ci][n=co] = w[tap][ci][co]  (n contiguous, ld = Co, K = Ci)
+    //                    dgrad B[k=co][n=ci] = w[tap][ci][co]  (k contiguous, ld = Co, K = Co)
+    using LB = typename std::conditional<DGRAD, LoaderK<BN>, LoaderMN<BN>>::type;
+    LB lb;
+    lb.init(a.w, a.Co, n0, a.Cd, true, tid);
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[LoaderConvA<BM, DGRAD>::NV], rb[LB::NV];
+    auto load_b = [&](int kt) {
+        const int tap = kt / cpt;
+        lb.ptr = a.w + tap * tapstride;
+        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb);
+    };
+    la.load(a, 0, cpt, ra);
+    load_b(0);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (more) {
+            la.load(a, kt + 1, cpt, ra);
+            load_b(kt + 1);
+        }
+        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    epilogue<BM, BN, WGM, WGN>(acc, a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, a.e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad : per tap, dw[tap][ci][co] += scale[co] * sum_m x[pix(m,tap)][ci] * dy[m][co]
+// grid = (ci tiles * co tiles, 9 taps, row splits); reduction rows are the output pixels.
+// ------------------------------------------------------------------------------------------------
+struct ConvWgradArgs {
+    int N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad;
+    const float *x;
+    const float *dy;
+    float *dw;
+    int M, rows_per_split;
+    int tiles_m, tiles_n;
+    EpiArgs e;
+};
+
+template <int BM>
+struct LoaderWgradA {
+    static constexpr int VPR = BM / 4;
+    static constexpr int TOTAL = GEMM_BK * VPR;
+    static constexpr int NV = (TOTAL >= GEMM_THREADS) ? TOTAL / GEMM_THREADS : 1;
+    int n_[NV], h_[NV], w_[NV];  // output-pixel coordinates of this entry's current reduction row
+    int m_[NV];
+    int tid, ci0, kh, kw;
+
+    __device__ __forceinline__ void init(const ConvWgradArgs &a, int ci0_, int tap, int m_begin, int tid_) {
+        tid = tid_;
+        ci0 = ci0_;
+        kh = tap / 3;
+        kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            const int kr = idx / VPR;
+            const int m = m_begin + kr;
+            m_[i] = m;
+            const int wo = m % a.Wo;
+            const int t = m / a.Wo;
+            w_[i] = wo;
+            h_[i] = t % a.Ho;
+            n_[i] = t / a.Ho;
+        }
+    }
+    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            const int c4 = (idx % VPR) * 4;
+            const int hs = h_[i] * a.stride - a.pad + kh;
+            const int ws = w_[i] * a.stride - a.pad + kw;
+            const bool v = (idx < TOTAL) && (m_[i] < m_end) && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi &&
+                           (ci0 + c4 < a.Ci);
+            if (v) {
+                const long long off = (((long long)n_[i] * a.Hi + hs) * a.Wi + ws) * a.Ci + ci0 + c4;
+                r[i] = *reinterpret_cast<const float4 *>(a.x + off);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void advance(const ConvWgradArgs &a) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            m_[i] += GEMM_BK;
+            w_[i] += GEMM_BK;
+            while (w_[i] >= a.Wo) {
+                w_[i] -= a.Wo;
+                h_[i] += 1;
+            }
+            while (h_[i] >= a.Ho) {
+                h_[i] -= a.Ho;
+                n_[i] += 1;
+            }
+        }
+    }
+    template <int LD>
+    __device__ __forceinline__ void store(float (*S)[LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            if (idx < TOTAL) {
+                const int kr = idx / VPR;
+                const int c4 = (idx % VPR) * 4;
+                *reinterpret_cast<float4 *>(&S[kr][c4]) = r[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradArgs a) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ GemmSmem<BM, BN> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tn = blockIdx.x % a.tiles_n, tm = blockIdx.x / a.tiles_n;
+    const int ci0 = tm * BM, co0 = tn * BN;
+    const int tap = blockIdx.y;
+    const int m_begin = blockIdx.z * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    if (m_begin >= m_end) return;
+    const int nkt = (m_end - m_begin + GEMM_BK - 1) / GEMM_BK;
+
+    LoaderWgradA<BM> la;
+    la.init(a, ci0, tap, m_begin, tid);
+    LoaderMN<BN> lb;
+    lb.init(a.dy, a.Co, co0, a.Co, true, tid);
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[LoaderWgradA<BM>::NV], rb[LoaderMN<BN>::NV];
+    la.load(a, m_end, ra);
+    lb.load(m_begin, m_end, rb);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (more) {
+            la.advance(a);
+            la.load(a, m_end, ra);
+            lb.load(m_begin + (kt + 1) * GEMM_BK, m_end, rb);
+        }
+        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *dw = a.dw + (long long)tap * a.Ci * a.Co;
+    epilogue<BM, BN, WGM, WGN>(acc, dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, a.e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem / pooling / subsample elementwise kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void stem_im2col_kernel(const float *__restrict__ img, float *__restrict__ col, int N, int H, int W,
+                                   int Ho, int Wo, int ldcol, long long total_v) {
+    const int vpr = ldcol >> 2;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_v;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / vpr;
+        const int v = (int)(idx - m * vpr);
+        const int wo = (int)(m % Wo);
+        const long long t = m / Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = v * 4 + j;
+            float val = 0.0f;
+            if (k < 147) {
+                const int kh = k / 21;
+                const int rem = k - kh * 21;
+                const int kw = rem / 3;
+                const int c = rem - kw * 3;
+                const int hi = ho * 2 - 3 + kh, wi = wo * 2 - 3 + kw;
+                if (hi >= 0 && wi >= 0 && hi < H && wi < W) val = img[(((long long)n * H + hi) * W + wi) * 3 + c];
+            }
+            o[j] = val;
+        }
+        *reinterpret_cast<float4 *>(col + m * ldcol + v * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, uint8_t *__restrict__ amax,
+                                   int N, int H, int W, int C, int Ho, int Wo, long long total) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long t = idx / C;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
+                float v = 0.0f;  // the explicit ZeroPadding2D(1) takes part in the max
+                if (hi >= 0 && wi >= 0 && hi < H && wi < W) v = x[(((long long)n * H + hi) * W + wi) * C + c];
+                if (v > best) {
+                    best = v;
+                    bi = kh * 3 + kw;
+                }
+            }
+        y[idx] = best;
+        amax[idx] = (uint8_t)bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ amax,
+                                   const float *__restrict__ x, float *__restrict__ dx, int N, int H, int W, int C,
+                                   int Ho, int Wo, long long total) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long t = idx / C;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float g = 0.0f;
+        if (x[idx] > 0.0f) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int th = h + 1 - kh;
+                if (th < 0 || (th & 1)) continue;
+                const int ho = th >> 1;
+                if (ho >= Ho) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tw = w + 1 - kw;
+                    if (tw < 0 || (tw & 1)) continue;
+                    const int wo = tw >> 1;
+                    if (wo >= Wo) continue;
+                    const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + c;
+                    if (amax[o] == kh * 3 + kw) g += dy[o];
+                }
+            }
+        }
+        dx[idx] = g;
+    }
+}
+
+__global__ void subsample2_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4,
+                                      int Ho, int Wo, long long total) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long long t = idx / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long long n = t / Ho;
+        y[idx] = x[((n * H + 2 * ho) * W + 2 * wo) * C4 + c];
+    }
+}
+
+__global__ void subsample2_bwd_kernel(const float4 *__restrict__ dy, float4 *__restrict__ dx, int H, int W, int C4,
+                                      int Ho, int Wo, long long total) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long long t = idx / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const long long n = t / H;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(h & 1) && !(w & 1) && (h >> 1) < Ho && (w >> 1) < Wo)
+            v = dy[((n * Ho + (h >> 1)) * Wo + (w >> 1)) * C4 + c];
+        dx[idx] = v;
+    }
+}
+
+static inline int ew_grid(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+    ConvArgs a = a0;
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cd, BN);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static void launch_wgrad(const ConvWgradArgs &a0, int split, hipStream_t s) {
+    ConvWgradArgs a = a0;
+    a.tiles_m = cdiv(a.Ci, BM);
+    a.tiles_n = cdiv(a.Co, BN);
+    const int tiles = a.tiles_m * a.tiles_n;
+    if (split <= 0) {
+        split = cdiv(1536, tiles * 9);
+        const int max_split = cdiv(a.M, 256);
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    int rps = cdiv(a.M, split);
+    rps = ((rps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+    a.rows_per_split = rps;
+    split = cdiv(a.M, rps);
+    dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
+}
+
+}  // namespace detr
+
+using namespace detr;
+
+extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream) {
+    DETR_REQUIRE(d != nullptr, "conv3x3: null descriptor");
+    DETR_REQUIRE(mode >= 0 && mode <= 2, "conv3x3: bad mode %d", mode);
+    DETR_REQUIRE(d->stride == 1 || d->stride == 2, "conv3x3: stride %d unsupported", d->stride);
+    DETR_REQUIRE(d->Ci % 16 == 0 && d->Co % 16 == 0, "conv3x3: Ci=%d Co=%d must be multiples of 16", d->Ci, d->Co);
+    DETR_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - 3) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - 3) / d->stride + 1,
+                 "conv3x3: output %dx%d inconsistent with input %dx%d pad %d stride %d", d->Ho, d->Wo, d->Hi, d->Wi,
+                 d->pad, d->stride);
+    DETR_REQUIRE(d->x && d->w && d->y, "conv3x3: null operand");
+    DETR_REQUIRE(aligned16(d->x) && aligned16(d->w) && aligned16(d->y), "conv3x3: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    EpiArgs e;
+    e.alpha = d->alpha;
+    e.scale = d->scale;
+    e.bias = d->bias;
+    e.residual = d->residual;
+    e.mask = d->mask;
+    e.act = d->act;
+    e.atomic = 0;
+    if (mode == 2) {
+        DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0, "conv3x3 wgrad: only scale/alpha epilogue");
+        ConvWgradArgs a;
+        a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+        a.stride = d->stride; a.pad = d->pad;
+        a.x = d->x; a.dy = d->w; a.dw = d->y;
+        a.M = d->N * d->Ho * d->Wo;
+        e.atomic = 1; e.ldr = 0; e.ldmask = 0;
+        a.e = e;
+        if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, s);
+        else launch_wgrad<64, 64, 2, 2>(a, d->split, s);
+        DETR_LAUNCH_CHECK("conv3x3 wgrad");
+        return 0;
+    }
+    ConvArgs a;
+    a.N = d->N; a.stride = d->stride; a.pad = d->pad; a.Ci = d->Ci; a.Co = d->Co;
+    a.w = d->w; a.src = d->x; a.dst = d->y;
+    if (mode == 0) {
+        a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Ci;
+        a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Co;
+    } else {
+        a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Co;
+        a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Ci;
+    }
+    a.M = d->N * a.Hd * a.Wd;
+    e.ldr = a.Cd;
+    e.ldmask = a.Cd;
+    a.e = e;
+    const bool dgrad = mode == 1;
+    const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
+    if (a.Cd <= 64) {
+        launch_conv<128, 64, 2, 2>(a, dgrad, s);
+    } else if (big >= 192) {
+        launch_conv<128, 128, 2, 2>(a, dgrad, s);
+    } else {
+        launch_conv<64, 64, 2, 2>(a, dgrad, s);
+    }
+    DETR_LAUNCH_CHECK("conv3x3");
+    return 0;
+}
+
+extern "C" int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W, int32_t Ho,
+                                        int32_t Wo, int32_t ldcol, void *stream) {
+    DETR_REQUIRE(img && col, "stem_im2col: null operand");
+    DETR_REQUIRE(ldcol >= 148 && ldcol % 4 == 0, "stem_im2col: ldcol=%d must be >=148 and a multiple of 4", ldcol);
+    DETR_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "stem_im2col: bad output size");
+    DETR_REQUIRE(aligned16(col), "stem_im2col: col must be 16-byte aligned");
+    const long long total = (long long)N * Ho * Wo * (ldcol / 4);
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, img, col, N, H,
+                       W, Ho, Wo, ldcol, total);
+    DETR_LAUNCH_CHECK("stem_im2col");
+    return 0;
+}
+
+extern "C" int detr_hip_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W,
+                                             int32_t C, int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(x && y && argmax, "maxpool fwd: null operand");
+    DETR_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool fwd: bad output size");
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N,
+                       H, W, C, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("maxpool fwd");
+    return 0;
+}
+
+extern "C" int detr_hip_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, const float *x, float *dx, int32_t N,
+                                             int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(dy && argmax && x && dx, "maxpool bwd: null operand");
+    const long long total = (long long)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, argmax, x,
+                       dx, N, H, W, C, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("maxpool bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_subsample2_fwd_f32(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(x && y && C % 4 == 0 && aligned16(x) && aligned16(y), "subsample2 fwd: bad operands");
+    DETR_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "subsample2 fwd: bad output size");
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(subsample2_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)x, (float4 *)y, H, W, C / 4, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("subsample2 fwd");
+    return 0;
+}
+
+extern "C" int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(dy && dx && C % 4 == 0 && aligned16(dy) && aligned16(dx), "subsample2 bwd: bad operands");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)dy, (float4 *)dx, H, W, C / 4, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("subsample2 bwd");
+    return 0;
+}

@@ -1,0 +1,247 @@
+// gemm_core.h -- the fp32 MFMA tile engine shared by the plain GEMM and the implicit-GEMM
+// 3x3 convolution kernels (gfx950 / CDNA4).
+//
+// Design (MI355X-first, see DESIGN.md "K2 GEMM"):
+//   * v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain) at 157 TF peak; one f32 VGPR per
+//     operand per lane, 16 accumulator registers per 32x32 tile.
+//   * 256 threads = 4 waves arranged WGM x WGN; each wave owns TM x TN tiles of 32x32.
+//   * operands are staged K-major in LDS ( S[k][m] ): a fragment read is one ds_read_b32 per
+//     lane with lanes 0..31 on consecutive dwords of row k and lanes 32..63 on row k+1 ->
+//     conflict free; rows are padded by 4 dwords so that the transposing ds_write_b32 of a
+//     K-contiguous global operand is at most 2-way conflicted (free on ds_write_b32).
+//   * global -> register -> LDS software pipeline, double-buffered LDS, ONE barrier per K tile:
+//     the loads of tile t+1 are in flight while tile t is multiplied.
+//   * workgroup -> tile mapping is XCD-aware (8 XCDs, private L2s): each XCD walks a contiguous
+//     run of tiles with the N index fastest, so the A panel of a row block is fetched into one
+//     L2 only.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace detr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_PAD = 4;
+
+struct EpiArgs {
+    float alpha;
+    const float *scale;
+    const float *bias;
+    const float *residual;
+    long long ldr;
+    const float *mask;
+    long long ldmask;
+    int act;     // 0 none 1 relu 2 sigmoid
+    int atomic;  // 1: atomicAdd into C (split-K / wgrad)
+};
+
+template <int BM, int BN>
+struct GemmSmem {
+    static constexpr int LDA = BM + GEMM_PAD;
+    static constexpr int LDB = BN + GEMM_PAD;
+    float A[2][GEMM_BK][LDA];
+    float B[2][GEMM_BK][LDB];
+};
+
+// bijective XCD-aware remap of a linear workgroup id (guide T1, bijective variant)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float4 ld4_guard(const float *p, int nvalid, bool vec) {
+    // nvalid = number of in-range elements starting at p (may be <= 0)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && vec) {
+        v = *reinterpret_cast<const float4 *>(p);
+    } else {
+        if (nvalid > 0) v.x = p[0];
+        if (nvalid > 1) v.y = p[1];
+        if (nvalid > 2) v.z = p[2];
+        if (nvalid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loader for an operand stored [mn][k] with k contiguous (row stride ld).
+// Thread t handles float4 (row = (t>>2) + 64*i, k = (t&3)*4 .. +3) of the BMN x 16 tile.
+// ---------------------------------------------------------------------------------------------
+template <int BMN>
+struct LoaderK {
+    static constexpr int NV = (BMN >= 64) ? BMN / 64 : 1;
+    const float *ptr;
+    long long off[NV];
+    bool ok[NV];
+    bool vec;
+    int kq;
+    int tid;
+
+    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, bool vec_, int tid_) {
+        ptr = p;
+        vec = vec_;
+        tid = tid_;
+        kq = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            const int g = mn0 + row;
+            ok[i] = (row < BMN) && (g < MN);
+            off[i] = (long long)g * ld;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i] = ok[i] ? ld4_guard(ptr + off[i] + k, K - k, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    template <int LD>
+    __device__ __forceinline__ void store(float (*S)[LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            if (row < BMN) {
+                S[kq + 0][row] = r[i].x;
+                S[kq + 1][row] = r[i].y;
+                S[kq + 2][row] = r[i].z;
+                S[kq + 3][row] = r[i].w;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Loader for an operand stored [k][mn] with mn contiguous (row stride ld).
+// float4 index idx = t + 256*i : k row = idx / (BMN/4), column = (idx % (BMN/4))*4.
+// ---------------------------------------------------------------------------------------------
+template <int BMN>
+struct LoaderMN {
+    static constexpr int VPR = BMN / 4;
+    static constexpr int TOTAL = GEMM_BK * VPR;
+    static constexpr int NV = (TOTAL >= GEMM_THREADS) ? TOTAL / GEMM_THREADS : 1;
+    const float *ptr;
+    long long ld;
+    int mn0, MN;
+    bool vec;
+    int tid;
+
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, bool vec_, int tid_) {
+        ptr = p;
+        ld = ld_;
+        mn0 = mn0_;
+        MN = MN_;
+        vec = vec_;
+        tid = tid_;
+    }
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            const int kr = idx / VPR;
+            const int c4 = (idx % VPR) * 4;
+            const int k = k0 + kr;
+            const int col = mn0 + c4;
+            if (idx < TOTAL && k < K && col < MN) {
+                r[i] = ld4_guard(ptr + (long long)k * ld + col, MN - col, vec);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    template <int LD>
+    __device__ __forceinline__ void store(float (*S)[LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + GEMM_THREADS * i;
+            if (idx < TOTAL) {
+                const int kr = idx / VPR;
+                const int c4 = (idx % VPR) * 4;
+                *reinterpret_cast<float4 *>(&S[kr][c4]) = r[i];
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// One K tile of MFMAs out of LDS.
+// MFMA 32x32x2 f32 operand map: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+struct TileCfg {
+    static constexpr int WTM = BM / WGM;
+    static constexpr int WTN = BN / WGN;
+    static constexpr int TM = WTM / 32;
+    static constexpr int TN = WTN / 32;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void mma_ktile(const float (*As)[BM + GEMM_PAD], const float (*Bs)[BN + GEMM_PAD],
+                                          f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                          int wm, int wn, int lane) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    const int l31 = lane & 31;
+    const int kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK; kk += 2) {
+        float a[T::TM], b[T::TN];
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi) a[mi] = As[kk + kh][wm * T::WTM + mi * 32 + l31];
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni) b[ni] = Bs[kk + kh][wn * T::WTN + ni * 32 + l31];
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                         float *C, long long ldc, int M, int N, int m0, int n0, int wm, int wn,
+                                         int lane, const EpiArgs &e) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    const int l31 = lane & 31;
+    const int rh = (lane >> 5) * 4;
+#pragma unroll
+    for (int ni = 0; ni < T::TN; ++ni) {
+        const int col = n0 + wn * T::WTN + ni * 32 + l31;
+        if (col >= N) continue;
+        const float sc = e.scale ? e.scale[col] : 1.0f;
+        const float bi = e.bias ? e.bias[col] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi) {
+            const int rbase = m0 + wm * T::WTM + mi * 32 + rh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) {
+                    float v = acc[mi][ni][r];
+                    v = v * sc + bi;
+                    v *= e.alpha;
+                    if (e.residual) v += e.residual[(long long)row * e.ldr + col];
+                    if (e.act == 1) v = fmaxf(v, 0.0f);
+                    else if (e.act == 2) v = 1.0f / (1.0f + __expf(-v));
+                    if (e.mask) v = (e.mask[(long long)row * e.ldmask + col] > 0.0f) ? v : 0.0f;
+                    float *dst = C + (long long)row * ldc + col;
+                    if (e.atomic) unsafeAtomicAdd(dst, v);
+                    else *dst = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace detr

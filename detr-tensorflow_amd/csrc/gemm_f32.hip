@@ -1,0 +1,156 @@
+// gemm_f32.hip -- generic batched fp32 GEMM with fused epilogue on the MFMA tile engine.
+// Replaces every tf.matmul / 1x1 Conv2D / Linear of the reference's hot path and their
+// gradients (see include/detr_hip.h for the reference lines).
+#include "gemm_core.h"
+
+namespace detr {
+
+struct GemmArgs {
+    int M, N, K;
+    const float *A; long long lda;
+    const float *B; long long ldb;
+    float *C; long long ldc;
+    int batch_inner;
+    long long sA0, sA1, sB0, sB1, sC0, sC1;
+    int split_k;
+    int tiles_m, tiles_n;
+    int a_vec, b_vec;
+    EpiArgs e;
+};
+
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ GemmSmem<BM, BN> sm;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = id % g.tiles_n, tm = id / g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z;
+    const int split = z % g.split_k;
+    const int zb = z / g.split_k;
+    const int z0 = zb / g.batch_inner, z1 = zb % g.batch_inner;
+    const float *A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float *B = g.B + z0 * g.sB0 + z1 * g.sB1;
+    float *C = g.C + z0 * g.sC0 + z1 * g.sC1;
+
+    const int nkt = (g.K + GEMM_BK - 1) / GEMM_BK;
+    const int per = (nkt + g.split_k - 1) / g.split_k;
+    const int kt0 = split * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;   // empty split (uniform per workgroup)
+
+    using LA = typename std::conditional<AK, LoaderK<BM>, LoaderMN<BM>>::type;
+    using LB = typename std::conditional<BKC, LoaderK<BN>, LoaderMN<BN>>::type;
+    LA la;
+    LB lb;
+    la.init(A, g.lda, m0, g.M, g.a_vec != 0, tid);
+    lb.init(B, g.ldb, n0, g.N, g.b_vec != 0, tid);
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[LA::NV], rb[LB::NV];
+    la.load(kt0 * GEMM_BK, g.K, ra);
+    lb.load(kt0 * GEMM_BK, g.K, rb);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) {
+            la.load((kt + 1) * GEMM_BK, g.K, ra);
+            lb.load((kt + 1) * GEMM_BK, g.K, rb);
+        }
+        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    epilogue<BM, BN, WGM, WGN>(acc, C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, g.e);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
+    GemmArgs a = g;
+    a.tiles_m = cdiv(g.M, BM);
+    a.tiles_n = cdiv(g.N, BN);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
+    dim3 block(GEMM_THREADS);
+    if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+    return 0;
+}
+
+}  // namespace detr
+
+using namespace detr;
+
+extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
+    DETR_REQUIRE(d != nullptr, "gemm: null descriptor");
+    DETR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    DETR_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
+    const int batch = d->batch > 0 ? d->batch : 1;
+    const int inner = d->batch_inner > 0 ? d->batch_inner : 1;
+    const int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > 1) {
+        DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0,
+                     "gemm: split_k allows only scale/alpha in the epilogue");
+    }
+    DETR_REQUIRE((long long)batch * split <= 65535, "gemm: batch*split_k=%lld exceeds grid.z", (long long)batch * split);
+
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.A = d->A; g.lda = d->lda;
+    g.B = d->B; g.ldb = d->ldb;
+    g.C = d->C; g.ldc = d->ldc;
+    g.batch_inner = inner;
+    g.sA0 = d->sA0; g.sA1 = d->sA1; g.sB0 = d->sB0; g.sB1 = d->sB1; g.sC0 = d->sC0; g.sC1 = d->sC1;
+    g.split_k = split;
+    g.tiles_m = g.tiles_n = 0;
+    auto strides_ok = [](long long ld, long long s0, long long s1) { return (ld % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0); };
+    g.a_vec = aligned16(d->A) && strides_ok(d->lda, d->sA0, d->sA1);
+    g.b_vec = aligned16(d->B) && strides_ok(d->ldb, d->sB0, d->sB1);
+    g.e.alpha = d->alpha;
+    g.e.scale = d->scale;
+    g.e.bias = d->bias;
+    g.e.residual = d->residual; g.e.ldr = d->ldr;
+    g.e.mask = d->mask; g.e.ldmask = d->ldmask;
+    g.e.act = d->act;
+    g.e.atomic = split > 1 ? 1 : 0;
+
+    const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
+    hipStream_t s = (hipStream_t)stream;
+    // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
+    const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
+    if (d->N <= 32) {
+        launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
+    } else if (d->N <= 64) {
+        if ((long long)cdiv(d->M, 128) * batch * split >= 128) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
+        else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
+    } else if (big_tiles >= 192) {
+        launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
+    } else {
+        launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
+    }
+    DETR_LAUNCH_CHECK("gemm");
+    return 0;
+}

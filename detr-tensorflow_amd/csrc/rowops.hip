@@ -1,0 +1,381 @@
+// rowops.hip -- HBM-bound row / elementwise kernels of the transformer and the backbone glue
+// (LayerNorm, attention softmax, bias-gradient column sums, broadcast adds, sigmoid/ReLU
+// backward, frozen-BN folding).  One wave64 per row for the row kernels, float4 accesses,
+// wave shuffles for the reductions.  Reference lines: see include/detr_hip.h.
+#include "common.h"
+
+namespace detr {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim C (C % 4 == 0, C <= 1024): one wave per row, each lane holds
+// up to 4 float4 (lane-strided so that a wave reads 1 KiB contiguous per step).
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ y,
+                                                            float *__restrict__ mean, float *__restrict__ rstd,
+                                                            int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int nv = C >> 2;  // float4 per row
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (long long)row * C);
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = (j < nv) ? xr[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        const float var = wave_sum(q) / (float)C;
+        const float rs = rsqrtf(var + eps);
+        float4 *yr = reinterpret_cast<float4 *>(y + (long long)row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nv) {
+                const float4 g = reinterpret_cast<const float4 *>(gamma)[j];
+                const float4 b = reinterpret_cast<const float4 *>(beta)[j];
+                float4 o;
+                o.x = (v[i].x - mu) * rs * g.x + b.x;
+                o.y = (v[i].y - mu) * rs * g.y + b.y;
+                o.z = (v[i].z - mu) * rs * g.z + b.z;
+                o.w = (v[i].w - mu) * rs * g.w + b.w;
+                yr[j] = o;
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; dgamma += sum dy*xhat ; dbeta += sum dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, float *__restrict__ dx,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                            int rows, int C) {
+    __shared__ float red[2][4][64 * LN_MAXV * 4 / 4];  // [gamma|beta][wave][C] ; C <= 1024 -> see below
+    // (partial sums are kept per lane in registers and reduced through LDS at the end)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int nv = C >> 2;
+    float4 pg[LN_MAXV], pb[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        pg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (long long)row * C);
+        const float4 *dr = reinterpret_cast<const float4 *>(dy + (long long)row * C);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nv) {
+                const float4 xv = xr[j], dv = dr[j];
+                const float4 gm = reinterpret_cast<const float4 *>(gamma)[j];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                pg[i].x += dv.x * xh[i].x; pg[i].y += dv.y * xh[i].y; pg[i].z += dv.z * xh[i].z; pg[i].w += dv.w * xh[i].w;
+                pb[i].x += dv.x; pb[i].y += dv.y; pb[i].z += dv.z; pb[i].w += dv.w;
+            } else {
+                xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g[i] = xh[i];
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)C;
+        const float m2 = wave_sum(s2) / (float)C;
+        float4 *oxr = reinterpret_cast<float4 *>(dx + (long long)row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nv) {
+                float4 o;
+                o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                oxr[j] = o;
+            }
+        }
+    }
+    // block reduction of the per-wave column partials, then one atomic per column per block
+    float *rg = &red[0][0][0];
+    float *rb = &red[1][0][0];
+    // layout red[which][wave][256] only holds C<=256 per pass: loop over the LN_MAXV chunks
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int j = lane + 64 * i;  // float4 index
+        __syncthreads();
+        rg[wave * 256 + lane * 4 + 0] = pg[i].x; rg[wave * 256 + lane * 4 + 1] = pg[i].y;
+        rg[wave * 256 + lane * 4 + 2] = pg[i].z; rg[wave * 256 + lane * 4 + 3] = pg[i].w;
+        rb[wave * 256 + lane * 4 + 0] = pb[i].x; rb[wave * 256 + lane * 4 + 1] = pb[i].y;
+        rb[wave * 256 + lane * 4 + 2] = pb[i].z; rb[wave * 256 + lane * 4 + 3] = pb[i].w;
+        __syncthreads();
+        if (wave == 0 && j < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sg = 0.f, sb = 0.f;
+                for (int w = 0; w < wpb; ++w) {
+                    sg += rg[w * 256 + lane * 4 + e];
+                    sb += rb[w * 256 + lane * 4 + e];
+                }
+                unsafeAtomicAdd(dgamma + j * 4 + e, sg);
+                unsafeAtomicAdd(dbeta + j * 4 + e, sb);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention softmax over rows of the score tensor (in place) and its backward.
+// One wave per row, three passes over an L1/L2 resident row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float *__restrict__ s, long long rows, int cols,
+                                                               long long ld) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
+         row += (long long)gridDim.x * wpb) {
+        float *r = s + row * ld;
+        float mx = -INFINITY;
+        for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, r[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < cols; j += 64) {
+            const float e = expf(r[j] - mx);
+            r[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < cols; j += 64) r[j] = r[j] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__restrict__ p, float *__restrict__ dp,
+                                                               long long rows, int cols, long long ld) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
+         row += (long long)gridDim.x * wpb) {
+        const float *pr = p + row * ld;
+        float *dr = dp + row * ld;
+        float dot = 0.f;
+        for (int j = lane; j < cols; j += 64) dot += pr[j] * dr[j];
+        dot = wave_sum(dot);
+        for (int j = lane; j < cols; j += 64) dr[j] = pr[j] * (dr[j] - dot);
+    }
+}
+
+// out[c] += alpha * sum_r x[r*ld + c] ; grid (col blocks of 256, row chunks)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long rows,
+                                                     int cols, long long ld, float alpha, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    float s0 = 0.f, s1 = 0.f;
+    long long r = r0;
+    for (; r + 1 < r1; r += 2) {
+        s0 += x[r * ld + c];
+        s1 += x[(r + 1) * ld + c];
+    }
+    if (r < r1) s0 += x[r * ld + c];
+    unsafeAtomicAdd(out + c, alpha * (s0 + s1));
+}
+
+__global__ void add_bcast_kernel(const float4 *__restrict__ x, const float4 *__restrict__ p, float4 *__restrict__ out,
+                                 long long n4, long long period4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = x[i], b = p[i % period4];
+        out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+__global__ void sigmoid_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dz,
+                                   long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = y[i];
+        dz[i] = dy[i] * v * (1.0f - v);
+    }
+}
+
+__global__ void relu_mask_kernel(const float *__restrict__ g, const float *__restrict__ ref, float *__restrict__ out,
+                                 long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = ref[i] > 0.0f ? g[i] : 0.0f;
+}
+
+__global__ void scale_cols_kernel(const float *__restrict__ w, const float *__restrict__ scale, float *__restrict__ o,
+                                  long long n, int cols) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        o[i] = w[i] * scale[i % cols];
+}
+
+__global__ void bn_fold_kernel(const float *__restrict__ weight, const float *__restrict__ bias,
+                               const float *__restrict__ mean, const float *__restrict__ var, float *__restrict__ scale,
+                               float *__restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float s = weight[c] * rsqrtf(var[c] + eps);
+        scale[c] = s;
+        shift[c] = bias[c] - mean[c] * s;
+    }
+}
+
+__global__ void axpy_kernel(float *__restrict__ acc, const float *__restrict__ g, float a, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc[i] += a * g[i];
+}
+
+static inline int ew_grid(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace detr
+
+using namespace detr;
+
+extern "C" int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                                          float *rstd, int32_t rows, int32_t C, float eps, void *stream) {
+    DETR_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm fwd: null operand");
+    DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm fwd: C=%d rows=%d unsupported", C, rows);
+    DETR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm fwd: alignment");
+    const int grid = min(cdiv(rows, 4), 4096);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
+                       rows, C, eps);
+    DETR_LAUNCH_CHECK("layernorm fwd");
+    return 0;
+}
+
+extern "C" int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
+                                          const float *rstd, float *dx, float *dgamma, float *dbeta, int32_t rows,
+                                          int32_t C, void *stream) {
+    DETR_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm bwd: null operand");
+    DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm bwd: C=%d rows=%d unsupported", C, rows);
+    DETR_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma), "layernorm bwd: alignment");
+    const int grid = min(cdiv(rows, 16), 512);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx,
+                       dgamma, dbeta, rows, C);
+    DETR_LAUNCH_CHECK("layernorm bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream) {
+    DETR_REQUIRE(s && rows > 0 && cols > 0 && ld >= cols, "softmax fwd: bad args");
+    const int grid = (int)((rows + 3) / 4 > 16384 ? 16384 : (rows + 3) / 4);
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (long long)rows, cols,
+                       (long long)ld);
+    DETR_LAUNCH_CHECK("softmax fwd");
+    return 0;
+}
+
+extern "C" int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,
+                                             void *stream) {
+    DETR_REQUIRE(p && dp && rows > 0 && cols > 0 && ld >= cols, "softmax bwd: bad args");
+    const int grid = (int)((rows + 3) / 4 > 16384 ? 16384 : (rows + 3) / 4);
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, dp, (long long)rows,
+                       cols, (long long)ld);
+    DETR_LAUNCH_CHECK("softmax bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha,
+                                   void *stream) {
+    DETR_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad args");
+    int rpb = 64;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    dim3 grid((unsigned)cdiv(cols, 256), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, cols,
+                       (long long)ld, alpha, rpb);
+    DETR_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n, int64_t period,
+                                      void *stream) {
+    DETR_REQUIRE(x && p && out && n > 0 && period > 0, "add_bcast: bad args");
+    DETR_REQUIRE(n % 4 == 0 && period % 4 == 0 && aligned16(x) && aligned16(p) && aligned16(out), "add_bcast: alignment");
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x,
+                       (const float4 *)p, (float4 *)out, (long long)(n / 4), (long long)(period / 4));
+    DETR_LAUNCH_CHECK("add_bcast");
+    return 0;
+}
+
+extern "C" int detr_hip_add_f32(const float *a, const float *b, float *out, int64_t n, void *stream) {
+    DETR_REQUIRE(a && b && out && n > 0, "add: bad args");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);
+    DETR_LAUNCH_CHECK("add");
+    return 0;
+}
+
+extern "C" int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *dz, int64_t n, void *stream) {
+    DETR_REQUIRE(dy && y && dz && n > 0, "sigmoid_bwd: bad args");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz,
+                       (long long)n);
+    DETR_LAUNCH_CHECK("sigmoid_bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_relu_mask_f32(const float *g, const float *ref, float *out, int64_t n, void *stream) {
+    DETR_REQUIRE(g && ref && out && n > 0, "relu_mask: bad args");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, ref, out,
+                       (long long)n);
+    DETR_LAUNCH_CHECK("relu_mask");
+    return 0;
+}
+
+extern "C" int detr_hip_scale_cols_f32(const float *w, const float *scale, float *w_out, int64_t rows, int32_t cols,
+                                       void *stream) {
+    DETR_REQUIRE(w && scale && w_out && rows > 0 && cols > 0, "scale_cols: bad args");
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, scale, w_out, n,
+                       cols);
+    DETR_LAUNCH_CHECK("scale_cols");
+    return 0;
+}
+
+extern "C" int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *mean, const float *var,
+                                    float *scale, float *shift, int32_t C, float eps, void *stream) {
+    DETR_REQUIRE(weight && bias && mean && var && scale && shift && C > 0, "bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, mean, var,
+                       scale, shift, C, eps);
+    DETR_LAUNCH_CHECK("bn_fold");
+    return 0;
+}
+
+extern "C" int detr_hip_axpy_f32(float *acc, const float *g, float a, int64_t n, void *stream) {
+    DETR_REQUIRE(acc && g && n > 0, "axpy: bad args");
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, acc, g, a, (long long)n);
+    DETR_LAUNCH_CHECK("axpy");
+    return 0;
+}

@@ -1,0 +1,211 @@
+/* detr_hip.h -- C ABI of libdetr_hip.so: the MI355X (gfx950) hot path of DETR
+ * (ResNet backbone convolutions, transformer GEMMs/attention pieces, Hungarian set loss,
+ * clip+Adam) as hand-written HIP kernels.
+ *
+ * The reference (Visual-Behavior/detr-tensorflow) has NO native/FFI boundary: its hot path is
+ * TensorFlow ops plus one host callback into SciPy.  Each entry point below therefore cites the
+ * reference Python lines whose arithmetic it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch.Tensor storage); nothing is
+ *     allocated, freed or synchronised inside; every call only enqueues work on `stream`
+ *     (a hipStream_t passed as void*) and is safe to capture in a hipGraph;
+ *   - all arithmetic is fp32 ("f32" in the names); indices are int32 on the device;
+ *   - return value: 0 = ok, negative = rejected (bad shape / alignment / launch failure); the
+ *     reason is retrievable with detr_hip_last_error() (thread-local);
+ *   - thread-safe for distinct streams.
+ */
+#ifndef DETR_HIP_H
+#define DETR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DETR_HIP_ABI_VERSION 1
+
+const char *detr_hip_last_error(void);
+int detr_hip_abi_version(void);
+/* hipMemsetAsync wrapper (zero-fill of accumulators) */
+int detr_hip_memset_zero(void *ptr, size_t bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic batched GEMM with fused epilogue:   C = epi( A(MxK) * B(KxN) )
+ *   replaces: every tf.matmul / 1x1 Conv2D / Linear on the path --
+ *     detr_tf/networks/custom_layers.py:49-50 (Linear), resnet_backbone.py:101,107,111 (1x1 convs),
+ *     detr.py:44 (input_proj), transformer.py:294-304,317,343,346 (MHA projections, QK^T, PV),
+ *     and their tape gradients (optimizers.py:115): dgrad and wgrad are the same kernel with
+ *     other operand layouts.
+ *   epilogue, in this order:  v = acc; v *= scale[n]; v += bias[n]; v *= alpha;
+ *                             v += residual[m,n]; act(v); v = mask[m,n] > 0 ? v : 0
+ *     (frozen-BN fold custom_layers.py:21-24, bias, q-scaling transformer.py:307, residual adds,
+ *      ReLU, sigmoid detr.py:188, ReLU-backward masking)
+ *   a_kcontig = 1: A[m*lda + k]   0: A[k*lda + m]        (same for B with n)
+ *   batch z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner, operand offset z0*s?0 + z1*s?1
+ *   split_k > 1: the K range is split over split_k workgroups whose partial results are
+ *     atomically ADDED to C (C must hold zeros or the value to accumulate onto); only
+ *     scale and alpha are allowed in the epilogue then.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, N, K;
+    const float *A; int64_t lda; int32_t a_kcontig;
+    const float *B; int64_t ldb; int32_t b_kcontig;
+    float *C; int64_t ldc;
+    int32_t batch, batch_inner;
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+    float alpha;
+    const float *scale;
+    const float *bias;
+    const float *residual; int64_t ldr;
+    const float *mask; int64_t ldmask;
+    int32_t act;            /* 0 none, 1 relu, 2 sigmoid */
+    int32_t split_k;        /* 0/1 = no split */
+} detr_gemm_desc;
+int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution (explicit zero pad `pad`, then VALID, stride 1|2, dilation 1), NHWC / HWIO,
+ * as an implicit GEMM (no im2col buffer):
+ *   replaces: ZeroPadding2D + Conv2D(3x3) + FrozenBatchNorm2D + ReLU
+ *             detr_tf/networks/resnet_backbone.py:98,104-105,123-126 and its gradients.
+ *   mode 0 fwd  : y[N,Ho,Wo,Co]  = epi( conv(x[N,Hi,Wi,Ci], w[3,3,Ci,Co]) )
+ *   mode 1 dgrad: dx[N,Hi,Wi,Ci] = epi( conv^T(dy[N,Ho,Wo,Co], w) )          (x = dy in, y = dx out)
+ *   mode 2 wgrad: dw[3,3,Ci,Co] += scale[co] * sum_m x[pix(m,tap),ci] * dy[m,co]   (atomic; y = dw)
+ *   epilogue fields as in detr_gemm_desc (rows = output pixels, ld = channel count).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad;
+    const float *x;      /* fwd: input; dgrad: dy; wgrad: input x */
+    const float *w;      /* fwd/dgrad: weights; wgrad: dy */
+    float *y;            /* fwd: output; dgrad: dx; wgrad: dw (pre-zeroed / accumulated onto) */
+    float alpha;
+    const float *scale;
+    const float *bias;
+    const float *residual;
+    const float *mask;
+    int32_t act;
+    int32_t split;       /* wgrad: number of row splits (0 = auto) */
+} detr_conv3x3_desc;
+int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stem helpers (detr_tf/networks/resnet_backbone.py:11-26):
+ *   im2col of the 7x7 stride-2 pad-3 conv on a 3-channel NHWC image into rows of `ldcol`
+ *   (>= 147, multiple of 4) floats, k = (kh*7+kw)*3+c, tail zero -- the GEMM above does the conv;
+ *   3x3 stride-2 max pool over the ZERO-padded (pad 1) map (padding takes part in the max, as
+ *   ZeroPadding2D + MaxPool2D('valid') does) with argmax for the backward;
+ *   maxpool backward fused with the stem ReLU mask.
+ * ------------------------------------------------------------------------------------------- */
+int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W,
+                             int32_t Ho, int32_t Wo, int32_t ldcol, void *stream);
+int detr_hip_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H,
+                                  int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
+/* dx[n,h,w,c] = (x[n,h,w,c] > 0) * sum over windows whose argmax is (h,w) of dy */
+int detr_hip_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, const float *x, float *dx,
+                                  int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                                  void *stream);
+/* stride-2 1x1 downsample helpers (resnet_backbone.py:111-113): gather / zero-filled scatter */
+int detr_hip_subsample2_fwd_f32(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t Ho, int32_t Wo, void *stream);
+int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t Ho, int32_t Wo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row kernels of the transformer (detr_tf/networks/transformer.py):
+ *   LayerNormalization(eps) over the last dim C (C % 4 == 0, C <= 1024) :151-152,169-170,177
+ *   softmax over rows of the score tensor :340, and their backwards;
+ *   column sums (bias gradients), broadcast add (src + pos :161-163, tgt + query_pos :209),
+ *   sigmoid backward (detr.py:188).
+ * ------------------------------------------------------------------------------------------- */
+int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, float *y,
+                               float *mean, float *rstd, int32_t rows, int32_t C, float eps, void *stream);
+/* dgamma/dbeta are ACCUMULATED (atomic) */
+int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
+                               const float *rstd, float *dx, float *dgamma, float *dbeta,
+                               int32_t rows, int32_t C, void *stream);
+int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream);
+/* ds = p * (dp - sum(dp*p)), written over dp */
+int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,
+                                  void *stream);
+/* out[c] += alpha * sum_r x[r*ld + c] (atomic) */
+int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha,
+                        void *stream);
+/* out[i] = x[i] + p[i % period]   (n, period multiples of 4) */
+int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n, int64_t period,
+                           void *stream);
+/* out[i] = a[i] + b[i] */
+int detr_hip_add_f32(const float *a, const float *b, float *out, int64_t n, void *stream);
+/* dz[i] = dy[i] * y[i] * (1 - y[i]) */
+int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *dz, int64_t n, void *stream);
+/* out[i] = (ref[i] > 0) ? g[i] : 0 */
+int detr_hip_relu_mask_f32(const float *g, const float *ref, float *out, int64_t n, void *stream);
+/* w_out[k, co] = w[k, co] * scale[co]   (frozen-BN scale folded into conv kernels, HWIO flat) */
+int detr_hip_scale_cols_f32(const float *w, const float *scale, float *w_out, int64_t rows, int32_t cols,
+                            void *stream);
+/* frozen BN vectors -> (scale, shift)  custom_layers.py:21-23 */
+int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *mean, const float *var,
+                         float *scale, float *shift, int32_t C, float eps, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,
+ * detr_tf/bbox.py:29-124,171-183).  P = levels * B problems; prediction p of level lv, image b:
+ *   logits + lv*sL_l + b*sL_b + q*sL_q + c ,  boxes + lv*sB_l + b*sB_b + q*sB_q + k
+ * targets in the reference's header layout (detr_tf/data/processing.py:35-55):
+ *   t_bbox [B, R, 4] f32 (row 0 = [n,0,0,0]), t_class [B, R] int64 (row 0 = 0).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t levels, B, Q, C, R;        /* R = target rows incl. header (100) */
+    const float *logits; int64_t sL_l, sL_b, sL_q;
+    const float *boxes;  int64_t sB_l, sB_b, sB_q;
+    const float *t_bbox; const int64_t *t_class;
+    int32_t background_class;
+} detr_setloss_desc;
+
+/* K12: cost[p][q][j] (ld = R-1 per q) = 5*L1 + 1*(-softmax[class_j]) + 2*(-GIoU)   hungarian_matching.py:171-195 */
+int detr_hip_match_cost_f32(const detr_setloss_desc *d, float *cost, void *stream);
+/* K13: exact rectangular assignment per problem (replaces the tf.numpy_function -> SciPy call,
+ *   hungarian_matching.py:27-46,197).  cost [P][Q][ldc] f32, n[P] taken from the t_bbox headers
+ *   (n_from_header[b*R*4]) ; outputs tgt_for_pred [P][Q] int32 (-1 = unmatched prediction = the
+ *   complement of the reference's bool selector) and pred_for_tgt [P][ldc] int32 (-1 padded).
+ *   status[P]: 0 ok, 1 infeasible/NaN (the reference raises there). */
+int detr_hip_assign_f32(const float *cost, int32_t P, int32_t Q, int32_t ldc, const float *t_bbox,
+                        int32_t B, int32_t R, int32_t *tgt_for_pred, int32_t *pred_for_tgt,
+                        int32_t *status, void *stream);
+/* K14: loss.py:37-96.  Three steps so that data-parallel ranks can all-reduce `sums` in between:
+ *   sums [levels][8] = {sum w*CE, sum w, n_neg_correct, n_neg, n_pos, n_pos_not_bg, n_pos_correct, -}
+ *                      {.. [7] unused};  box sums [levels][2] are stored at sums + levels*8:
+ *                      {sum L1, sum (1-GIoU)} ; all ACCUMULATED atomically (zero them first). */
+int detr_hip_set_loss_sums_f32(const detr_setloss_desc *d, const int32_t *tgt_for_pred, float *sums,
+                               void *stream);
+/* losses [levels][6] = label_cost,true_neg,true_pos,pos_accuracy,giou_loss,l1_loss (loss.py:172-179);
+ * total[0] = sum_lv 1*label + 2*giou + 5*l1 (loss.py:6-19) */
+int detr_hip_set_loss_finalize_f32(const float *sums, int32_t levels, float *losses, float *total,
+                                   void *stream);
+/* gradients of loss_scale*total w.r.t. logits and boxes (same strides as the inputs) */
+int detr_hip_set_loss_grad_f32(const detr_setloss_desc *d, const int32_t *tgt_for_pred, const float *sums,
+                               float loss_scale, float *d_logits, float *d_boxes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser (detr_tf/optimizers.py:86-88,137-163): per-tensor clip-by-norm then Keras Adam on
+ * a flat fp32 parameter buffer.  Tensor t occupies [seg_off[t], seg_off[t+1]) ; chunk c of
+ * `chunk` elements belongs to tensor chunk_tensor[c] and starts at chunk_start[c].
+ *   hyper (device, float[8]) = {lr_t group0, lr_t group1, lr_t group2, clipnorm, beta1, beta2, eps, -}
+ *   with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host each step.
+ * ------------------------------------------------------------------------------------------- */
+int detr_hip_sumsq_segments_f32(const float *g, const int32_t *chunk_tensor, const int64_t *chunk_start,
+                                const int64_t *seg_end, int32_t n_chunks, int32_t chunk, float *sumsq,
+                                void *stream);
+int detr_hip_clip_adam_f32(float *param, const float *g, float *m, float *v, const int32_t *chunk_tensor,
+                           const int64_t *chunk_start, const int64_t *seg_end, const int32_t *tensor_group,
+                           const float *sumsq, const float *hyper, int32_t n_chunks, int32_t chunk,
+                           void *stream);
+/* acc[i] += g[i] (gradient accumulation optimizers.py:157) */
+int detr_hip_axpy_f32(float *acc, const float *g, float a, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETR_HIP_H */
