@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one DETR-R50 training step (forward with training=True, Hungarian
+set loss with 5 aux levels, backward, per-tensor clipnorm, 3x Adam) at 800x1333, batch 8 per GPU,
+fp32, synthetic data, random-init weights (BASELINE.json metric / SURVEY.md 8d).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel family timed live with HIP
+events on the launch stream; `cpu_baseline` = the CPU oracle (restatement of the TF reference; TF
+is not installable here) timed on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "detr-tensorflow_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FWD_GFLOP_PER_IMAGE = 203.3          # SURVEY.md 8d (R50, 800x1333, Q=100)
+STEP_GFLOP_PER_IMAGE = 610.0         # fwd + dgrad + wgrad
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def make_targets(B, rng, rows=100):
+    """SURVEY.md 8d synthetic targets in the header layout of detr_tf/data/processing.py:35-55."""
+    t_bbox = np.zeros((B, rows, 4), np.float32)
+    t_class = np.zeros((B, rows, 1), np.int64)
+    for b in range(B):
+        n = int(np.clip(rng.poisson(7), 1, rows - 1))
+        if b == B - 1:
+            n = rows - 1
+        t_bbox[b, 0, 0] = n
+        t_bbox[b, 1:1 + n, 0:2] = rng.uniform(0.2, 0.8, (n, 2))
+        t_bbox[b, 1:1 + n, 2:4] = rng.uniform(0.05, 0.4, (n, 2))
+        t_class[b, 1:1 + n, 0] = rng.integers(1, 91, n)
+    return t_bbox, t_class
+
+
+def cpu_baseline(height, width, budget_s=25.0):
+    """The oracle (kind "port": CPU restatement of the reference, torch-CPU fp32 + SciPy matcher)
+    timed on the host cores on a bounded sample: train steps at batch 1 of the same shape."""
+    from oracle import detr_ref as R, optim_ref as O, set_loss_ref as L
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = R.make_params(0)
+    rng = np.random.default_rng(1234)
+    img = torch.from_numpy(rng.normal(size=(1, height, width, 3)).astype(np.float32))
+    tb, tc = L.make_targets(1, seed=1235, force_full=False)
+    opts = {g: O.Adam(lr, clipnorm=0.1) for g, lr in (("backbone", 1e-5), ("transformers", 1e-4), ("nlayers", 1e-4))}
+    n, t0 = 0, time.perf_counter()
+    times = []
+    while True:
+        t1 = time.perf_counter()
+        P = R.to_torch(params, requires_grad=True)
+        out = R.detr_forward(img, P)
+        total, _ = L.get_losses(out, torch.from_numpy(tb), torch.from_numpy(tc), 91)
+        total.backward()
+        grads = {k: P[k].grad.numpy() for k in P if R.trainable(k)}
+        for g in opts:
+            opts[g].apply({k: v for k, v in grads.items() if O.variable_group(k) == g}, params)
+        times.append(time.perf_counter() - t1)
+        n += 1
+        if n >= 3 or time.perf_counter() - t0 > budget_s:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+set loss+bwd+clip+Adam) at batch 1, {height}x{width}, torch-CPU fp32 "
+                      f"restatement of the TF reference (TF not installable) + SciPy matcher; best step {best:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from detr_tf import _hip, parallel, training
+    from detr_tf.loss.loss import get_losses
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from detr_tf.training_config import TrainingConfig
+
+    rank, world = parallel.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cfg = TrainingConfig()
+    cfg.background_class = 91
+    cfg.batch_size = args.batch
+    cfg.target_batch = None
+    cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
+    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0)
+    opt = setup_optimizers(model, cfg)
+    if world > 1:
+        # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
+        dist.broadcast(model.engine.P.flat, src=0)
+        for raw in model.engine.P.bn_raw.values():
+            dist.broadcast(raw, src=0)
+        model.engine.fold_bn()
+        model.dp = parallel.DataParallel(model.engine.P.grad, model.engine.P.bucket_bounds())
+
+    rng = np.random.default_rng(1234 + rank)
+    images = torch.from_numpy(rng.normal(size=(args.batch, args.height, args.width, 3)).astype(np.float32)).to(dev)
+    tb, tc = make_targets(args.batch, np.random.default_rng(1235 + rank))
+    tb, tc = torch.from_numpy(tb).to(dev), torch.from_numpy(tc).to(dev)
+
+    def step(i):
+        if args.mode == "train":
+            out, total, log, steps = training.run_train_step(model, images, tb, tc, opt, cfg)
+            for name in steps:
+                training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], i, cfg)
+            return total
+        out = model(images, training=False)
+        total, log = get_losses(out, tb, tc, cfg)
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        last = step(i)
+    barrier()
+    prof = None
+    if not args.no_kernel_events and rank == 0:
+        prof = _hip.PROFILER = _hip.KernelProfiler()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    _hip.PROFILER = None
+    loss_val = float(last)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    if rank == 0:
+        gflop = STEP_GFLOP_PER_IMAGE if args.mode == "train" else FWD_GFLOP_PER_IMAGE
+        scale = (args.height * args.width) / (800.0 * 1333.0)
+        roofline = None
+        if prof is not None:
+            fam = prof.summary()
+            if fam:
+                dom = max(fam, key=lambda k: fam[k]["ms"])
+                d = fam[dom]
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": d["launches"] // args.steps,
+                            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                            "families": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                             "launches_per_step": v["launches"] // args.steps} for k, v in fam.items()}}
+        res = {
+            "metric": "images/sec training step, DETR-R50 800x1333 bs=8/GPU" if args.mode == "train"
+                      else "images/sec forward+set-loss, DETR-R50 800x1333 bs=8/GPU",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DETR-R50 {'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
+                                   f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout off",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)"},
+            "loss": round(loss_val, 5),
+            "whole_step_fraction_of_f32_mfma_peak": round(value / world * gflop * scale / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.height, args.width)
+            except Exception as e:          # the baseline is a report, never the product path
+                res["cpu_baseline"] = {"error": repr(e)}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

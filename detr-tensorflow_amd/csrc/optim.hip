@@ -61,9 +61,24 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ para
     }
 }
 
+__global__ void set_floats8_kernel(float *dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                   float v7) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4; dst[5] = v5; dst[6] = v6; dst[7] = v7;
+    }
+}
+
 }  // namespace detr
 
 using namespace detr;
+
+extern "C" int detr_hip_set_floats8_f32(float *dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                        float v7, void *stream) {
+    DETR_REQUIRE(dst, "set_floats8: null dst");
+    hipLaunchKernelGGL(set_floats8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, v0, v1, v2, v3, v4, v5, v6, v7);
+    DETR_LAUNCH_CHECK("set_floats8");
+    return 0;
+}
 
 extern "C" int detr_hip_sumsq_segments_f32(const float *g, const int32_t *chunk_tensor, const int64_t *chunk_start,
                                            const int64_t *seg_end, int32_t n_chunks, int32_t chunk, float *sumsq,

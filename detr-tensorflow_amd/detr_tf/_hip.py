@@ -1,0 +1,248 @@
+"""ctypes binding of libdetr_hip.so (the C ABI declared in include/detr_hip.h).
+
+PyTorch is used only as the owner of device memory and of the HIP stream: every wrapper
+passes raw device pointers + the current stream to the library.  There is NO fallback: if the
+shared library is missing or a call is rejected, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch  # imported first so that libamdhip64 (same SONAME) is the one torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdetr_hip.so")
+
+f32p = c_void_p
+
+
+class GemmDesc(Structure):
+    _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32),
+                ("A", c_void_p), ("lda", c_int64), ("a_kcontig", c_int32),
+                ("B", c_void_p), ("ldb", c_int64), ("b_kcontig", c_int32),
+                ("C", c_void_p), ("ldc", c_int64),
+                ("batch", c_int32), ("batch_inner", c_int32),
+                ("sA0", c_int64), ("sA1", c_int64), ("sB0", c_int64), ("sB1", c_int64),
+                ("sC0", c_int64), ("sC1", c_int64),
+                ("alpha", c_float),
+                ("scale", c_void_p), ("bias", c_void_p),
+                ("residual", c_void_p), ("ldr", c_int64),
+                ("mask", c_void_p), ("ldmask", c_int64),
+                ("act", c_int32), ("split_k", c_int32)]
+
+
+class Conv3x3Desc(Structure):
+    _fields_ = [("N", c_int32), ("Hi", c_int32), ("Wi", c_int32), ("Ci", c_int32),
+                ("Ho", c_int32), ("Wo", c_int32), ("Co", c_int32), ("stride", c_int32), ("pad", c_int32),
+                ("x", c_void_p), ("w", c_void_p), ("y", c_void_p),
+                ("alpha", c_float),
+                ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
+                ("act", c_int32), ("split", c_int32)]
+
+
+class SetLossDesc(Structure):
+    _fields_ = [("levels", c_int32), ("B", c_int32), ("Q", c_int32), ("C", c_int32), ("R", c_int32),
+                ("logits", c_void_p), ("sL_l", c_int64), ("sL_b", c_int64), ("sL_q", c_int64),
+                ("boxes", c_void_p), ("sB_l", c_int64), ("sB_b", c_int64), ("sB_q", c_int64),
+                ("t_bbox", c_void_p), ("t_class", c_void_p),
+                ("background_class", c_int32)]
+
+
+# name -> argtypes (every function returns int)
+_SIGNATURES = {
+    "detr_hip_abi_version": [],
+    "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
+    "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
+    "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
+    "detr_hip_stem_im2col_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_maxpool3x3s2_fwd_f32": [f32p, f32p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_maxpool3x3s2_bwd_f32": [f32p, c_void_p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_subsample2_fwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_subsample2_bwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_layernorm_fwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_float, c_void_p],
+    "detr_hip_layernorm_bwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_void_p],
+    "detr_hip_softmax_rows_fwd_f32": [f32p, c_int64, c_int32, c_int64, c_void_p],
+    "detr_hip_softmax_rows_bwd_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_void_p],
+    "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
+    "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],
+    "detr_hip_add_f32": [f32p, f32p, f32p, c_int64, c_void_p],
+    "detr_hip_sigmoid_bwd_f32": [f32p, f32p, f32p, c_int64, c_void_p],
+    "detr_hip_relu_mask_f32": [f32p, f32p, f32p, c_int64, c_void_p],
+    "detr_hip_scale_cols_f32": [f32p, f32p, f32p, c_int64, c_int32, c_void_p],
+    "detr_hip_bn_fold_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_float, c_void_p],
+    "detr_hip_match_cost_f32": [POINTER(SetLossDesc), f32p, c_void_p],
+    "detr_hip_assign_f32": [f32p, c_int32, c_int32, c_int32, f32p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    "detr_hip_set_loss_sums_f32": [POINTER(SetLossDesc), c_void_p, f32p, c_void_p],
+    "detr_hip_set_loss_finalize_f32": [f32p, c_int32, f32p, f32p, c_void_p],
+    "detr_hip_set_loss_grad_f32": [POINTER(SetLossDesc), c_void_p, f32p, c_float, f32p, f32p, c_void_p],
+    "detr_hip_sumsq_segments_f32": [f32p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, f32p, c_void_p],
+    "detr_hip_clip_adam_f32": [f32p, f32p, f32p, f32p, c_void_p, c_void_p, c_void_p, c_void_p, f32p, f32p, c_int32, c_int32, c_void_p],
+    "detr_hip_axpy_f32": [f32p, f32p, c_float, c_int64, c_void_p],
+    "detr_hip_set_floats8_f32": [f32p] + [c_float] * 8 + [c_void_p],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["detr_hip_last_error"])
+
+_lib = None
+
+
+class KernelProfiler:
+    """Optional HIP-event timing of the GEMM-class launches (bench.py roofline leg): events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []          # (family, flops, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, family, flops, ev0):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.records.append((family, flops, ev0, ev1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, e0, e1 in self.records:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+PROFILER = None
+
+
+def load():
+    """Load libdetr_hip.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C detr-tensorflow_amd`) first; there is no CPU/eager fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int32
+    lib.detr_hip_last_error.argtypes = []
+    lib.detr_hip_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().detr_hip_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------
+def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
+         residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0):
+    """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kcontig = A.data_ptr() + 4 * a_off, lda, int(a_kcontig)
+    d.B, d.ldb, d.b_kcontig = B.data_ptr() + 4 * b_off, ldb, int(b_kcontig)
+    d.C, d.ldc = C.data_ptr() + 4 * c_off, ldc
+    d.batch, d.batch_inner = batch, batch_inner
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.alpha = alpha
+    d.scale, d.bias = ptr(scale), ptr(bias)
+    d.residual, d.ldr = ptr(residual), ldr
+    d.mask, d.ldmask = ptr(mask), ldmask
+    d.act, d.split_k = act, split_k
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
+    if ev0 is not None:
+        PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0)
+
+
+def pick_split_k(M, N, K, max_split=1024):
+    """Reduction-heavy GEMMs (weight gradients): split K so that ~1000 workgroups exist."""
+    bm = 128 if (M > 64 and N > 64) else 64
+    tiles = -(-M // bm) * -(-N // bm)
+    want = max(1, 1024 // max(tiles, 1))
+    ktiles = -(-K // 16)
+    return int(max(1, min(want, max_split, ktiles // 8 if ktiles >= 16 else 1)))
+
+
+def linear_fwd(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0):
+    """out = act((x @ W^T + b) * alpha + residual); W is (out, in) like custom_layers.Linear."""
+    M, K = x2d.shape
+    N = w_out_in.shape[0]
+    gemm(M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0),
+         alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act)
+
+
+def linear_dgrad(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):
+    """dx = (dy @ W) * alpha (+ residual) (masked by mask > 0)."""
+    M, N = dy2d.shape
+    K = w_out_in.shape[1]
+    gemm(M, K, N, dy2d, dy2d.stride(0), 1, w_out_in, w_out_in.stride(0), 0, dx2d, dx2d.stride(0), alpha=alpha,
+         residual=residual, ldr=(residual.stride(0) if residual is not None else 0),
+         mask=mask, ldmask=(mask.stride(0) if mask is not None else 0))
+
+
+def linear_wgrad(dy2d, x2d, dw_out_in, *, alpha=1.0):
+    """dW(out,in) += alpha * dy^T @ x  (atomic split-K; dW must hold zeros / the running sum)."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    sk = pick_split_k(N, K, M)
+    if sk == 1:
+        gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
+             residual=dw_out_in, ldr=dw_out_in.stride(0))
+    else:
+        gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
+             split_k=sk)
+
+
+# ------------------------------------------------------------------------------------------
+# conv
+# ------------------------------------------------------------------------------------------
+def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.0, scale=None, bias=None,
+            residual=None, mask=None, act=0, split=0):
+    d = Conv3x3Desc()
+    d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.stride, d.pad = N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.alpha = alpha
+    d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
+    d.act, d.split = act, split
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
+    if ev0 is not None:
+        rows = N * (Hi * Wi if mode == 1 else Ho * Wo)
+        PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0)
+
+
+def call(name, *args):
+    """Generic call by symbol name with the current stream appended."""
+    _check(getattr(load(), name)(*args, _stream()), name)
+
+
+def zero_(t):
+    call("detr_hip_memset_zero", t.data_ptr(), t.numel() * t.element_size())
+    return t

@@ -1,0 +1,527 @@
+"""DETR execution engine for MI355X: the forward and the hand-written backward of the whole
+hot path (ResNet backbone -> 6+6 transformer -> heads) as an explicit sequence of launches of
+the HIP kernels in libdetr_hip.so.  No autograd graph, no allocation in the step: every
+activation lives in a named, cached device buffer (static memory plan, hipGraph friendly).
+
+Internal layout: NHWC feature maps, i.e. batch-first token matrices [B*L, 256]; this is the
+reference's [L, B, 256] (transformer.py:32-33) with the two transposes removed -- every op of
+the transformer is row-wise except attention, which addresses (batch, head) through strides.
+
+Reference lines implemented (paths relative to the reference root):
+  backbone   detr_tf/networks/resnet_backbone.py:20-32,116-137, custom_layers.py:21-24
+  pos enc    detr_tf/networks/position_embeddings.py:23-50 (constant for a zero mask, detr.py:172)
+  transformer detr_tf/networks/transformer.py:29-57,157-179,207-234,285-356
+  heads      detr_tf/networks/detr.py:94-114,181-204
+  backward   what tape.gradient (detr_tf/optimizers.py:115) computes for the graph above
+"""
+import math
+from ctypes import byref, c_float
+
+import numpy as np
+import torch
+
+from . import _hip as hip
+from .params import ParamStore, RESNET50_BLOCKS
+
+D = 256
+HEADS = 8
+HD = 32
+FF = 2048
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def position_embedding_sine_host(H, W, num_pos_features=128, temperature=10000.0, eps=1e-6):
+    """position_embeddings.py:23-50 for an all-False mask: [H*W, 256] fp32, [pos_y | pos_x]."""
+    y = (np.arange(1, H + 1, dtype=np.float32) / np.float32(H + eps) * np.float32(2 * math.pi)).astype(np.float32)
+    x = (np.arange(1, W + 1, dtype=np.float32) / np.float32(W + eps) * np.float32(2 * math.pi)).astype(np.float32)
+    k = np.arange(num_pos_features, dtype=np.float32)
+    dim_t = np.power(np.float32(temperature), (2 * np.floor(k / 2) / np.float32(num_pos_features)).astype(np.float32)).astype(np.float32)
+    py = (y[:, None] / dim_t[None, :]).astype(np.float32)
+    px = (x[:, None] / dim_t[None, :]).astype(np.float32)
+    ey = np.empty_like(py)
+    ex = np.empty_like(px)
+    ey[:, 0::2], ey[:, 1::2] = np.sin(py[:, 0::2]), np.cos(py[:, 1::2])
+    ex[:, 0::2], ex[:, 1::2] = np.sin(px[:, 0::2]), np.cos(px[:, 1::2])
+    pos = np.concatenate([np.broadcast_to(ey[:, None, :], (H, W, num_pos_features)),
+                          np.broadcast_to(ex[None, :, :], (H, W, num_pos_features))], axis=2)
+    return np.ascontiguousarray(pos.reshape(H * W, 2 * num_pos_features), dtype=np.float32)
+
+
+class DetrEngine:
+    def __init__(self, device="cuda:0", blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, num_queries=100,
+                 num_classes=92, nb_class=None, seed=0):
+        hip.load()
+        self.device = torch.device(device)
+        self.blocks = tuple(blocks)
+        self.num_enc, self.num_dec, self.Q = num_enc, num_dec, num_queries
+        self.nb_class = nb_class
+        self.C = num_classes if nb_class is None else nb_class
+        self.P = ParamStore(self.device, blocks, num_enc, num_dec, num_queries, num_classes, nb_class, seed)
+        self._bufs = {}
+        self._pos_cache = {}
+        self._shape = None
+        self.bn_scale, self.bn_shift = {}, {}
+        self.fold_bn()
+        self.weights_dirty = True        # scaled conv kernels must be refreshed after every optimiser step
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=torch.float32):
+        key = name
+        t = self._bufs.get(key)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def fold_bn(self):
+        """custom_layers.py:21-23: scale = w * rsqrt(var + eps), shift = b - mean * scale (frozen)."""
+        for p, c in self.P.bn.items():
+            raw = self.P.bn_raw[p]
+            sc = self.buf(f"bnscale:{p}", (c,))
+            sh = self.buf(f"bnshift:{p}", (c,))
+            hip.call("detr_hip_bn_fold_f32", raw[0].data_ptr(), raw[1].data_ptr(), raw[2].data_ptr(), raw[3].data_ptr(),
+                     sc.data_ptr(), sh.data_ptr(), c, c_float(BN_EPS))
+            self.bn_scale[p], self.bn_shift[p] = sc, sh
+        self.weights_dirty = True
+
+    def load_params(self, params):
+        missing = self.P.load_dict(params)
+        self.fold_bn()
+        return missing
+
+    def _scaled_kernel(self, conv_name, bn_name):
+        """kernel * bn scale per output channel (the frozen-BN fold into the conv)."""
+        w = self.P.views[conv_name]
+        ws = self.buf(f"ws:{conv_name}", w.shape)
+        if self.weights_dirty:
+            co = w.shape[-1]
+            hip.call("detr_hip_scale_cols_f32", w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws.data_ptr(),
+                     w.numel() // co, co)
+        return ws
+
+    # ---- small helpers ----------------------------------------------------------------------------
+    @staticmethod
+    def _wgrad(M_out, N_out, K_red, A, lda, Bm, ldb, C, ldc, scale=None, alpha=1.0):
+        """C[M_out,N_out] += alpha * scale[n] * A'^T-style reduction (both operands reduction-major)."""
+        sk = hip.pick_split_k(M_out, N_out, K_red)
+        if sk > 1:
+            hip.gemm(M_out, N_out, K_red, A, lda, 0, Bm, ldb, 0, C, ldc, alpha=alpha, scale=scale, split_k=sk)
+        else:
+            hip.gemm(M_out, N_out, K_red, A, lda, 0, Bm, ldb, 0, C, ldc, alpha=alpha, scale=scale, residual=C, ldr=ldc)
+
+    def _colsum(self, x2d, out, alpha=1.0):
+        hip.call("detr_hip_colsum_f32", x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], x2d.stride(0),
+                 c_float(alpha))
+
+    def _ln_fwd(self, x, pfx, y, tag):
+        rows = x.shape[0]
+        mean = self.buf(f"{tag}:mean", (rows,))
+        rstd = self.buf(f"{tag}:rstd", (rows,))
+        hip.call("detr_hip_layernorm_fwd_f32", x.data_ptr(), self.P.views[f"{pfx}/gamma"].data_ptr(),
+                 self.P.views[f"{pfx}/beta"].data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D,
+                 c_float(LN_EPS))
+
+    def _ln_bwd(self, dy, x, pfx, dx, tag):
+        rows = x.shape[0]
+        hip.call("detr_hip_layernorm_bwd_f32", dy.data_ptr(), x.data_ptr(), self.P.views[f"{pfx}/gamma"].data_ptr(),
+                 self._bufs[f"{tag}:mean"].data_ptr(), self._bufs[f"{tag}:rstd"].data_ptr(), dx.data_ptr(),
+                 self.P.gviews[f"{pfx}/gamma"].data_ptr(), self.P.gviews[f"{pfx}/beta"].data_ptr(), rows, D)
+
+    def _add(self, a, b, out):
+        hip.call("detr_hip_add_f32", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())
+
+    def _add_bcast(self, x, p, out):
+        hip.call("detr_hip_add_bcast_f32", x.data_ptr(), p.data_ptr(), out.data_ptr(), x.numel(), p.numel())
+
+    # ---- attention --------------------------------------------------------------------------------
+    def _mha_fwd(self, tag, pfx, q_in, k_in, v_in, B, T, S, out, residual):
+        """MultiHeadAttention.call transformer.py:285-356 + the residual add of the caller.
+        q_in [B*T,256], k_in/v_in [B*S,256]; out = attn(q,k,v) @ Wo^T + bo + residual."""
+        W, bias = self.P.views[f"{pfx}/in_proj_kernel"], self.P.views[f"{pfx}/in_proj_bias"]
+        Qb, Kb, Vb = self.buf(f"{tag}:Q", (B * T, D)), self.buf(f"{tag}:K", (B * S, D)), self.buf(f"{tag}:V", (B * S, D))
+        hip.linear_fwd(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5)          # :297,:307
+        hip.linear_fwd(k_in, W[D:2 * D], bias[D:2 * D], Kb)
+        hip.linear_fwd(v_in, W[2 * D:], bias[2 * D:], Vb)
+        Sp = (S + 3) // 4 * 4
+        Pm = self.buf(f"{tag}:P", (B * HEADS, T, Sp))
+        BH = B * HEADS
+        hip.gemm(T, S, HD, Qb, D, 1, Kb, D, 1, Pm, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD),
+                 sC=(HEADS * T * Sp, T * Sp))                                          # :317
+        hip.call("detr_hip_softmax_rows_fwd_f32", Pm.data_ptr(), BH * T, S, Sp)         # :340
+        O = self.buf(f"{tag}:O", (B * T, D))
+        hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
+                 sB=(S * D, HD), sC=(T * D, HD))                                       # :343-345
+        hip.linear_fwd(O, self.P.views[f"{pfx}/out_proj_kernel"], self.P.views[f"{pfx}/out_proj_bias"], out,
+                       residual=residual)                                              # :346-347
+
+    def _mha_bwd(self, tag, pfx, d_out, q_in, k_in, v_in, B, T, S, dq_in, dk_in, dv_in, dk_accum=False, dv_accum=False):
+        """Backward of _mha_fwd w.r.t. q_in, k_in, v_in and the MHA parameters.
+        d_out: gradient of the out-projection output.  dk_in/dv_in may be accumulated onto."""
+        V, G = self.P.views, self.P.gviews
+        W, gW, gb = V[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
+        Qb, Kb, Vb, Pm, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "P", "O"))
+        Sp = Pm.shape[2]
+        BH = B * HEADS
+        # out projection
+        hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"])
+        self._colsum(d_out, G[f"{pfx}/out_proj_bias"])
+        dO = self.buf("scratch:dO", (B * T, D))
+        hip.linear_dgrad(d_out, V[f"{pfx}/out_proj_kernel"], dO)
+        # attention core
+        dQ, dK, dV = self.buf("scratch:dQ", (B * T, D)), self.buf("scratch:dK", (B * S, D)), self.buf("scratch:dV", (B * S, D))
+        dP = self.buf("scratch:dP", (BH, T, Sp))
+        sP = (HEADS * T * Sp, T * Sp)
+        hip.gemm(S, HD, T, Pm, Sp, 0, dO, D, 0, dV, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
+        hip.gemm(T, S, HD, dO, D, 1, Vb, D, 1, dP, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD), sC=sP)
+        hip.call("detr_hip_softmax_rows_bwd_f32", Pm.data_ptr(), dP.data_ptr(), BH * T, S, Sp)
+        hip.gemm(T, HD, S, dP, Sp, 1, Kb, D, 0, dQ, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(S * D, HD), sC=(T * D, HD))
+        hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
+        # in projection: Q = (q_in Wq^T + bq) * alpha
+        alpha = float(HD) ** -0.5
+        hip.linear_wgrad(dQ, q_in, gW[0:D], alpha=alpha)
+        self._colsum(dQ, gb[0:D], alpha)
+        hip.linear_wgrad(dK, k_in, gW[D:2 * D])
+        self._colsum(dK, gb[D:2 * D])
+        hip.linear_wgrad(dV, v_in, gW[2 * D:])
+        self._colsum(dV, gb[2 * D:])
+        hip.linear_dgrad(dQ, W[0:D], dq_in, alpha=alpha)
+        hip.linear_dgrad(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None)
+        hip.linear_dgrad(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)
+
+    def _ffn_fwd(self, tag, pfx, x, out_pre_ln):
+        V = self.P.views
+        h = self.buf(f"{tag}:h", (x.shape[0], FF))
+        hip.linear_fwd(x, V[f"{pfx}/linear1/kernel"], V[f"{pfx}/linear1/bias"], h, act=1)
+        hip.linear_fwd(h, V[f"{pfx}/linear2/kernel"], V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x)
+
+    def _ffn_bwd(self, tag, pfx, d_f, x, dx):
+        """d_f: grad of (linear2(relu(linear1(x))) + x); dx = full gradient w.r.t. x."""
+        V, G = self.P.views, self.P.gviews
+        h = self._bufs[f"{tag}:h"]
+        hip.linear_wgrad(d_f, h, G[f"{pfx}/linear2/kernel"])
+        self._colsum(d_f, G[f"{pfx}/linear2/bias"])
+        dh = self.buf("scratch:dh", h.shape)
+        hip.linear_dgrad(d_f, V[f"{pfx}/linear2/kernel"], dh, mask=h)
+        hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"])
+        self._colsum(dh, G[f"{pfx}/linear1/bias"])
+        hip.linear_dgrad(dh, V[f"{pfx}/linear1/kernel"], dx, residual=d_f)
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward(self, images, training=False):
+        """images: CUDA fp32 NHWC [B,H,W,3] (already normalised, processing.py:12-16).
+        Returns (logits [Lv,B,Q,C], boxes [Lv,B,Q,4]) views of engine buffers."""
+        assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[3] == 3
+        images = images.contiguous()
+        B, H, W, _ = images.shape
+        self._shape = (B, H, W)
+        self.images = images
+        V = self.P.views
+        # ---------------- stem (resnet_backbone.py:11-26) ----------------
+        H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        M1 = B * H1 * W1
+        col = self.buf("stem:col", (M1, 160))
+        hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
+        ws = self._scaled_kernel("backbone/conv1/kernel", "backbone/bn1")
+        stem = self.buf("stem:out", (B, H1, W1, 64))
+        hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift["backbone/bn1"], act=1)
+        H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        pool = self.buf("stem:pool", (B, H2, W2, 64))
+        amax = self.buf("stem:amax", (B, H2, W2, 64), torch.uint8)
+        hip.call("detr_hip_maxpool3x3s2_fwd_f32", stem.data_ptr(), pool.data_ptr(), amax.data_ptr(), B, H1, W1, 64, H2, W2)
+        # ---------------- residual stages (resnet_backbone.py:116-137) ----------------
+        x, h, w, cin = pool, H2, W2, 64
+        self._block_meta = []
+        for li, nb in enumerate(self.blocks):
+            d1, d2 = 64 * 2 ** li, 256 * 2 ** li
+            for b in range(nb):
+                p = f"backbone/layer{li + 1}/{b}"
+                stride = 2 if (b == 0 and li > 0) else 1
+                ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+                M_in, M_out = B * h * w, B * ho * wo
+                y1 = self.buf(f"{p}:y1", (B, h, w, d1))
+                hip.gemm(M_in, d1, cin, x, cin, 1, self._scaled_kernel(f"{p}/conv1/kernel", f"{p}/bn1"), d1, 0, y1, d1,
+                         bias=self.bn_shift[f"{p}/bn1"], act=1)
+                y2 = self.buf(f"{p}:y2", (B, ho, wo, d1))
+                hip.conv3x3(0, y1, self._scaled_kernel(f"{p}/conv2/kernel", f"{p}/bn2"), y2, B, h, w, d1, ho, wo, d1,
+                            stride, bias=self.bn_shift[f"{p}/bn2"], act=1)
+                if b == 0:
+                    if stride == 2:
+                        xs = self.buf(f"{p}:xs", (B, ho, wo, cin))
+                        hip.call("detr_hip_subsample2_fwd_f32", x.data_ptr(), xs.data_ptr(), B, h, w, cin, ho, wo)
+                    else:
+                        xs = x
+                    idn = self.buf(f"{p}:idn", (B, ho, wo, d2))
+                    hip.gemm(M_out, d2, cin, xs, cin, 1,
+                             self._scaled_kernel(f"{p}/downsample_0/kernel", f"{p}/downsample_1"), d2, 0, idn, d2,
+                             bias=self.bn_shift[f"{p}/downsample_1"])
+                else:
+                    xs, idn = None, x
+                out = self.buf(f"{p}:out", (B, ho, wo, d2))
+                hip.gemm(M_out, d2, d1, y2, d1, 1, self._scaled_kernel(f"{p}/conv3/kernel", f"{p}/bn3"), d2, 0, out, d2,
+                         bias=self.bn_shift[f"{p}/bn3"], residual=idn, ldr=d2, act=1)
+                self._block_meta.append(dict(p=p, x=x, xs=xs, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, cin=cin,
+                                             d1=d1, d2=d2, stride=stride, first=(b == 0)))
+                x, h, w, cin = out, ho, wo, d2
+        self.weights_dirty = False
+        feat, Hf, Wf = x, h, w
+        L = Hf * Wf
+        self._feat_meta = (feat, Hf, Wf, L)
+        # ---------------- input_proj + positional encoding (detr.py:172-175) ----------------
+        src = self.buf("enc:src0", (B * L, D))
+        hip.gemm(B * L, D, 2048, feat, 2048, 1, V["input_proj/kernel"], D, 0, src, D, bias=V["input_proj/bias"])
+        key = (Hf, Wf)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = torch.from_numpy(position_embedding_sine_host(Hf, Wf)).to(self.device)
+        pos = self._pos_cache[key]
+        self.pos = pos
+        # ---------------- encoder (transformer.py:157-179) ----------------
+        x = src
+        for i in range(self.num_enc):
+            pfx, tag = f"transformer/encoder/layer_{i}", f"enc{i}"
+            qk = self.buf(f"{tag}:qk", (B * L, D))
+            self._add_bcast(x, pos, qk)
+            a = self.buf(f"{tag}:a", (B * L, D))
+            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, qk, x, B, L, L, a, residual=x)
+            x1 = self.buf(f"{tag}:x1", (B * L, D))
+            self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1")
+            f = self.buf(f"{tag}:f", (B * L, D))
+            self._ffn_fwd(tag, pfx, x1, f)
+            x2 = self.buf(f"{tag}:x2", (B * L, D))
+            self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2")
+            x = x2
+        memory = x
+        mem_pos = self.buf("dec:mem_pos", (B * L, D))
+        self._add_bcast(memory, pos, mem_pos)
+        # ---------------- decoder (transformer.py:207-234, :104-133) ----------------
+        Q = self.Q
+        qpos = V["query_embed/kernel"]
+        tgt = self.buf("dec:tgt0", (B * Q, D))
+        hip.zero_(tgt)                                           # transformer.py:45
+        hs = self.buf("dec:hs", (self.num_dec, B * Q, D))
+        for i in range(self.num_dec):
+            pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
+            qin = self.buf(f"{tag}:qin", (B * Q, D))
+            self._add_bcast(tgt, qpos, qin)
+            a1 = self.buf(f"{tag}:a1", (B * Q, D))
+            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, qin, tgt, B, Q, Q, a1, residual=tgt)
+            t1 = self.buf(f"{tag}:t1", (B * Q, D))
+            self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1")
+            q2 = self.buf(f"{tag}:q2", (B * Q, D))
+            self._add_bcast(t1, qpos, q2)
+            a2 = self.buf(f"{tag}:a2", (B * Q, D))
+            self._mha_fwd(f"{tag}:ca", f"{pfx}/multihead_attn", q2, mem_pos, memory, B, Q, L, a2, residual=t1)
+            t2 = self.buf(f"{tag}:t2", (B * Q, D))
+            self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2")
+            f = self.buf(f"{tag}:f", (B * Q, D))
+            self._ffn_fwd(tag, pfx, t2, f)
+            t3 = self.buf(f"{tag}:t3", (B * Q, D))
+            self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
+            self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
+            tgt = t3
+        # ---------------- heads (detr.py:181-204 / :94-114) ----------------
+        Lv = self.num_dec
+        R = Lv * B * Q
+        hs2 = hs.view(R, D)
+        logits = self.buf("head:logits", (R, self.C))
+        boxes = self.buf("head:boxes", (R, 4))
+        t_a, t_b = self.buf("head:t1", (R, D)), self.buf("head:t2", (R, D))
+        if self.nb_class is None:
+            hip.linear_fwd(hs2, V["class_embed/kernel"], V["class_embed/bias"], logits)
+            hip.linear_fwd(hs2, V["bbox_embed_0/kernel"], V["bbox_embed_0/bias"], t_a, act=1)
+            hip.linear_fwd(t_a, V["bbox_embed_1/kernel"], V["bbox_embed_1/bias"], t_b, act=1)
+            hip.linear_fwd(t_b, V["bbox_embed_2/kernel"], V["bbox_embed_2/bias"], boxes, act=2)
+        else:   # Keras Dense kernels are (in, out)
+            def dense(x, name, out, act):
+                k = V[f"{name}/kernel"]
+                hip.gemm(x.shape[0], k.shape[1], k.shape[0], x, x.stride(0), 1, k, k.shape[1], 0, out, out.stride(0),
+                         bias=V[f"{name}/bias"], act=act)
+            dense(hs2, "cls_layer", logits, 0)
+            dense(hs2, "pos_layer/dense_0", t_a, 1)
+            dense(t_a, "pos_layer/dense_1", t_b, 1)
+            dense(t_b, "pos_layer/dense_2", boxes, 2)
+        return logits.view(Lv, B, Q, self.C), boxes.view(Lv, B, Q, 4)
+
+    # ---- backward ---------------------------------------------------------------------------------
+    def zero_grad(self):
+        hip.zero_(self.P.grad)
+
+    def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
+        """d_logits [Lv,B,Q,C], d_boxes [Lv,B,Q,4] (contiguous CUDA fp32): gradients of the scalar
+        loss w.r.t. the head outputs.  Parameter gradients are ACCUMULATED into P.grad.
+        on_bucket(i) is called when gradient bucket i (ParamStore.bucket_bounds) is final."""
+        B, H, W = self._shape
+        V, G = self.P.views, self.P.gviews
+        Q, Lv = self.Q, self.num_dec
+        R = Lv * B * Q
+        hs = self._bufs["dec:hs"]
+        hs2 = hs.view(R, D)
+        dl = d_logits.reshape(R, self.C)
+        db = d_boxes.reshape(R, 4)
+        boxes, t_a, t_b = self._bufs["head:boxes"], self._bufs["head:t1"], self._bufs["head:t2"]
+        # ---------------- heads ----------------
+        dz3 = self.buf("scratch:dz3", (R, 4))
+        hip.call("detr_hip_sigmoid_bwd_f32", db.data_ptr(), boxes.data_ptr(), dz3.data_ptr(), R * 4)
+        d_hs = self.buf("scratch:d_hs", (R, D))
+        dt_b, dt_a = self.buf("scratch:dt_b", (R, D)), self.buf("scratch:dt_a", (R, D))
+        if self.nb_class is None:
+            hip.linear_wgrad(dz3, t_b, G["bbox_embed_2/kernel"])
+            self._colsum(dz3, G["bbox_embed_2/bias"])
+            hip.linear_dgrad(dz3, V["bbox_embed_2/kernel"], dt_b, mask=t_b)
+            hip.linear_wgrad(dt_b, t_a, G["bbox_embed_1/kernel"])
+            self._colsum(dt_b, G["bbox_embed_1/bias"])
+            hip.linear_dgrad(dt_b, V["bbox_embed_1/kernel"], dt_a, mask=t_a)
+            hip.linear_wgrad(dt_a, hs2, G["bbox_embed_0/kernel"])
+            self._colsum(dt_a, G["bbox_embed_0/bias"])
+            hip.linear_dgrad(dt_a, V["bbox_embed_0/kernel"], d_hs)
+            hip.linear_wgrad(dl, hs2, G["class_embed/kernel"])
+            self._colsum(dl, G["class_embed/bias"])
+            hip.linear_dgrad(dl, V["class_embed/kernel"], d_hs, residual=d_hs)
+        else:
+            def dense_bwd(dy, x, name, dx, mask=None, residual=None):
+                k, gk = V[f"{name}/kernel"], G[f"{name}/kernel"]      # (in, out)
+                n_in, n_out = k.shape
+                self._wgrad(n_in, n_out, x.shape[0], x, x.stride(0), dy, dy.stride(0), gk, n_out)
+                self._colsum(dy, G[f"{name}/bias"])
+                hip.gemm(dy.shape[0], n_in, n_out, dy, dy.stride(0), 1, k, n_out, 1, dx, dx.stride(0), residual=residual,
+                         ldr=(dx.stride(0) if residual is not None else 0), mask=mask,
+                         ldmask=(mask.stride(0) if mask is not None else 0))
+            dense_bwd(dz3, t_b, "pos_layer/dense_2", dt_b, mask=t_b)
+            dense_bwd(dt_b, t_a, "pos_layer/dense_1", dt_a, mask=t_a)
+            dense_bwd(dt_a, hs2, "pos_layer/dense_0", d_hs)
+            dense_bwd(dl, hs2, "cls_layer", d_hs, residual=d_hs)
+        d_hs3 = d_hs.view(Lv, B * Q, D)
+        # ---------------- decoder ----------------
+        feat, Hf, Wf, L = self._feat_meta
+        memory = self._bufs[f"enc{self.num_enc - 1}:x2"] if self.num_enc > 0 else self._bufs["enc:src0"]
+        mem_pos = self._bufs["dec:mem_pos"]
+        qpos, g_qpos = V["query_embed/kernel"], G["query_embed/kernel"]
+        d_mem = self.buf("scratch:d_mem", (B * L, D))
+        hip.zero_(d_mem)
+        d_next = None                       # gradient flowing into t3 of layer i from layer i+1
+        BQ = B * Q
+        for i in reversed(range(self.num_dec)):
+            pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
+            t1, t2, t3 = self._bufs[f"{tag}:t1"], self._bufs[f"{tag}:t2"], self._bufs[f"{tag}:t3"]
+            a1, a2, f = self._bufs[f"{tag}:a1"], self._bufs[f"{tag}:a2"], self._bufs[f"{tag}:f"]
+            qin, q2 = self._bufs[f"{tag}:qin"], self._bufs[f"{tag}:q2"]
+            tgt = self._bufs[f"dec{i - 1}:t3"] if i > 0 else self._bufs["dec:tgt0"]
+            d_t3 = self.buf("scratch:d_t3", (BQ, D))
+            self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf")
+            if d_next is not None:
+                self._add(d_t3, d_next, d_t3)
+            d_f = self.buf("scratch:d_f", (BQ, D))
+            self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3")
+            d_t2 = self.buf("scratch:d_t2", (BQ, D))
+            self._ffn_bwd(tag, pfx, d_f, t2, d_t2)
+            d_a2 = self.buf("scratch:d_a2", (BQ, D))
+            self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2")
+            d_q2 = self.buf("scratch:d_q2", (BQ, D))
+            self._mha_bwd(f"{tag}:ca", f"{pfx}/multihead_attn", d_a2, q2, mem_pos, memory, B, Q, L, d_q2, d_mem, d_mem,
+                          dk_accum=True, dv_accum=True)
+            self._colsum(d_q2.view(B, Q * D), g_qpos.view(Q * D))          # d query_pos (sum over the batch)
+            d_t1 = self.buf("scratch:d_t1", (BQ, D))
+            self._add(d_q2, d_a2, d_t1)                                    # q2 = t1 + qpos ; a2 = ... + t1
+            d_a1 = self.buf("scratch:d_a1", (BQ, D))
+            self._ln_bwd(d_t1, a1, f"{pfx}/norm1", d_a1, f"{tag}:ln1")
+            d_qin = self.buf("scratch:d_qin", (BQ, D))
+            d_kin = self.buf("scratch:d_kin", (BQ, D))
+            d_vin = self.buf("scratch:d_vin", (BQ, D))
+            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a1, qin, qin, tgt, B, Q, Q, d_qin, d_kin, d_vin)
+            self._add(d_qin, d_kin, d_qin)                                 # q and k share qin = tgt + qpos
+            self._colsum(d_qin.view(B, Q * D), g_qpos.view(Q * D))
+            d_tgt = self.buf(f"scratch:d_tgt{i & 1}", (BQ, D))
+            self._add(d_qin, d_vin, d_tgt)
+            self._add(d_tgt, d_a1, d_tgt)                                  # residual a1 = attn + tgt
+            d_next = d_tgt
+        # ---------------- encoder ----------------
+        d_x = d_mem
+        for i in reversed(range(self.num_enc)):
+            pfx, tag = f"transformer/encoder/layer_{i}", f"enc{i}"
+            x_in = self._bufs[f"enc{i - 1}:x2"] if i > 0 else self._bufs["enc:src0"]
+            qk, a, x1, f = (self._bufs[f"{tag}:{n}"] for n in ("qk", "a", "x1", "f"))
+            d_f = self.buf("scratch:e_d_f", (B * L, D))
+            self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2")
+            d_x1 = self.buf("scratch:e_d_x1", (B * L, D))
+            self._ffn_bwd(tag, pfx, d_f, x1, d_x1)
+            d_a = self.buf("scratch:e_d_a", (B * L, D))
+            self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1")
+            d_q = self.buf("scratch:e_d_q", (B * L, D))
+            d_k = self.buf("scratch:e_d_k", (B * L, D))
+            d_v = self.buf("scratch:e_d_v", (B * L, D))
+            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a, qk, qk, x_in, B, L, L, d_q, d_k, d_v)
+            d_xn = self.buf(f"scratch:e_d_x{i & 1}", (B * L, D))
+            self._add(d_q, d_k, d_xn)
+            self._add(d_xn, d_v, d_xn)
+            self._add(d_xn, d_a, d_xn)
+            d_x = d_xn
+        if on_bucket:
+            on_bucket(0)
+        # ---------------- input_proj ----------------
+        self._wgrad(2048, D, B * L, feat, 2048, d_x, D, G["input_proj/kernel"], D)
+        self._colsum(d_x, G["input_proj/bias"])
+        if not backbone:
+            if on_bucket:
+                for i in (1, 2, 3):
+                    on_bucket(i)
+            return
+        g = self.buf("scratch:g_feat", feat.shape)
+        hip.gemm(B * L, 2048, D, d_x, D, 1, V["input_proj/kernel"], D, 1, g, 2048, mask=feat, ldmask=2048)
+        # ---------------- residual stages ----------------
+        n_blocks = len(self._block_meta)
+        for bi in reversed(range(n_blocks)):
+            m = self._block_meta[bi]
+            p, x, y1, y2 = m["p"], m["x"], m["y1"], m["y2"]
+            h, w, ho, wo, cin, d1, d2, stride = m["h"], m["w"], m["ho"], m["wo"], m["cin"], m["d1"], m["d2"], m["stride"]
+            M_in, M_out = B * h * w, B * ho * wo
+            ws1 = self._bufs[f"ws:{p}/conv1/kernel"]
+            ws2 = self._bufs[f"ws:{p}/conv2/kernel"]
+            ws3 = self._bufs[f"ws:{p}/conv3/kernel"]
+            # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
+            self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{p}/conv3/kernel"], d2, scale=self.bn_scale[f"{p}/bn3"])
+            dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1))
+            hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
+            # conv2 (3x3)
+            hip.conv3x3(2, y1, dz2, G[f"{p}/conv2/kernel"], B, h, w, d1, ho, wo, d1, stride, scale=self.bn_scale[f"{p}/bn2"])
+            dz1 = self.buf(f"scratch:dz1:{d1}:{h}", (B, h, w, d1))
+            hip.conv3x3(1, dz2, ws2, dz1, B, h, w, d1, ho, wo, d1, stride, mask=y1)
+            # conv1
+            self._wgrad(cin, d1, M_in, x, cin, dz1, d1, G[f"{p}/conv1/kernel"], d1, scale=self.bn_scale[f"{p}/bn1"])
+            is_first_block = bi == 0
+            gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin))
+            mask = None if is_first_block else x           # x = ReLU output of the previous block
+            if m["first"]:
+                xs = m["xs"]
+                wsd = self._bufs[f"ws:{p}/downsample_0/kernel"]
+                self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{p}/downsample_0/kernel"], d2,
+                            scale=self.bn_scale[f"{p}/downsample_1"])
+                if stride == 2:
+                    dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin))
+                    hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
+                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin))
+                    hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin, ho, wo)
+                else:
+                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin))
+                    hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
+            else:
+                idg = g
+            hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
+                     ldmask=(cin if mask is not None else 0))
+            g = gx
+            if on_bucket:
+                if p == "backbone/layer4/0":
+                    on_bucket(1)
+                elif p == "backbone/layer3/0":
+                    on_bucket(2)
+        # ---------------- stem ----------------
+        stem, pool, amax, col = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax", "col"))
+        H1, W1 = stem.shape[1], stem.shape[2]
+        H2, W2 = pool.shape[1], pool.shape[2]
+        d_stem = self.buf("scratch:d_stem", stem.shape)
+        hip.call("detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(), amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1,
+                 W1, 64, H2, W2)
+        self._wgrad(147, 64, B * H1 * W1, col, 160, d_stem, 64, G["backbone/conv1/kernel"], 64,
+                    scale=self.bn_scale["backbone/bn1"])
+        if on_bucket:
+            on_bucket(3)

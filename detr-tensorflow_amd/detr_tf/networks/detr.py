@@ -1,0 +1,114 @@
+"""Model factory of the drop-in API: `get_detr_model(...)` (reference detr_tf/networks/detr.py:116-204).
+
+The returned object is callable like the reference's Keras model -- `model(images, training=bool)`
+with fp32 NHWC images -- and returns the same output structure
+`{"pred_logits": [B,Q,C], "pred_boxes": [B,Q,4], "aux": [{...}] * (levels-1)}` (detr.py:190-204);
+underneath every layer is a HIP kernel launch of `engine.DetrEngine`.
+"""
+import numpy as np
+import torch
+
+from ..engine import DetrEngine
+from ..params import RESNET50_BLOCKS, RESNET101_BLOCKS
+
+
+class DetrOutputs(dict):
+    """Output dict + handles used by get_losses / run_train_step (levels tensors, loss state)."""
+    levels_logits = None
+    levels_boxes = None
+    set_loss = None
+    reduce_sums = None
+    model = None
+
+
+class _Layer:
+    def __init__(self, name, variables):
+        self.name = name
+        self.trainable_variables = variables
+
+
+class DetrModel:
+    def __init__(self, include_top=True, nb_class=None, num_decoder_layers=6, num_encoder_layers=6, num_queries=100,
+                 backbone="resnet50", device=None, seed=0):
+        device = device or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None)
+        if device is None:
+            raise RuntimeError("DETR HIP model needs a GPU: the hot path has no CPU fallback")
+        blocks = {"resnet50": RESNET50_BLOCKS, "resnet101": RESNET101_BLOCKS}[backbone]
+        self.include_top = include_top
+        self.headless = (not include_top) and nb_class is None
+        self.name = "detr" if self.headless else "detr_finetuning"
+        self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed)
+        self.dp = None                        # parallel.DataParallel when training on several GPUs
+        self.device = self.engine.device
+
+    # ---- Keras-like surface used by the reference's scripts / optimizers.py ----------------
+    @property
+    def trainable_variables(self):
+        return list(self.engine.P.views.values())
+
+    @property
+    def layers(self):
+        tops = []
+        for k in self.engine.P.shapes:
+            t = k.split("/", 1)[0]
+            if t not in tops:
+                tops.append(t)
+        return [_Layer(t, [v for k, v in self.engine.P.views.items() if k.split("/", 1)[0] == t]) for t in tops]
+
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError(f"No such layer: {name}")
+
+    def summary(self):
+        P = self.engine.P
+        n_train = sum(n for _, n in P.offsets.values())
+        n_frozen = sum(4 * c for c in P.bn.values())
+        print(f'Model: "{self.name}"  trainable params: {n_train:,}  non-trainable (frozen BN): {n_frozen:,}')
+        for l in self.layers:
+            print(f"  {l.name:28s} {sum(v.numel() for v in l.trainable_variables):>12,}")
+
+    def load_weights(self, path_or_dict):
+        missing = self.engine.P.load(path_or_dict) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
+        self.engine.fold_bn()
+        return missing
+
+    def save_weights(self, path):
+        self.engine.P.save(path)
+
+    # ---- forward ----------------------------------------------------------------------------
+    def __call__(self, images, training=False):
+        if isinstance(images, np.ndarray):
+            images = torch.from_numpy(images)
+        images = images.to(device=self.device, dtype=torch.float32)
+        logits, boxes = self.engine.forward(images, training=training)
+        if self.headless:
+            return self.engine._bufs["dec:hs"].view(self.engine.num_dec, images.shape[0], self.engine.Q, 256)
+        out = DetrOutputs()
+        out["pred_logits"], out["pred_boxes"] = logits[-1], boxes[-1]
+        out["aux"] = [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(logits.shape[0] - 1)]
+        out.levels_logits, out.levels_boxes, out.model = logits, boxes, self
+        if self.dp is not None:
+            out.reduce_sums = self.dp.reduce_sums
+        return out
+
+
+def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_backbone=False, num_decoder_layers=6,
+                   num_encoder_layers=6, num_queries=100, backbone="resnet50", device=None, seed=0):
+    """Same arguments and three output modes as the reference (detr.py:116-204); `num_queries`,
+    `backbone` ("resnet50" | "resnet101", resnet_backbone.py:35-66), `device` and `seed` are
+    extensions (the reference never exposes num_queries / ResNet101)."""
+    if tf_backbone:
+        raise NotImplementedError("tf_backbone=True (keras.applications ResNet50) is not on the HIP hot path yet")
+    model = DetrModel(include_top=include_top, nb_class=nb_class, num_decoder_layers=num_decoder_layers,
+                      num_encoder_layers=num_encoder_layers, num_queries=num_queries, backbone=backbone, device=device,
+                      seed=seed)
+    if weights is not None:
+        if isinstance(weights, str) and not weights.endswith(".npz"):
+            raise NotImplementedError(f'weights="{weights}": the reference downloads a TF checkpoint (weights.py:5-11); '
+                                      "pass the path of an .npz keyed by the reference layer names instead")
+        model.load_weights(weights)
+    if include_top is False and nb_class is not None:
+        config.add_nlayers([_Layer("cls_layer", None), _Layer("pos_layer", None)])      # detr.py:103
+    return model

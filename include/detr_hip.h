@@ -202,7 +202,11 @@ int detr_hip_clip_adam_f32(float *param, const float *g, float *m, float *v, con
                            const int64_t *chunk_start, const int64_t *seg_end, const int32_t *tensor_group,
                            const float *sumsq, const float *hyper, int32_t n_chunks, int32_t chunk,
                            void *stream);
-/* acc[i] += g[i] (gradient accumulation optimizers.py:157) */
+/* dst[0..7] = v0..v7: the values travel as kernel arguments, so the host never has to
+ * synchronise to update `hyper` (stream ordered, race free) */
+int detr_hip_set_floats8_f32(float *dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                             float v7, void *stream);
+/* acc[i] += a * g[i] (gradient accumulation optimizers.py:157) */
 int detr_hip_axpy_f32(float *acc, const float *g, float a, int64_t n, void *stream);
 
 #ifdef __cplusplus

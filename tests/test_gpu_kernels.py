@@ -1,0 +1,478 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI (ctypes), against plain
+torch-CPU fp32/fp64 references of the same op and against the oracle (SciPy for the matcher).
+Tolerances are stated per test; GEMM-class kernels use the exact-f32 MFMA so only the summation
+order differs from the CPU (rel 2e-5 of the row scale)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+def close(a, b, rtol=2e-5, atol=None, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    scale = float(b.abs().max()) + 1e-30
+    atol = rtol * scale if atol is None else atol
+    err = float((a - b).abs().max())
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.3e} (scale {scale:.3e})"
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 92, 256), (1000, 256, 147), (77, 40, 33), (8400, 64, 64),
+                                   (520, 2048, 256), (130, 32, 100)])
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_layouts(hip, M, N, K, ak, bk):
+    torch.manual_seed(M * 7 + N * 3 + K + ak * 2 + bk)
+    A = torch.randn(M, K)
+    B = torch.randn(K, N)
+    ref = A.double() @ B.double()
+    lda = (K if ak else M) + 4
+    ldb = (K if bk else N) + 4
+    Am = torch.zeros((M, lda) if ak else (K, lda))
+    Bm = torch.zeros((N, ldb) if bk else (K, ldb))
+    if ak:
+        Am[:, :K] = A
+    else:
+        Am[:, :M] = A.t()
+    if bk:
+        Bm[:, :K] = B.t()
+    else:
+        Bm[:, :N] = B
+    Ad, Bd = g(Am), g(Bm)
+    C = torch.full((M, N + 4), 7.0, device=DEV)
+    hip.gemm(M, N, K, Ad, lda, ak, Bd, ldb, bk, C, N + 4)
+    torch.cuda.synchronize()
+    close(C[:, :N], ref, what=f"gemm {M}x{N}x{K} ak={ak} bk={bk}")
+    assert float((C[:, N:] - 7.0).abs().max()) == 0.0, "gemm wrote outside its columns"
+
+
+def test_gemm_unaligned_scalar_path(hip):
+    torch.manual_seed(1)
+    M, N, K = 70, 50, 37
+    A = torch.randn(M, K)
+    B = torch.randn(N, K)
+    Ad, Bd = g(A), g(B)          # ld = 37 -> not a multiple of 4 -> scalar loads
+    C = torch.zeros(M, N, device=DEV)
+    hip.gemm(M, N, K, Ad, K, 1, Bd, K, 1, C, N)
+    close(C, A.double() @ B.double().t(), what="gemm scalar path")
+
+
+def test_gemm_epilogue(hip):
+    torch.manual_seed(2)
+    M, N, K = 333, 200, 96
+    A, W = torch.randn(M, K), torch.randn(N, K)
+    scale, bias = torch.rand(N) + 0.5, torch.randn(N)
+    R, Mk = torch.randn(M, N), torch.randn(M, N)
+    acc = A.double() @ W.double().t()
+    for act in (0, 1, 2):
+        ref = (acc * scale.double() + bias.double()) * 0.25 + R.double()
+        if act == 1:
+            ref = ref.clamp_min(0)
+        elif act == 2:
+            ref = torch.sigmoid(ref)
+        ref = torch.where(Mk.double() > 0, ref, torch.zeros_like(ref))
+        C = torch.zeros(M, N, device=DEV)
+        hip.gemm(M, N, K, g(A), K, 1, g(W), K, 1, C, N, alpha=0.25, scale=g(scale), bias=g(bias), residual=g(R), ldr=N,
+                 mask=g(Mk), ldmask=N, act=act)
+        close(C, ref, what=f"gemm epilogue act={act}")
+
+
+def test_gemm_split_k_accumulates(hip):
+    torch.manual_seed(3)
+    M, N, K = 64, 256, 5000
+    A, B = torch.randn(K, M), torch.randn(K, N)
+    scale = torch.rand(N) + 0.5
+    C0 = torch.randn(M, N)
+    C = g(C0.clone())
+    hip.gemm(M, N, K, g(A), M, 0, g(B), N, 0, C, N, alpha=0.5, scale=g(scale), split_k=37)
+    ref = C0.double() + 0.5 * (A.double().t() @ B.double()) * scale.double()
+    close(C, ref, rtol=5e-5, what="gemm split-k")
+
+
+def test_gemm_batched_attention_layout(hip):
+    """scores[b,h] = Q_h K_h^T and O = P V_h on the [B, L, heads*32] layout used by the transformer."""
+    torch.manual_seed(4)
+    Bn, H, T, S, hd = 2, 8, 100, 150, 32
+    D = H * hd
+    q, k, v = torch.randn(Bn, T, D), torch.randn(Bn, S, D), torch.randn(Bn, S, D)
+    Sp = 152
+    sc = torch.zeros(Bn * H, T, Sp, device=DEV)
+    qd, kd, vd = g(q), g(k), g(v)
+    hip.gemm(T, S, hd, qd, D, 1, kd, D, 1, sc, Sp, batch=Bn * H, batch_inner=H, sA=(T * D, hd), sB=(S * D, hd),
+             sC=(H * T * Sp, T * Sp))
+    ref = torch.einsum("bthd,bshd->bhts", q.view(Bn, T, H, hd).double(), k.view(Bn, S, H, hd).double())
+    close(sc[:, :, :S].view(Bn, H, T, S), ref, what="batched QK^T")
+    p = torch.softmax(ref, -1).float()
+    pd = torch.zeros(Bn * H, T, Sp, device=DEV)
+    pd[:, :, :S] = p.view(Bn * H, T, S).to(DEV)
+    o = torch.zeros(Bn, T, D, device=DEV)
+    hip.gemm(T, hd, S, pd, Sp, 1, vd, D, 0, o, D, batch=Bn * H, batch_inner=H, sA=(H * T * Sp, T * Sp), sB=(S * D, hd),
+             sC=(T * D, hd))
+    oref = torch.einsum("bhts,bshd->bthd", p.double(), v.view(Bn, S, H, hd).double()).reshape(Bn, T, D)
+    close(o, oref, what="batched PV")
+
+
+def test_linear_helpers(hip):
+    torch.manual_seed(5)
+    M, K, N = 420, 256, 92
+    x = torch.randn(M, K, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(N, K, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(N, dtype=torch.float64)
+    y = torch.relu(x @ W.t() + b)
+    dy = torch.randn(M, N, dtype=torch.float64)
+    dz = dy * (y > 0)
+    y.backward(dy)
+    xd, Wd, bd = g(x.detach().float()), g(W.detach().float()), g(b.float())
+    yd = torch.zeros(M, N, device=DEV)
+    hip.linear_fwd(xd, Wd, bd, yd, act=1)
+    close(yd, y, what="linear fwd")
+    dzd = g(dz.float())
+    dxd = torch.zeros(M, K, device=DEV)
+    hip.linear_dgrad(dzd, Wd, dxd)
+    close(dxd, x.grad, what="linear dgrad")
+    dWd = torch.zeros(N, K, device=DEV)
+    hip.linear_wgrad(dzd, xd, dWd)
+    close(dWd, W.grad, rtol=5e-5, what="linear wgrad")
+
+
+# ------------------------------------------------------------------------------------------
+# conv 3x3 / stem / pooling
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 9, 11, 16, 32, 1),
+                                                (1, 50, 67, 64, 64, 1), (1, 25, 42, 256, 256, 2)])
+def test_conv3x3_all_modes(hip, N, H, W, Ci, Co, stride):
+    torch.manual_seed(N + H + W + Ci + stride)
+    x = torch.randn(N, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(3, 3, Ci, Co, dtype=torch.float64) / (3 * Ci ** 0.5)).requires_grad_(True)
+    scale, shift = torch.rand(Co, dtype=torch.float64) + 0.5, torch.randn(Co, dtype=torch.float64)
+    z = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=stride, padding=1).permute(0, 2, 3, 1)
+    Ho, Wo = z.shape[1], z.shape[2]
+    y = torch.relu(z * scale + shift)
+    xd, wd = g(x.detach().float()), g(w.detach().float())
+    yd = torch.zeros(N, Ho, Wo, Co, device=DEV)
+    hip.conv3x3(0, xd, wd, yd, N, H, W, Ci, Ho, Wo, Co, stride, scale=g(scale.float()), bias=g(shift.float()), act=1)
+    close(yd, y, what="conv3x3 fwd")
+    # backward of z (pre-BN) given dz
+    dz = torch.randn_like(z)
+    z.backward(dz)
+    dzd = g(dz.float())
+    mask = torch.randn(N, H, W, Ci)
+    dxd = torch.zeros(N, H, W, Ci, device=DEV)
+    hip.conv3x3(1, dzd, wd, dxd, N, H, W, Ci, Ho, Wo, Co, stride, mask=g(mask))
+    close(dxd, x.grad * (mask.double() > 0), what="conv3x3 dgrad(+mask)")
+    dwd = torch.zeros(3, 3, Ci, Co, device=DEV)
+    hip.conv3x3(2, xd, dzd, dwd, N, H, W, Ci, Ho, Wo, Co, stride, scale=g(scale.float()))
+    close(dwd, w.grad * scale, rtol=5e-5, what="conv3x3 wgrad(+scale)")
+
+
+def test_stem_im2col_gemm_and_pool(hip):
+    torch.manual_seed(11)
+    N, H, W = 2, 37, 50
+    img = torch.randn(N, H, W, 3)
+    k = torch.randn(7, 7, 3, 64) / 12.0
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    ref = F.conv2d(img.double().permute(0, 3, 1, 2), k.double().permute(3, 2, 0, 1), stride=2, padding=3).permute(0, 2, 3, 1)
+    col = torch.full((N * Ho * Wo, 160), 9.0, device=DEV)
+    hip.call("detr_hip_stem_im2col_f32", g(img).data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, 160)
+    y = torch.zeros(N * Ho * Wo, 64, device=DEV)
+    hip.gemm(N * Ho * Wo, 64, 147, col, 160, 1, g(k.reshape(147, 64)), 64, 0, y, 64, act=1)
+    close(y.view(N, Ho, Wo, 64), ref.clamp_min(0), what="stem conv via im2col")
+    assert float(col[:, 147:].abs().max()) == 0.0
+    # max pool over the zero padded map
+    x = y.view(N, Ho, Wo, 64)
+    Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    xc = x.cpu().double().requires_grad_(True)
+    pref = F.max_pool2d(F.pad(xc.permute(0, 3, 1, 2), (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+    pool = torch.zeros(N, Hp, Wp, 64, device=DEV)
+    amax = torch.zeros(N, Hp, Wp, 64, device=DEV, dtype=torch.uint8)
+    hip.call("detr_hip_maxpool3x3s2_fwd_f32", x.data_ptr(), pool.data_ptr(), amax.data_ptr(), N, Ho, Wo, 64, Hp, Wp)
+    close(pool, pref, atol=0.0, what="maxpool fwd")
+    dy = torch.randn(N, Hp, Wp, 64)
+    pref.backward(dy.double())
+    dx = torch.zeros(N, Ho, Wo, 64, device=DEV)
+    hip.call("detr_hip_maxpool3x3s2_bwd_f32", g(dy).data_ptr(), amax.data_ptr(), x.data_ptr(), dx.data_ptr(), N, Ho, Wo,
+             64, Hp, Wp)
+    # gradients at x == 0 are dropped by the fused ReLU mask; torch routes ties at 0 arbitrarily
+    refdx = xc.grad * (xc.detach() > 0)
+    close(dx, refdx, atol=1e-6, what="maxpool bwd (+relu mask)")
+
+
+def test_subsample2(hip):
+    x = torch.randn(2, 9, 13, 16)
+    Ho, Wo = 5, 7
+    y = torch.zeros(2, Ho, Wo, 16, device=DEV)
+    hip.call("detr_hip_subsample2_fwd_f32", g(x).data_ptr(), y.data_ptr(), 2, 9, 13, 16, Ho, Wo)
+    assert torch.equal(y.cpu(), x[:, ::2, ::2, :])
+    dy = torch.randn(2, Ho, Wo, 16)
+    dx = torch.full((2, 9, 13, 16), 3.0, device=DEV)
+    hip.call("detr_hip_subsample2_bwd_f32", g(dy).data_ptr(), dx.data_ptr(), 2, 9, 13, 16, Ho, Wo)
+    ref = torch.zeros(2, 9, 13, 16)
+    ref[:, ::2, ::2, :] = dy
+    assert torch.equal(dx.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,C", [(8400, 256), (37, 256), (5, 64), (130, 1024)])
+def test_layernorm_fwd_bwd(hip, rows, C):
+    torch.manual_seed(rows + C)
+    x = (torch.randn(rows, C, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
+    gam = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_(True)
+    bet = torch.randn(C, dtype=torch.float64).requires_grad_(True)
+    y = F.layer_norm(x, (C,), gam, bet, 1e-5)
+    dy = torch.randn(rows, C, dtype=torch.float64)
+    y.backward(dy)
+    xd, gd, bd = g(x.detach().float()), g(gam.detach().float()), g(bet.detach().float())
+    yd = torch.zeros(rows, C, device=DEV)
+    mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+    hip.call("detr_hip_layernorm_fwd_f32", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), rows, C, ctypes.c_float(1e-5))
+    close(yd, y, rtol=1e-5, what="layernorm fwd")
+    dxd = torch.zeros(rows, C, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    hip.call("detr_hip_layernorm_bwd_f32", g(dy.float()).data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), dxd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C)
+    close(dxd, x.grad, rtol=2e-5, what="layernorm dx")
+    close(dg, gam.grad, rtol=5e-5, what="layernorm dgamma")
+    close(db, bet.grad, rtol=5e-5, what="layernorm dbeta")
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(640, 1050, 1052), (64, 100, 100), (10, 7, 8), (33, 1344, 1344)])
+def test_softmax_rows(hip, rows, cols, ld):
+    torch.manual_seed(rows + cols)
+    s = (torch.randn(rows, cols, dtype=torch.float64) * 3).requires_grad_(True)
+    p = torch.softmax(s, -1)
+    dp = torch.randn(rows, cols, dtype=torch.float64)
+    p.backward(dp)
+    sd = torch.full((rows, ld), 5.0, device=DEV)
+    sd[:, :cols] = s.detach().float().to(DEV)
+    hip.call("detr_hip_softmax_rows_fwd_f32", sd.data_ptr(), rows, cols, ld)
+    close(sd[:, :cols], p, rtol=1e-5, what="softmax fwd")
+    dpd = torch.zeros(rows, ld, device=DEV)
+    dpd[:, :cols] = dp.float().to(DEV)
+    hip.call("detr_hip_softmax_rows_bwd_f32", sd.data_ptr(), dpd.data_ptr(), rows, cols, ld)
+    close(dpd[:, :cols], s.grad, rtol=2e-5, what="softmax bwd")
+
+
+def test_small_elementwise(hip):
+    torch.manual_seed(9)
+    x = torch.randn(8400, 300)
+    out = torch.zeros(300, device=DEV)
+    hip.call("detr_hip_colsum_f32", g(x).data_ptr(), out.data_ptr(), 8400, 300, 300, ctypes.c_float(0.5))
+    close(out, 0.5 * x.double().sum(0), rtol=2e-5, what="colsum")
+    a, p = torch.randn(4, 50, 256), torch.randn(50, 256)
+    o = torch.zeros(4, 50, 256, device=DEV)
+    hip.call("detr_hip_add_bcast_f32", g(a).data_ptr(), g(p).data_ptr(), o.data_ptr(), a.numel(), p.numel())
+    assert torch.equal(o.cpu(), a + p)
+    b = torch.randn(4, 50, 256)
+    hip.call("detr_hip_add_f32", g(a).data_ptr(), g(b).data_ptr(), o.data_ptr(), a.numel())
+    assert torch.equal(o.cpu(), a + b)
+    y = torch.rand(1000)
+    dy = torch.randn(1000)
+    dz = torch.zeros(1000, device=DEV)
+    hip.call("detr_hip_sigmoid_bwd_f32", g(dy).data_ptr(), g(y).data_ptr(), dz.data_ptr(), 1000)
+    close(dz, dy * y * (1 - y), rtol=1e-6, what="sigmoid bwd")
+    hip.call("detr_hip_relu_mask_f32", g(dy).data_ptr(), g(y - 0.5).data_ptr(), dz.data_ptr(), 1000)
+    assert torch.equal(dz.cpu(), torch.where(y - 0.5 > 0, dy, torch.zeros(())))
+    w, sc = torch.randn(576, 64), torch.rand(64)
+    wo = torch.zeros(576, 64, device=DEV)
+    hip.call("detr_hip_scale_cols_f32", g(w).data_ptr(), g(sc).data_ptr(), wo.data_ptr(), 576, 64)
+    assert torch.equal(wo.cpu(), w * sc)
+    bw, bb, bm, bv = torch.rand(64) + .5, torch.randn(64), torch.randn(64), torch.rand(64) + .5
+    s_, h_ = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    hip.call("detr_hip_bn_fold_f32", g(bw).data_ptr(), g(bb).data_ptr(), g(bm).data_ptr(), g(bv).data_ptr(), s_.data_ptr(),
+             h_.data_ptr(), 64, ctypes.c_float(1e-5))
+    rs = bw * torch.rsqrt(bv + 1e-5)
+    close(s_, rs, rtol=1e-6, what="bn scale")
+    close(h_, bb - bm * rs, rtol=1e-6, what="bn shift")
+    acc, gg = torch.randn(999), torch.randn(999)
+    accd = g(acc)
+    hip.call("detr_hip_axpy_f32", accd.data_ptr(), g(gg).data_ptr(), ctypes.c_float(2.0), 999)
+    close(accd, acc + 2 * gg, rtol=1e-6, what="axpy")
+    z = torch.ones(1001, device=DEV)
+    hip.zero_(z)
+    assert float(z.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------
+# set loss: cost, assignment (vs SciPy), loss + gradients (vs oracle autograd)
+# ------------------------------------------------------------------------------------------
+def _setloss_desc(hip, logits, boxes, t_bbox, t_class, bg):
+    """logits [Lv,B,Q,C], boxes [Lv,B,Q,4] contiguous CUDA tensors."""
+    Lv, B, Q, C = logits.shape
+    d = hip.SetLossDesc()
+    d.levels, d.B, d.Q, d.C, d.R = Lv, B, Q, C, t_bbox.shape[1]
+    d.logits, d.sL_l, d.sL_b, d.sL_q = logits.data_ptr(), B * Q * C, Q * C, C
+    d.boxes, d.sB_l, d.sB_b, d.sB_q = boxes.data_ptr(), B * Q * 4, Q * 4, 4
+    d.t_bbox, d.t_class = t_bbox.data_ptr(), t_class.data_ptr()
+    d.background_class = bg
+    return d
+
+
+@pytest.mark.parametrize("Q,n_list", [(100, [7, 1, 99, 0, 20]), (300, [99, 5]), (64, [64, 3])])
+def test_assign_matches_scipy(hip, Q, n_list):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(Q)
+    R = 100
+    B = len(n_list)
+    Lv = 3
+    P = Lv * B
+    ldc = R - 1
+    t_bbox = np.zeros((B, R, 4), np.float32)
+    for b, n in enumerate(n_list):
+        t_bbox[b, 0, 0] = n
+    cost = rng.normal(size=(P, Q, ldc)).astype(np.float32)
+    cd, tbd = g(torch.tensor(cost)), g(torch.tensor(t_bbox))
+    tfp = torch.full((P, Q), -7, device=DEV, dtype=torch.int32)
+    pft = torch.full((P, ldc), -7, device=DEV, dtype=torch.int32)
+    st = torch.full((P,), -7, device=DEV, dtype=torch.int32)
+    hip.call("detr_hip_assign_f32", cd.data_ptr(), P, Q, ldc, tbd.data_ptr(), B, R, tfp.data_ptr(), pft.data_ptr(),
+             st.data_ptr())
+    torch.cuda.synchronize()
+    tfp, pft, st = tfp.cpu().numpy(), pft.cpu().numpy(), st.cpu().numpy()
+    assert (st == 0).all()
+    for p in range(P):
+        n = n_list[p % B]
+        rows, cols = linear_sum_assignment(cost[p, :, :n])
+        got = pft[p, :n]
+        exp = np.full(n, -1)
+        exp[cols] = rows
+        assert np.array_equal(got, exp), f"problem {p} (Q={Q}, n={n}) differs from SciPy"
+        assert (pft[p, n:] == -1).all()
+        inv = np.full(Q, -1)
+        inv[rows] = cols
+        assert np.array_equal(tfp[p], inv)
+
+
+def test_assign_ties_and_invalid(hip):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(5)
+    Q, R, B, P = 100, 100, 4, 4
+    ldc = R - 1
+    t_bbox = np.zeros((B, R, 4), np.float32)
+    t_bbox[:, 0, 0] = [10, 30, 5, 8]
+    cost = np.round(rng.normal(size=(P, Q, ldc)) * 2).astype(np.float32) / 2     # heavy ties
+    cost[2, 3, 1] = np.nan
+    cost[3, :, 2] = np.inf                                                        # infeasible column
+    tfp = torch.zeros((P, Q), device=DEV, dtype=torch.int32)
+    pft = torch.zeros((P, ldc), device=DEV, dtype=torch.int32)
+    st = torch.zeros((P,), device=DEV, dtype=torch.int32)
+    hip.call("detr_hip_assign_f32", g(torch.tensor(cost)).data_ptr(), P, Q, ldc, g(torch.tensor(t_bbox)).data_ptr(), B, R,
+             tfp.data_ptr(), pft.data_ptr(), st.data_ptr())
+    st, pft = st.cpu().numpy(), pft.cpu().numpy()
+    assert st[0] == 0 and st[1] == 0 and st[2] == 1 and st[3] == 1      # SciPy raises ValueError for both
+    for p in (0, 1):
+        n = int(t_bbox[p, 0, 0])
+        rows, cols = linear_sum_assignment(cost[p, :, :n])
+        got = pft[p, :n]
+        assert len(set(got.tolist())) == n and (got >= 0).all()
+        assert abs(cost[p, got, np.arange(n)].sum() - cost[p, rows, cols].sum()) < 1e-6   # same optimum under ties
+
+
+@pytest.mark.parametrize("Q,B,bg", [(100, 4, 91), (300, 2, 91)])
+def test_set_loss_vs_oracle(hip, Q, B, bg):
+    from oracle import set_loss_ref as L
+    torch.manual_seed(Q + B)
+    Lv, C = 6, 92
+    logits = torch.randn(Lv, B, Q, C) * 2
+    boxes = torch.rand(Lv, B, Q, 4) * torch.tensor([1.0, 1.0, 0.6, 0.6]) + torch.tensor([0.0, 0.0, 0.02, 0.02])
+    boxes[0, 0, :5, 2] = 1.9   # boxes clipped on both sides: exercises the clip gradient
+    tb, tc = L.make_targets(B, seed=77)
+    tbt, tct = torch.tensor(tb), torch.tensor(tc)
+    # oracle (fp64 for the gradient reference, fp32 for the cost matrix)
+    lg64 = logits.double().requires_grad_(True)
+    bx64 = boxes.double().requires_grad_(True)
+    m_out = {"pred_logits": lg64[Lv - 1], "pred_boxes": bx64[Lv - 1],
+             "aux": [{"pred_logits": lg64[i], "pred_boxes": bx64[i]} for i in range(Lv - 1)]}
+    total, losses = L.get_losses(m_out, tbt.double(), tct, bg)
+    total.backward()
+    lgd, bxd, tbd, tcd = g(logits), g(boxes), g(tbt), g(tct.reshape(B, -1))
+    d = _setloss_desc(hip, lgd, bxd, tbd, tcd, bg)
+    P, R = Lv * B, tb.shape[1]
+    cost = torch.zeros(P, Q, R - 1, device=DEV)
+    hip.call("detr_hip_match_cost_f32", ctypes.byref(d), cost.data_ptr())
+    for lv in range(Lv):
+        for b in range(B):
+            tbs, tcs = L.strip_header(tbt[b], tct[b])
+            cref = L.cost_matrix(tbs, tcs, boxes[lv, b], logits[lv, b])
+            close(cost[lv * B + b, :, :tbs.shape[0]], cref, atol=2e-6, what=f"cost lv{lv} b{b}")
+    tfp = torch.zeros((P, Q), device=DEV, dtype=torch.int32)
+    pft = torch.zeros((P, R - 1), device=DEV, dtype=torch.int32)
+    st = torch.zeros((P,), device=DEV, dtype=torch.int32)
+    hip.call("detr_hip_assign_f32", cost.data_ptr(), P, Q, R - 1, tbd.data_ptr(), B, R, tfp.data_ptr(), pft.data_ptr(),
+             st.data_ptr())
+    assert int(st.abs().sum()) == 0
+    sums = torch.zeros(Lv * 10, device=DEV)
+    hip.call("detr_hip_set_loss_sums_f32", ctypes.byref(d), tfp.data_ptr(), sums.data_ptr())
+    out = torch.zeros(Lv, 6, device=DEV)
+    tot = torch.zeros(1, device=DEV)
+    hip.call("detr_hip_set_loss_finalize_f32", sums.data_ptr(), Lv, out.data_ptr(), tot.data_ptr())
+    names = ["label_cost", "true_neg", "true_pos", "pos_accuracy", "giou_loss", "l1_loss"]
+    out = out.cpu()
+    for lv in range(Lv):
+        suf = "" if lv == Lv - 1 else f"_{lv}"
+        for k, nm in enumerate(names):
+            ref = float(losses[nm + suf])
+            assert abs(float(out[lv, k]) - ref) <= 2e-5 * max(1.0, abs(ref)), (lv, nm, float(out[lv, k]), ref)
+    assert abs(float(tot) - float(total)) <= 1e-5 * abs(float(total))      # loss matches the oracle to 1e-5 rel
+    dl, dbx = torch.zeros_like(lgd), torch.zeros_like(bxd)
+    hip.call("detr_hip_set_loss_grad_f32", ctypes.byref(d), tfp.data_ptr(), sums.data_ptr(), ctypes.c_float(0.5),
+             dl.data_ptr(), dbx.data_ptr())
+    close(dl, 0.5 * lg64.grad, rtol=2e-5, what="d_logits")
+    close(dbx, 0.5 * bx64.grad, rtol=5e-5, what="d_boxes")
+
+
+# ------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------
+def test_clip_adam_vs_oracle(hip):
+    from oracle import optim_ref as O
+    rng = np.random.default_rng(3)
+    shapes = [(64, 3, 7), (5,), (300, 40), (1,), (4097,)]
+    groups = [0, 0, 1, 2, 1]
+    params = {i: rng.normal(size=s).astype(np.float32) for i, s in enumerate(shapes)}
+    sizes = [int(np.prod(s)) for s in shapes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    chunk = 1024
+    ct, cs = [], []
+    for t, (o, n) in enumerate(zip(offs[:-1], sizes)):
+        for st in range(0, n, chunk):
+            ct.append(t)
+            cs.append(o + st)
+    flat = g(torch.tensor(np.concatenate([params[i].ravel() for i in range(len(shapes))])))
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    ctd = g(torch.tensor(ct, dtype=torch.int32))
+    csd = g(torch.tensor(cs, dtype=torch.int64))
+    sed = g(torch.tensor(offs[1:], dtype=torch.int64))
+    tgd = g(torch.tensor(groups, dtype=torch.int32))
+    lrs = [1e-2, 3e-3, 1e-3]
+    opts = [O.Adam(lr, clipnorm=0.1) for lr in lrs]
+    import math
+    for step in range(1, 4):
+        scale = [1e-3, 10.0, 1.0][step - 1]    # below / above the clip threshold
+        grads = {i: (rng.normal(size=s) * scale).astype(np.float32) for i, s in enumerate(shapes)}
+        gflat = g(torch.tensor(np.concatenate([grads[i].ravel() for i in range(len(shapes))])))
+        sumsq = torch.zeros(len(shapes), device=DEV)
+        hip.call("detr_hip_sumsq_segments_f32", gflat.data_ptr(), ctd.data_ptr(), csd.data_ptr(), sed.data_ptr(), len(ct),
+                 chunk, sumsq.data_ptr())
+        hyper = torch.tensor([lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) for lr in lrs] + [0.1, 0.9, 0.999, 1e-7, 0],
+                             dtype=torch.float32, device=DEV)
+        hip.call("detr_hip_clip_adam_f32", flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(), ctd.data_ptr(),
+                 csd.data_ptr(), sed.data_ptr(), tgd.data_ptr(), sumsq.data_ptr(), hyper.data_ptr(), len(ct), chunk)
+        for gi in range(3):
+            opts[gi].apply({i: grads[i] for i in range(len(shapes)) if groups[i] == gi}, params)
+        ref = np.concatenate([params[i].ravel() for i in range(len(shapes))])
+        close(flat, torch.tensor(ref), rtol=1e-5, what=f"adam step {step}")

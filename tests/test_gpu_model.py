@@ -1,0 +1,198 @@
+"""GPU parity tests of the whole hot path through the drop-in API, against the CPU oracle
+(oracle/*.py -- a restatement of the TF reference; PARITY UNPINNED at the TF boundary, the
+matcher is pinned to SciPy).  Tolerances (fp32): logits/boxes 1e-4 rel of the
+tensor scale, loss 1e-3 rel (BASELINE.json north_star), gradients 2e-3 rel per tensor."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(train=True):
+    from detr_tf.training_config import TrainingConfig
+    cfg = TrainingConfig()
+    cfg.background_class = 91
+    cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = train
+    cfg.target_batch = None
+    return cfg
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def small():
+    """R50 6+6 at 2 x 128x160 with the seeded oracle weights."""
+    from detr_tf.networks.detr import get_detr_model
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(3)
+    model = get_detr_model(cfg, include_top=True)
+    missing = model.load_weights(params)
+    assert not missing, missing
+    rng = np.random.default_rng(11)
+    images = rng.normal(size=(2, 128, 160, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=21, force_full=False)
+    return dict(cfg=cfg, params=params, model=model, images=images, t_bbox=t_bbox, t_class=t_class)
+
+
+def test_forward_taps_vs_oracle(hip, small):
+    from oracle import detr_ref as R
+    taps = {}
+    ref = R.detr_forward(torch.from_numpy(small["images"]), R.to_torch(small["params"]), taps=taps)
+    out = small["model"](small["images"])
+    eng = small["model"].engine
+    B = 2
+    got = {
+        "stem_conv": eng._bufs["stem:out"],
+        "stem_pool": eng._bufs["stem:pool"],
+        "layer1": eng._bufs["backbone/layer1/2:out"],
+        "layer2": eng._bufs["backbone/layer2/3:out"],
+        "layer3": eng._bufs["backbone/layer3/5:out"],
+        "layer4": eng._bufs["backbone/layer4/2:out"],
+    }
+    for k, v in got.items():
+        assert _rel(v, taps[k]) < 1e-4, f"{k}: rel err {_rel(v, taps[k]):.2e}"
+    L = taps["memory"].shape[0]
+    assert _rel(eng._bufs["enc:src0"].view(B, L, 256), taps["input_proj"].reshape(B, L, 256)) < 1e-4
+    assert _rel(eng.pos, taps["pos"][0].reshape(L, 256)) < 1e-5
+    assert _rel(eng._bufs["enc5:x2"].view(B, L, 256), taps["memory"].transpose(0, 1)) < 2e-4
+    assert _rel(eng._bufs["dec:hs"].view(6, B, 100, 256), taps["hs"]) < 2e-4
+    assert _rel(out["pred_logits"], ref["pred_logits"]) < 2e-4
+    assert _rel(out["pred_boxes"], ref["pred_boxes"]) < 2e-4
+    assert len(out["aux"]) == 5
+    for i in range(5):
+        assert _rel(out["aux"][i]["pred_logits"], ref["aux"][i]["pred_logits"]) < 2e-4
+        assert _rel(out["aux"][i]["pred_boxes"], ref["aux"][i]["pred_boxes"]) < 2e-4
+
+
+def test_loss_vs_oracle(hip, small):
+    from detr_tf.loss.loss import get_losses
+    from oracle import detr_ref as R, set_loss_ref as L
+    ref_out = R.detr_forward(torch.from_numpy(small["images"]), R.to_torch(small["params"]))
+    ref_total, ref_log = L.get_losses(ref_out, torch.from_numpy(small["t_bbox"]), torch.from_numpy(small["t_class"]), 91)
+    out = small["model"](small["images"])
+    total, log = get_losses(out, small["t_bbox"], small["t_class"], small["cfg"])
+    assert list(log.keys()) == list(ref_log.keys())            # same 36 keys in the same order
+    for k in ref_log:
+        assert abs(float(log[k]) - float(ref_log[k])) <= 1e-3 * max(1.0, abs(float(ref_log[k]))), (k, float(log[k]), float(ref_log[k]))
+    assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total))
+
+
+def test_backward_vs_oracle_autograd(hip, small):
+    """Every trainable tensor's gradient of the total loss vs torch autograd of the oracle."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    P = R.to_torch(small["params"], requires_grad=True)
+    ref_out = R.detr_forward(torch.from_numpy(small["images"]), P)
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(small["t_bbox"]), torch.from_numpy(small["t_class"]), 91)
+    ref_total.backward()
+    model = small["model"]
+    opt = setup_optimizers(model, small["cfg"])
+    training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
+    torch.cuda.synchronize()
+    worst = []
+    for name, gv in model.engine.P.gviews.items():
+        ref = P[name].grad
+        assert ref is not None, name
+        r = _rel(gv, ref)
+        worst.append((r, name))
+    worst.sort(reverse=True)
+    bad = [(r, n) for r, n in worst if r > 2e-3]
+    assert not bad, f"gradient mismatch (rel err, tensor): {bad[:10]}"
+
+
+def test_train_steps_vs_oracle_adam(hip):
+    """Two full train steps (forward, set loss, backward, per-tensor clipnorm, 3x Adam) on a reduced
+    depth model vs the oracle optimiser; also the accumulate/apply cadence with target_batch."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L, optim_ref as O
+    cfg = _cfg()
+    cfg.backbone_lr.assign(1e-4)
+    cfg.transformers_lr.assign(1e-3)
+    params = R.make_params(5, num_enc=1, num_dec=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    rng = np.random.default_rng(2)
+    ref_params = {k: v.copy() for k, v in params.items()}
+    ref_opts = {g: O.Adam(lr, clipnorm=0.1) for g, lr in (("backbone", 1e-4), ("transformers", 1e-3), ("nlayers", 1e-4))}
+    for step in range(2):
+        images = rng.normal(size=(2, 96, 128, 3)).astype(np.float32)
+        t_bbox, t_class = L.make_targets(2, seed=30 + step, force_full=False)
+        out, total, log, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+        for name in steps:
+            training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], step, cfg)
+        P = R.to_torch(ref_params, requires_grad=True)
+        ref_out = R.detr_forward(torch.from_numpy(images), P, num_enc=1, num_dec=2)
+        ref_total, _ = L.get_losses(ref_out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+        ref_total.backward()
+        assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total)), (step, float(total), float(ref_total))
+        grads = {k: P[k].grad.numpy() for k in P if R.trainable(k)}
+        for g in ref_opts:
+            ref_opts[g].apply({k: v for k, v in grads.items() if O.variable_group(k) == g}, ref_params)
+    torch.cuda.synchronize()
+    got = model.engine.P.state_dict()
+    for k in ref_params:
+        if R.trainable(k):
+            # Adam's first steps move every weight by ~lr: compare the UPDATE, not the weight
+            upd_ref = ref_params[k] - params[k]
+            upd = got[k] - params[k]
+            denom = np.abs(upd_ref).max() + 1e-12
+            assert np.abs(upd - upd_ref).max() / denom < 2e-2, (k, np.abs(upd - upd_ref).max() / denom)
+    assert log["backbone_lr"] == pytest.approx(1e-4) and log["transformers_lr"] == pytest.approx(1e-3)
+
+
+def test_finetune_heads_and_inference(hip):
+    """include_top=False + nb_class (detr.py:94-114) and get_model_inference (inference.py:68-95)."""
+    from detr_tf.inference import get_model_inference
+    from detr_tf.networks.detr import get_detr_model
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(9, num_enc=1, num_dec=6, nb_class=4)
+    model = get_detr_model(cfg, include_top=False, nb_class=4, num_encoder_layers=1, num_decoder_layers=6)
+    assert cfg.nlayers == ["cls_layer", "pos_layer"]
+    assert not model.load_weights(params)
+    images = np.random.default_rng(1).normal(size=(1, 64, 96, 3)).astype(np.float32)
+    out = model(images)
+    ref = R.detr_forward(torch.from_numpy(images), R.to_torch(params), num_enc=1, num_dec=6)
+    assert _rel(out["pred_logits"], ref["pred_logits"]) < 2e-4 and len(out["aux"]) == 5
+    for fmt in ("xy_center", "xyxy", "yxyx"):
+        b, l, s = get_model_inference(out, 3, fmt)
+        rb, rl, rs = L.get_model_inference(ref, 3, fmt)
+        assert torch.equal(l.cpu(), rl) and _rel(b, rb) < 1e-4 and _rel(s, rs) < 1e-4
+    hs = get_detr_model(cfg, include_top=False, num_encoder_layers=1, num_decoder_layers=2)(images)
+    assert tuple(hs.shape) == (2, 1, 100, 256)
+
+
+def test_c2_full_size_forward_loss_parity(hip):
+    """BASELINE config C2: R50 fp32 forward + set loss at B=8, 800x1333, Q=100, 92 logits."""
+    from detr_tf.loss.loss import get_losses
+    from detr_tf.networks.detr import get_detr_model
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg(train=False)
+    params = R.make_params(0)
+    model = get_detr_model(cfg, include_top=True)
+    model.load_weights(params)
+    B = 8
+    images = np.random.default_rng(1234).normal(size=(B, 800, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(B, seed=1235)
+    out = model(images)
+    total, log = get_losses(out, t_bbox, t_class, cfg)
+    P = R.to_torch(params)
+    with torch.no_grad():
+        refs = [R.detr_forward(torch.from_numpy(images[b:b + 1]), P) for b in range(B)]
+    ref = {"pred_logits": torch.cat([r["pred_logits"] for r in refs]), "pred_boxes": torch.cat([r["pred_boxes"] for r in refs]),
+           "aux": [{"pred_logits": torch.cat([r["aux"][i]["pred_logits"] for r in refs]),
+                    "pred_boxes": torch.cat([r["aux"][i]["pred_boxes"] for r in refs])} for i in range(5)]}
+    ref_total, ref_log = L.get_losses(ref, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    assert tuple(out["pred_logits"].shape) == (8, 100, 92)
+    assert _rel(out["pred_logits"], ref["pred_logits"]) < 1e-3
+    assert _rel(out["pred_boxes"], ref["pred_boxes"]) < 1e-3
+    assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total)), (float(total), float(ref_total))
