@@ -46,11 +46,21 @@ def make_targets(B, rng, rows=100):
     return t_bbox, t_class
 
 
-def cpu_baseline(height, width, budget_s=25.0):
+def _pick_threads(requested):
+    if requested > 0:
+        return requested
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 32))        # torch-CPU convs stop scaling (and thrash) far below 256 threads
+
+
+def cpu_baseline(height, width, budget_s=25.0, threads=0):
     """The oracle (kind "port": CPU restatement of the reference, torch-CPU fp32 + SciPy matcher)
     timed on the host cores on a bounded sample: train steps at batch 1 of the same shape."""
     from oracle import detr_ref as R, optim_ref as O, set_loss_ref as L
-    cores = os.cpu_count() or 1
+    cores = _pick_threads(threads)
     torch.set_num_threads(cores)
     params = R.make_params(0)
     rng = np.random.default_rng(1234)
@@ -70,7 +80,7 @@ def cpu_baseline(height, width, budget_s=25.0):
             opts[g].apply({k: v for k, v in grads.items() if O.variable_group(k) == g}, params)
         times.append(time.perf_counter() - t1)
         n += 1
-        if n >= 3 or time.perf_counter() - t0 > budget_s:
+        if n >= 4 or time.perf_counter() - t0 > budget_s:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
     return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
@@ -89,6 +99,8 @@ def main():
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
 
     from detr_tf import _hip, parallel, training
@@ -166,6 +178,9 @@ def main():
         roofline = None
         if prof is not None:
             fam = prof.summary()
+            if args.dump_shapes:
+                with open(args.dump_shapes, "w") as f:
+                    json.dump({"steps": args.steps, "rows": prof.by_shape(60)}, f, indent=1)
             if fam:
                 dom = max(fam, key=lambda k: fam[k]["ms"])
                 d = fam[dom]
@@ -192,7 +207,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(args.height, args.width)
+                res["cpu_baseline"] = cpu_baseline(args.height, args.width, threads=args.cpu_threads)
             except Exception as e:          # the baseline is a report, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
         else:

@@ -97,15 +97,28 @@ class KernelProfiler:
         ev.record()
         return ev
 
-    def end(self, family, flops, ev0):
+    def end(self, family, flops, ev0, sig=None):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.records.append((family, flops, ev0, ev1))
+        self.records.append((family, flops, ev0, ev1, sig))
+
+    def by_shape(self, top=40):
+        """Per (family, shape signature) totals, sorted by time: where the GEMM time goes."""
+        torch.cuda.synchronize()
+        agg = {}
+        for fam, flops, e0, e1, sig in self.records:
+            d = agg.setdefault((fam, sig), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += flops
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [{"family": k[0], "shape": k[1], "launches": v[0], "ms": round(v[1], 3),
+                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0.0} for k, v in rows]
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, e0, e1 in self.records:
+        for fam, flops, e0, e1, _sig in self.records:
             d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -178,7 +191,9 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
     if ev0 is not None:
-        PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0)
+        PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0,
+                     f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
+                     f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -235,7 +250,8 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
     if ev0 is not None:
         rows = N * (Hi * Wi if mode == 1 else Ho * Wo)
-        PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0)
+        PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0,
+                     f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}")
 
 
 def call(name, *args):

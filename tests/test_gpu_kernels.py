@@ -185,7 +185,8 @@ def test_stem_im2col_gemm_and_pool(hip):
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     ref = F.conv2d(img.double().permute(0, 3, 1, 2), k.double().permute(3, 2, 0, 1), stride=2, padding=3).permute(0, 2, 3, 1)
     col = torch.full((N * Ho * Wo, 160), 9.0, device=DEV)
-    hip.call("detr_hip_stem_im2col_f32", g(img).data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, 160)
+    imgd = g(img)
+    hip.call("detr_hip_stem_im2col_f32", imgd.data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, 160)
     y = torch.zeros(N * Ho * Wo, 64, device=DEV)
     hip.gemm(N * Ho * Wo, 64, 147, col, 160, 1, g(k.reshape(147, 64)), 64, 0, y, 64, act=1)
     close(y.view(N, Ho, Wo, 64), ref.clamp_min(0), what="stem conv via im2col")
@@ -202,7 +203,8 @@ def test_stem_im2col_gemm_and_pool(hip):
     dy = torch.randn(N, Hp, Wp, 64)
     pref.backward(dy.double())
     dx = torch.zeros(N, Ho, Wo, 64, device=DEV)
-    hip.call("detr_hip_maxpool3x3s2_bwd_f32", g(dy).data_ptr(), amax.data_ptr(), x.data_ptr(), dx.data_ptr(), N, Ho, Wo,
+    dyd = g(dy)
+    hip.call("detr_hip_maxpool3x3s2_bwd_f32", dyd.data_ptr(), amax.data_ptr(), x.data_ptr(), dx.data_ptr(), N, Ho, Wo,
              64, Hp, Wp)
     # gradients at x == 0 are dropped by the fused ReLU mask; torch routes ties at 0 arbitrarily
     refdx = xc.grad * (xc.detach() > 0)
@@ -213,11 +215,13 @@ def test_subsample2(hip):
     x = torch.randn(2, 9, 13, 16)
     Ho, Wo = 5, 7
     y = torch.zeros(2, Ho, Wo, 16, device=DEV)
-    hip.call("detr_hip_subsample2_fwd_f32", g(x).data_ptr(), y.data_ptr(), 2, 9, 13, 16, Ho, Wo)
+    xd = g(x)
+    hip.call("detr_hip_subsample2_fwd_f32", xd.data_ptr(), y.data_ptr(), 2, 9, 13, 16, Ho, Wo)
     assert torch.equal(y.cpu(), x[:, ::2, ::2, :])
     dy = torch.randn(2, Ho, Wo, 16)
     dx = torch.full((2, 9, 13, 16), 3.0, device=DEV)
-    hip.call("detr_hip_subsample2_bwd_f32", g(dy).data_ptr(), dx.data_ptr(), 2, 9, 13, 16, Ho, Wo)
+    dyd = g(dy)
+    hip.call("detr_hip_subsample2_bwd_f32", dyd.data_ptr(), dx.data_ptr(), 2, 9, 13, 16, Ho, Wo)
     ref = torch.zeros(2, 9, 13, 16)
     ref[:, ::2, ::2, :] = dy
     assert torch.equal(dx.cpu(), ref)
@@ -243,7 +247,8 @@ def test_layernorm_fwd_bwd(hip, rows, C):
     close(yd, y, rtol=1e-5, what="layernorm fwd")
     dxd = torch.zeros(rows, C, device=DEV)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    hip.call("detr_hip_layernorm_bwd_f32", g(dy.float()).data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
+    dyd = g(dy.float())
+    hip.call("detr_hip_layernorm_bwd_f32", dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
              rstd.data_ptr(), dxd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C)
     close(dxd, x.grad, rtol=2e-5, what="layernorm dx")
     close(dg, gam.grad, rtol=5e-5, what="layernorm dgamma")
@@ -269,38 +274,46 @@ def test_softmax_rows(hip, rows, cols, ld):
 
 def test_small_elementwise(hip):
     torch.manual_seed(9)
+    # NOTE: every device tensor is bound to a local before its pointer is taken (a temporary would be
+    # freed -- and its block reused by the next allocation -- before the kernel runs)
     x = torch.randn(8400, 300)
+    xd = g(x)
     out = torch.zeros(300, device=DEV)
-    hip.call("detr_hip_colsum_f32", g(x).data_ptr(), out.data_ptr(), 8400, 300, 300, ctypes.c_float(0.5))
+    hip.call("detr_hip_colsum_f32", xd.data_ptr(), out.data_ptr(), 8400, 300, 300, ctypes.c_float(0.5))
     close(out, 0.5 * x.double().sum(0), rtol=2e-5, what="colsum")
     a, p = torch.randn(4, 50, 256), torch.randn(50, 256)
+    ad, pd = g(a), g(p)
     o = torch.zeros(4, 50, 256, device=DEV)
-    hip.call("detr_hip_add_bcast_f32", g(a).data_ptr(), g(p).data_ptr(), o.data_ptr(), a.numel(), p.numel())
+    hip.call("detr_hip_add_bcast_f32", ad.data_ptr(), pd.data_ptr(), o.data_ptr(), a.numel(), p.numel())
     assert torch.equal(o.cpu(), a + p)
     b = torch.randn(4, 50, 256)
-    hip.call("detr_hip_add_f32", g(a).data_ptr(), g(b).data_ptr(), o.data_ptr(), a.numel())
+    bd_ = g(b)
+    hip.call("detr_hip_add_f32", ad.data_ptr(), bd_.data_ptr(), o.data_ptr(), a.numel())
     assert torch.equal(o.cpu(), a + b)
     y = torch.rand(1000)
     dy = torch.randn(1000)
+    yd, dyd, ymd = g(y), g(dy), g(y - 0.5)
     dz = torch.zeros(1000, device=DEV)
-    hip.call("detr_hip_sigmoid_bwd_f32", g(dy).data_ptr(), g(y).data_ptr(), dz.data_ptr(), 1000)
+    hip.call("detr_hip_sigmoid_bwd_f32", dyd.data_ptr(), yd.data_ptr(), dz.data_ptr(), 1000)
     close(dz, dy * y * (1 - y), rtol=1e-6, what="sigmoid bwd")
-    hip.call("detr_hip_relu_mask_f32", g(dy).data_ptr(), g(y - 0.5).data_ptr(), dz.data_ptr(), 1000)
+    hip.call("detr_hip_relu_mask_f32", dyd.data_ptr(), ymd.data_ptr(), dz.data_ptr(), 1000)
     assert torch.equal(dz.cpu(), torch.where(y - 0.5 > 0, dy, torch.zeros(())))
     w, sc = torch.randn(576, 64), torch.rand(64)
+    wd_, scd = g(w), g(sc)
     wo = torch.zeros(576, 64, device=DEV)
-    hip.call("detr_hip_scale_cols_f32", g(w).data_ptr(), g(sc).data_ptr(), wo.data_ptr(), 576, 64)
+    hip.call("detr_hip_scale_cols_f32", wd_.data_ptr(), scd.data_ptr(), wo.data_ptr(), 576, 64)
     assert torch.equal(wo.cpu(), w * sc)
     bw, bb, bm, bv = torch.rand(64) + .5, torch.randn(64), torch.randn(64), torch.rand(64) + .5
+    bwd_, bbd, bmd, bvd = g(bw), g(bb), g(bm), g(bv)
     s_, h_ = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
-    hip.call("detr_hip_bn_fold_f32", g(bw).data_ptr(), g(bb).data_ptr(), g(bm).data_ptr(), g(bv).data_ptr(), s_.data_ptr(),
+    hip.call("detr_hip_bn_fold_f32", bwd_.data_ptr(), bbd.data_ptr(), bmd.data_ptr(), bvd.data_ptr(), s_.data_ptr(),
              h_.data_ptr(), 64, ctypes.c_float(1e-5))
     rs = bw * torch.rsqrt(bv + 1e-5)
     close(s_, rs, rtol=1e-6, what="bn scale")
     close(h_, bb - bm * rs, rtol=1e-6, what="bn shift")
     acc, gg = torch.randn(999), torch.randn(999)
-    accd = g(acc)
-    hip.call("detr_hip_axpy_f32", accd.data_ptr(), g(gg).data_ptr(), ctypes.c_float(2.0), 999)
+    accd, ggd = g(acc), g(gg)
+    hip.call("detr_hip_axpy_f32", accd.data_ptr(), ggd.data_ptr(), ctypes.c_float(2.0), 999)
     close(accd, acc + 2 * gg, rtol=1e-6, what="axpy")
     z = torch.ones(1001, device=DEV)
     hip.zero_(z)
@@ -370,8 +383,9 @@ def test_assign_ties_and_invalid(hip):
     tfp = torch.zeros((P, Q), device=DEV, dtype=torch.int32)
     pft = torch.zeros((P, ldc), device=DEV, dtype=torch.int32)
     st = torch.zeros((P,), device=DEV, dtype=torch.int32)
-    hip.call("detr_hip_assign_f32", g(torch.tensor(cost)).data_ptr(), P, Q, ldc, g(torch.tensor(t_bbox)).data_ptr(), B, R,
-             tfp.data_ptr(), pft.data_ptr(), st.data_ptr())
+    cd, tbd = g(torch.tensor(cost)), g(torch.tensor(t_bbox))
+    hip.call("detr_hip_assign_f32", cd.data_ptr(), P, Q, ldc, tbd.data_ptr(), B, R, tfp.data_ptr(), pft.data_ptr(),
+             st.data_ptr())
     st, pft = st.cpu().numpy(), pft.cpu().numpy()
     assert st[0] == 0 and st[1] == 0 and st[2] == 1 and st[3] == 1      # SciPy raises ValueError for both
     for p in (0, 1):

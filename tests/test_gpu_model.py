@@ -20,7 +20,25 @@ def _cfg(train=True):
 
 def _rel(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+def _grad_report(engine, P_ref, rtol=2e-3):
+    """Per-tensor gradient comparison.  A tensor passes when max|g - ref| <= rtol * max|ref| + 1e-6 * G
+    where G is the largest gradient entry of the whole model (tensors whose true gradient is zero --
+    e.g. the q/k projections of decoder layer 0, whose values are all equal -- hold only rounding noise)."""
+    gmax = max(float(P_ref[n].grad.abs().max()) for n in engine.P.gviews)
+    rows = []
+    for name, gv in engine.P.gviews.items():
+        ref = P_ref[name].grad.double()
+        err = float((gv.detach().cpu().double() - ref).abs().max())
+        tol = rtol * float(ref.abs().max()) + 1e-6 * gmax
+        rows.append((err / tol, name, err, float(ref.abs().max())))
+    rows.sort(reverse=True)
+    return rows
 
 
 @pytest.fixture(scope="module")
@@ -95,15 +113,34 @@ def test_backward_vs_oracle_autograd(hip, small):
     opt = setup_optimizers(model, small["cfg"])
     training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
     torch.cuda.synchronize()
-    worst = []
-    for name, gv in model.engine.P.gviews.items():
-        ref = P[name].grad
-        assert ref is not None, name
-        r = _rel(gv, ref)
-        worst.append((r, name))
-    worst.sort(reverse=True)
-    bad = [(r, n) for r, n in worst if r > 2e-3]
-    assert not bad, f"gradient mismatch (rel err, tensor): {bad[:10]}"
+    rows = _grad_report(model.engine, P)
+    bad = [r for r in rows if r[0] > 1.0]
+    assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
+
+
+def test_backward_small_shapes_vs_oracle(hip):
+    """Same check on the reduced model / tiny feature map (3x4 tokens) used by the train-step test:
+    exercises the partial-tile and split-free code paths of every backward kernel."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(5, num_enc=1, num_dec=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    images = np.random.default_rng(2).normal(size=(2, 96, 128, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=30, force_full=False)
+    training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    P = R.to_torch(params, requires_grad=True)
+    ref_out = R.detr_forward(torch.from_numpy(images), P, num_enc=1, num_dec=2)
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    ref_total.backward()
+    torch.cuda.synchronize()
+    rows = _grad_report(model.engine, P)
+    bad = [r for r in rows if r[0] > 1.0]
+    assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
 
 
 def test_train_steps_vs_oracle_adam(hip):
@@ -135,18 +172,63 @@ def test_train_steps_vs_oracle_adam(hip):
         ref_total.backward()
         assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total)), (step, float(total), float(ref_total))
         grads = {k: P[k].grad.numpy() for k in P if R.trainable(k)}
+        before = {k: v.copy() for k, v in ref_params.items()}
         for g in ref_opts:
             ref_opts[g].apply({k: v for k, v in grads.items() if O.variable_group(k) == g}, ref_params)
-    torch.cuda.synchronize()
-    got = model.engine.P.state_dict()
-    for k in ref_params:
-        if R.trainable(k):
-            # Adam's first steps move every weight by ~lr: compare the UPDATE, not the weight
-            upd_ref = ref_params[k] - params[k]
-            upd = got[k] - params[k]
-            denom = np.abs(upd_ref).max() + 1e-12
-            assert np.abs(upd - upd_ref).max() / denom < 2e-2, (k, np.abs(upd - upd_ref).max() / denom)
+        torch.cuda.synchronize()
+        got = model.engine.P.state_dict()
+        # Adam normalises every entry by its own |g|: an entry whose gradient is rounding noise gets an
+        # O(lr) update of arbitrary sign.  So (a) the bulk of every tensor must agree (mean abs deviation of
+        # the update < 2 % of lr) and (b) entries whose oracle gradient is well above the noise must agree
+        # tightly; the engine continues from the ORACLE's parameters so that steps are compared one by one.
+        report = []
+        for k in grads:
+            lr = 1e-3 if O.variable_group(k) == "transformers" else 1e-4
+            upd_ref = ref_params[k] - before[k]
+            upd = got[k] - before[k]
+            dev = np.abs(upd - upd_ref)
+            gk = np.abs(grads[k])
+            solid = gk > 1e-3 * gk.max()
+            tight = float(dev[solid].max()) / lr if solid.any() else 0.0
+            report.append((max(float(dev.mean()) / lr / 0.02, tight / 0.05), k, float(dev.mean()) / lr, tight))
+        report.sort(reverse=True)
+        assert report[0][0] <= 1.0, f"step {step}: update mismatch (score, tensor, mean dev/lr, solid-entry dev/lr): {report[:10]}"
+        model.load_weights(ref_params)
     assert log["backbone_lr"] == pytest.approx(1e-4) and log["transformers_lr"] == pytest.approx(1e-3)
+
+
+def test_gradient_accumulation_cadence(hip):
+    """target_batch // batch_size = 2 (optimizers.py:137-163): no apply on even steps, one Adam apply on odd
+    steps with the SUM of the two half-scaled gradients (training.py:20)."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    cfg.batch_size, cfg.target_batch = 2, 4
+    params = R.make_params(6, num_enc=1, num_dec=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    images = np.random.default_rng(3).normal(size=(2, 64, 96, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=31, force_full=False)
+    w0 = model.engine.P.flat.clone()
+    _, total, log, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    g_half = model.engine.P.grad.clone()
+    for name in steps:
+        training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], 0, cfg)
+    assert torch.equal(model.engine.P.flat, w0), "parameters moved on an accumulation-only step"
+    assert all(opt[f"{n}_optimizer"].iterations == 0 for n in ("backbone", "transformers", "nlayers"))
+    _, total2, _, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    for name in steps:
+        training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], 1, cfg)
+    torch.cuda.synchronize()
+    assert all(opt[f"{n}_optimizer"].iterations == 1 for n in ("backbone", "transformers", "nlayers"))
+    acc = opt["transformers_gradients"]
+    o, n = model.engine.P.offsets["class_embed/kernel"]
+    assert _rel(acc[o:o + n], 2 * g_half[o:o + n]) < 1e-3          # same batch twice -> twice the half gradient
+    assert not torch.equal(model.engine.P.flat, w0)
+    assert abs(float(total) - float(total2)) < 1e-5 * abs(float(total))   # same weights, same batch
 
 
 def test_finetune_heads_and_inference(hip):

@@ -1,0 +1,162 @@
+"""CPU tests of the multi-process data-parallel path (gloo, world_size 2) and of the host logic
+that does not need a GPU (parameter store layout, buckets, config, positional encoding)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "detr-tensorflow_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from detr_tf import parallel
+    r, w = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def _bucket_job(rank, world):
+    from detr_tf import parallel
+    n = 1000
+    grad = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    bounds = [(0, 300), (300, 300), (300, 900), (900, 1000)]      # one empty bucket
+    dp = parallel.DataParallel(grad, bounds)
+    order = []
+    for i in range(4):
+        dp.on_bucket(i)
+        order.append(i)
+    dp.finish()
+    sums = torch.tensor([1.0 + rank, 2.0, 3.0 * rank])
+    dp.reduce_sums(sums)
+    return grad.numpy().copy(), sums.numpy().copy(), parallel.shard_batch(64, rank, world)
+
+
+def test_bucketed_allreduce_and_shards_gloo():
+    out = _run(_bucket_job, 2)
+    expect = np.arange(1000, dtype=np.float32) * 3            # (1 + 2) x
+    for r in (0, 1):
+        g, s, shard = out[r]
+        assert np.array_equal(g, expect)
+        assert np.allclose(s, [3.0, 4.0, 3.0])
+        assert shard == (r * 32, (r + 1) * 32)
+
+
+def _loss_normaliser_job(rank, world):
+    """The whole-batch set loss (loss.py:66-67,82,94) from per-rank sums + ONE all-reduce of the
+    normalisers equals the oracle on the concatenated batch."""
+    from detr_tf import parallel
+    from oracle import set_loss_ref as L
+    B, Q, C = 4, 100, 92
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(B, Q, C, generator=g)
+    boxes = torch.rand(B, Q, 4, generator=g) * 0.5 + 0.1
+    tb, tc = L.make_targets(B, seed=4, force_full=False)
+    tb, tc = torch.tensor(tb), torch.tensor(tc)
+    lo, hi = parallel.shard_batch(B, rank, world)
+    sums = torch.zeros(4)                                        # sum w*CE, sum w, sum L1, sum (1-giou)  (+ n_pos = col 1 pos part)
+    npos = torch.zeros(1)
+    for b in range(lo, hi):
+        ti, pi, sel, tbs, tcs = L.hungarian_matching(tb[b], tc[b], boxes[b], logits[b])
+        ce = torch.logsumexp(logits[b], -1)
+        tgt = torch.full((Q,), 91, dtype=torch.int64)
+        tgt[pi] = tcs[ti].long()
+        w = torch.full((Q,), 0.1)
+        w[pi] = 1.0
+        ce = ce - logits[b].gather(1, tgt[:, None])[:, 0]
+        sums[0] += (ce * w).sum()
+        sums[1] += w.sum()
+        sums[2] += (boxes[b][pi] - tbs[ti]).abs().sum()
+        sums[3] += (1 - torch.diagonal(L.giou_matrix(L.xcycwh_to_xy_min_xy_max(boxes[b][pi]), L.xcycwh_to_xy_min_xy_max(tbs[ti])))).sum()
+        npos += len(pi)
+    dp = parallel.DataParallel(torch.zeros(4), [(0, 4)])
+    dp.reduce_sums(sums)
+    dp.reduce_sums(npos)
+    total = sums[0] / sums[1] + 2 * sums[3] / npos[0] + 5 * sums[2] / npos[0]
+    ref_total, _ = L.get_losses({"pred_logits": logits, "pred_boxes": boxes}, tb, tc, 91)
+    return float(total), float(ref_total)
+
+
+def test_dp_loss_normalisers_match_whole_batch_oracle():
+    out = _run(_loss_normaliser_job, 2)
+    for r in (0, 1):
+        got, ref = out[r]
+        assert abs(got - ref) < 1e-4 * abs(ref), (got, ref)
+
+
+def test_param_store_layout_and_buckets_cpu():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "detr-tensorflow_amd"))
+    from detr_tf.params import ParamStore, variable_group
+    from oracle import detr_ref as R
+    st = ParamStore("cpu", num_enc=1, num_dec=1)
+    assert all(o % 4 == 0 for o, _ in st.offsets.values())              # 16-byte aligned tensors
+    b = st.bucket_bounds()
+    assert b[0][0] == 0 and b[-1][1] == st.total and all(b[i][1] == b[i + 1][0] for i in range(3))
+    names = list(st.shapes)
+    assert names[0].startswith("class_embed") and names[-1] == "backbone/conv1/kernel"    # reverse-forward order
+    params = R.make_params(1, num_enc=1, num_dec=1)
+    assert st.load_dict(params) == []
+    back = st.state_dict()
+    assert all(np.array_equal(back[k], params[k]) for k in params)
+    t = st.build_tables(["cls_layer", "pos_layer"], chunk=4096)
+    assert t["n_chunks"] == sum(-(-n // 4096) for _, n in st.offsets.values())
+    assert variable_group("input_proj/bias", []) == 0 and variable_group("query_embed/kernel", []) == 0
+    assert variable_group("bbox_embed_1/kernel", []) == 1 and variable_group("pos_layer/dense_0/bias", ["pos_layer"]) == 2
+
+
+def test_config_and_parser_surface():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "detr-tensorflow_amd"))
+    from detr_tf.training_config import TrainingConfig, training_config_parser
+    cfg = TrainingConfig()
+    assert cfg.image_size == (376, 672) and cfg.batch_size == 1 and cfg.target_batch == 1
+    assert cfg.gradient_norm_clipping == 0.1 and float(cfg.backbone_lr) == 1e-5 and float(cfg.nlayers_lr) == 1e-4
+    args = training_config_parser().parse_args(["--train_backbone", "--batch_size", "8", "--backbone_lr", "3e-5",
+                                                "--data_dir", "/d", "--img_dir", "im"])
+    cfg.update_from_args(args)
+    assert cfg.train_backbone and not cfg.train_transformers and cfg.batch_size == 8
+    assert float(cfg.backbone_lr) == 3e-5 and cfg.target_batch is None and cfg.data.img_dir == "/d/im"
+    cfg.transformers_lr.assign(5e-5)
+    assert float(cfg.transformers_lr) == 5e-5
+
+
+def test_position_embedding_host_matches_oracle():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "detr-tensorflow_amd"))
+    from detr_tf.engine import position_embedding_sine_host
+    from oracle import detr_ref as R
+    for H, W in ((25, 42), (15, 20), (32, 42), (2, 3)):
+        got = position_embedding_sine_host(H, W)
+        ref = R.position_embedding_sine(1, H, W)[0].reshape(H * W, 256).numpy()
+        assert np.abs(got - ref).max() < 1e-6
