@@ -101,7 +101,8 @@ struct LoaderConvA {
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
 __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
-    __shared__ GemmSmem<BM, BN> sm;
+    __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
+    GemmSmem<BM, BN> &sm = *reinterpret_cast<GemmSmem<BM, BN> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    epilogue<BM, BN, WGM, WGN>(acc, a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, a.e);
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, wave, a.e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,7 +248,8 @@ struct LoaderWgradA {
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
-    __shared__ GemmSmem<BM, BN> sm;
+    __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
+    GemmSmem<BM, BN> &sm = *reinterpret_cast<GemmSmem<BM, BN> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int tn = blockIdx.x % a.tiles_n, tm = blockIdx.x / a.tiles_n;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
         cur ^= 1;
     }
     float *dw = a.dw + (long long)tap * a.Ci * a.Co;
-    epilogue<BM, BN, WGM, WGN>(acc, dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, a.e);
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,6 +484,8 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.mask = d->mask;
     e.act = d->act;
     e.atomic = 0;
+    e.vec = (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
+            (!d->residual || aligned16(d->residual)) && (!d->mask || aligned16(d->mask));   // channel counts are % 16
     if (mode == 2) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0, "conv3x3 wgrad: only scale/alpha epilogue");
         ConvWgradArgs a;

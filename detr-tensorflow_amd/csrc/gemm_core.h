@@ -36,7 +36,11 @@ struct EpiArgs {
     long long ldmask;
     int act;     // 0 none 1 relu 2 sigmoid
     int atomic;  // 1: atomicAdd into C (split-K / wgrad)
+    int vec;     // 1: C / residual / mask rows and scale / bias are 16-byte aligned -> float4 epilogue
 };
+
+template <int BM, int BN, int WGN>
+struct SmemBytes;
 
 template <int BM, int BN>
 struct GemmSmem {
@@ -44,6 +48,13 @@ struct GemmSmem {
     static constexpr int LDB = BN + GEMM_PAD;
     float A[2][GEMM_BK][LDA];
     float B[2][GEMM_BK][LDB];
+};
+
+template <int BM, int BN, int WGN>
+struct SmemBytes {
+    static constexpr int TILES = (int)sizeof(GemmSmem<BM, BN>);
+    static constexpr int STAGE = 4 * 32 * (BN / WGN + 4) * 4;
+    static constexpr int VALUE = TILES > STAGE ? TILES : STAGE;
 };
 
 // bijective XCD-aware remap of a linear workgroup id (guide T1, bijective variant)
@@ -207,37 +218,95 @@ __device__ __forceinline__ void mma_ktile(const float (*As)[BM + GEMM_PAD], cons
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// The accumulators are transposed through LDS (one 32-row strip per wave at a time) so that every
+// lane then owns 4 CONSECUTIVE columns of one row: residual / mask reads and the output store are
+// 16-byte accesses and a wave instruction covers whole 256-byte row segments (the direct
+// register->global form issued 4x more, 4-byte, store instructions and ran the output-heavy
+// layer1/layer2 GEMMs at ~1 TB/s).
 // ---------------------------------------------------------------------------------------------
+template <int BN, int WGN>
+struct StageCfg {
+    static constexpr int WTN = BN / WGN;
+    static constexpr int LD = WTN + 4;                 // floats; keeps rows 16-byte aligned
+    static constexpr int FLOATS_PER_WAVE = 32 * LD;
+    static constexpr int BYTES = 4 * FLOATS_PER_WAVE * 4;
+};
+
+__device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiArgs &e, float res, float msk) {
+    v = v * sc + bi;
+    v *= e.alpha;
+    v += res;
+    if (e.act == 1) v = fmaxf(v, 0.0f);
+    else if (e.act == 2) v = 1.0f / (1.0f + expf(-v));
+    if (e.mask) v = (msk > 0.0f) ? v : 0.0f;
+    return v;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
-                                         float *C, long long ldc, int M, int N, int m0, int n0, int wm, int wn,
-                                         int lane, const EpiArgs &e) {
+                                         float *stage_base, float *C, long long ldc, int M, int N, int m0, int n0,
+                                         int wm, int wn, int lane, int wave, const EpiArgs &e) {
     using T = TileCfg<BM, BN, WGM, WGN>;
+    using S = StageCfg<BN, WGN>;
+    constexpr int VPR = T::WTN / 4;                    // float4 per staged row
+    constexpr int ITERS = (32 * VPR) / 64;
+    float *stage = stage_base + wave * S::FLOATS_PER_WAVE;
     const int l31 = lane & 31;
     const int rh = (lane >> 5) * 4;
+    const int colbase = n0 + wn * T::WTN;
 #pragma unroll
-    for (int ni = 0; ni < T::TN; ++ni) {
-        const int col = n0 + wn * T::WTN + ni * 32 + l31;
-        if (col >= N) continue;
-        const float sc = e.scale ? e.scale[col] : 1.0f;
-        const float bi = e.bias ? e.bias[col] : 0.0f;
+    for (int mi = 0; mi < T::TM; ++mi) {
+        __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
 #pragma unroll
-        for (int mi = 0; mi < T::TM; ++mi) {
-            const int rbase = m0 + wm * T::WTM + mi * 32 + rh;
+        for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < M) {
-                    float v = acc[mi][ni][r];
-                    v = v * sc + bi;
-                    v *= e.alpha;
-                    if (e.residual) v += e.residual[(long long)row * e.ldr + col];
-                    if (e.act == 1) v = fmaxf(v, 0.0f);
-                    else if (e.act == 2) v = 1.0f / (1.0f + __expf(-v));
-                    if (e.mask) v = (e.mask[(long long)row * e.ldmask + col] > 0.0f) ? v : 0.0f;
-                    float *dst = C + (long long)row * ldc + col;
-                    if (e.atomic) unsafeAtomicAdd(dst, v);
-                    else *dst = v;
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + rh) * S::LD + ni * 32 + l31] = acc[mi][ni][r];
+        __syncthreads();
+        const int rowbase = m0 + wm * T::WTM + mi * 32;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = it * 64 + lane;
+            const int rl = idx / VPR;
+            const int c4 = (idx - rl * VPR) * 4;
+            const int row = rowbase + rl;
+            const int col = colbase + c4;
+            if (row >= M || col >= N) continue;
+            const float4 a = *reinterpret_cast<const float4 *>(stage + rl * S::LD + c4);
+            float *dst = C + (long long)row * ldc + col;
+            if (e.vec && col + 3 < N) {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (e.scale) sc = *reinterpret_cast<const float4 *>(e.scale + col);
+                if (e.bias) bi = *reinterpret_cast<const float4 *>(e.bias + col);
+                if (e.residual) rs = *reinterpret_cast<const float4 *>(e.residual + (long long)row * e.ldr + col);
+                if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + (long long)row * e.ldmask + col);
+                float4 o;
+                o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x);
+                o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y);
+                o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z);
+                o.w = epi_one(a.w, sc.w, bi.w, e, rs.w, mk.w);
+                if (e.atomic) {
+                    unsafeAtomicAdd(dst + 0, o.x);
+                    unsafeAtomicAdd(dst + 1, o.y);
+                    unsafeAtomicAdd(dst + 2, o.z);
+                    unsafeAtomicAdd(dst + 3, o.w);
+                } else {
+                    *reinterpret_cast<float4 *>(dst) = o;
+                }
+            } else {
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (col + j < N) {
+                        const float sc = e.scale ? e.scale[col + j] : 1.0f;
+                        const float bi = e.bias ? e.bias[col + j] : 0.0f;
+                        const float rs = e.residual ? e.residual[(long long)row * e.ldr + col + j] : 0.0f;
+                        const float mk = e.mask ? e.mask[(long long)row * e.ldmask + col + j] : 1.0f;
+                        const float o = epi_one(av[j], sc, bi, e, rs, mk);
+                        if (e.atomic) unsafeAtomicAdd(dst + j, o);
+                        else dst[j] = o;
+                    }
                 }
             }
         }

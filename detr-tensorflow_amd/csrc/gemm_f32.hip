@@ -21,7 +21,8 @@ struct GemmArgs {
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     using T = TileCfg<BM, BN, WGM, WGN>;
-    __shared__ GemmSmem<BM, BN> sm;
+    __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
+    GemmSmem<BM, BN> &sm = *reinterpret_cast<GemmSmem<BM, BN> *>(smem_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     const int per = (nkt + g.split_k - 1) / g.split_k;
     const int kt0 = split * per;
     const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;   // empty split (uniform per workgroup)
+    if (kt0 >= kt1) return;   // empty split (uniform per workgroup, before any barrier)
 
     using LA = typename std::conditional<AK, LoaderK<BM>, LoaderMN<BM>>::type;
     using LB = typename std::conditional<BKC, LoaderK<BN>, LoaderMN<BN>>::type;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
         cur ^= 1;
     }
-    epilogue<BM, BN, WGM, WGN>(acc, C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, g.e);
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -136,12 +137,20 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     g.e.mask = d->mask; g.e.ldmask = d->ldmask;
     g.e.act = d->act;
     g.e.atomic = split > 1 ? 1 : 0;
+    g.e.vec = aligned16(d->C) && (d->ldc % 4 == 0) && (d->sC0 % 4 == 0) && (d->sC1 % 4 == 0) &&
+              (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
+              (!d->residual || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
+              (!d->mask || (aligned16(d->mask) && d->ldmask % 4 == 0));
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
     hipStream_t s = (hipStream_t)stream;
     // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
-    if (d->N <= 32) {
+    if (split > 1 && d->M <= 64 && d->N >= 256) {
+        launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);       // thin wgrad outputs: every operand is read once
+    } else if (split > 1 && d->N <= 64 && d->M > 64) {
+        launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
+    } else if (d->N <= 32) {
         launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
     } else if (d->N <= 64) {
         if ((long long)cdiv(d->M, 128) * batch * split >= 128) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);

@@ -170,11 +170,16 @@ def conv2d_valid(x_nhwc, k_hwio, stride=1, pad=0, dilation=1):
     return y.permute(0, 2, 3, 1)
 
 
-def bottleneck(x, P, p, stride, downsample):
+def bottleneck(x, P, p, stride, downsample, taps=None):
     """BottleNeck.call resnet_backbone.py:116-137 (dilation is always 1: :36,:80-85)."""
-    out = torch.relu(frozen_bn(conv2d_valid(x, P[f"{p}/conv1/kernel"]), P, f"{p}/bn1"))
-    out = torch.relu(frozen_bn(conv2d_valid(out, P[f"{p}/conv2/kernel"], stride=stride, pad=1), P, f"{p}/bn2"))
-    out = frozen_bn(conv2d_valid(out, P[f"{p}/conv3/kernel"]), P, f"{p}/bn3")
+    y1 = torch.relu(frozen_bn(conv2d_valid(x, P[f"{p}/conv1/kernel"]), P, f"{p}/bn1"))
+    y2 = torch.relu(frozen_bn(conv2d_valid(y1, P[f"{p}/conv2/kernel"], stride=stride, pad=1), P, f"{p}/bn2"))
+    if taps is not None and taps.get("_blocks"):
+        taps[f"{p}:x"], taps[f"{p}:y1"], taps[f"{p}:y2"] = x, y1, y2
+        for t in (y1, y2):
+            if t.requires_grad:
+                t.retain_grad()
+    out = frozen_bn(conv2d_valid(y2, P[f"{p}/conv3/kernel"]), P, f"{p}/bn3")
     if downsample:
         identity = frozen_bn(conv2d_valid(x, P[f"{p}/downsample_0/kernel"], stride=stride), P, f"{p}/downsample_1")
     else:
@@ -196,7 +201,7 @@ def backbone(images_nhwc, P, blocks=RESNET50_BLOCKS, taps=None):
     for li, nb in enumerate(blocks):
         for b in range(nb):
             stride = 2 if (b == 0 and li > 0) else 1     # resnet_backbone.py:39-48,80-81
-            x = bottleneck(x, P, f"backbone/layer{li + 1}/{b}", stride, b == 0)
+            x = bottleneck(x, P, f"backbone/layer{li + 1}/{b}", stride, b == 0, taps)
         if taps is not None:
             taps[f"layer{li + 1}"] = x
     return x

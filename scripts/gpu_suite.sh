@@ -13,7 +13,9 @@ for w in $WHAT; do
     kernels) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --no-header -p no:cacheprovider > $OUT/kernels.log 2>&1; echo "kernels rc=$?" >> $OUT/summary.txt ;;
     kernels_all) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider > $OUT/kernels.log 2>&1; echo "kernels rc=$?" >> $OUT/summary.txt ;;
     model) timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q --no-header -p no:cacheprovider > $OUT/model.log 2>&1; echo "model rc=$?" >> $OUT/summary.txt ;;
-    smoke) timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
+    debug) timeout 300 python scripts/debug_grad.py > $OUT/debug.log 2>&1; echo "debug rc=$?" >> $OUT/summary.txt; tail -30 $OUT/debug.log ;;
+    golden) timeout 300 python -m pytest tests/test_golden.py -m gpu -q --no-header -p no:cacheprovider > $OUT/golden.log 2>&1; echo "golden rc=$?" >> $OUT/summary.txt; tail -15 $OUT/golden.log ;;
+    smoke)timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
     bench) timeout 600 python bench.py --steps 5 --warmup 2 --dump-shapes $OUT/shapes.json > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt ;;
     fwd) timeout 300 python bench.py --steps 5 --warmup 2 --mode fwdloss --no-cpu-baseline > $OUT/bench_fwd.log 2>&1; echo "fwd rc=$?" >> $OUT/summary.txt ;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof -o prof -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events > /root/repo/$OUT/prof.log 2>&1); echo "prof rc=$?" >> $OUT/summary.txt ;;
