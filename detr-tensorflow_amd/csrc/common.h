@@ -28,6 +28,10 @@ void set_error(const char *fmt, ...);
         }                                                                               \
     } while (0)
 
+// out[r*ldc + c] += alpha * scale[c] * sum_s ws[s*part_stride + r*cols + c]   (gemm_f32.hip)
+void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
+                          float alpha, const float *scale, hipStream_t stream);
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

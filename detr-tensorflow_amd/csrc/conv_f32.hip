@@ -168,6 +168,7 @@ struct ConvWgradArgs {
     const float *dy;
     float *dw;
     int M, rows_per_split;
+    long long part_stride;   // 9*Ci*Co when the splits write partial slabs, 0 for the atomic fallback
     int tiles_m, tiles_n;
     EpiArgs e;
 };
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
         __syncthreads();
         cur ^= 1;
     }
-    float *dw = a.dw + (long long)tap * a.Ci * a.Co;
+    float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
 }
 
@@ -442,7 +443,7 @@ static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_wgrad(const ConvWgradArgs &a0, int split, hipStream_t s) {
+static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s) {
     ConvWgradArgs a = a0;
     a.tiles_m = cdiv(a.Ci, BM);
     a.tiles_n = cdiv(a.Co, BN);
@@ -457,8 +458,24 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, hipStream_t s) {
     rps = ((rps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     a.rows_per_split = rps;
     split = cdiv(a.M, rps);
+    const long long part = 9LL * a.Ci * a.Co;
+    const bool partial = split > 1 && ws && aligned16(ws) && ws_bytes >= (long long)split * part * 4;
+    float *dw_final = a.dw;
+    const EpiArgs final_e = a.e;
+    a.part_stride = 0;
+    if (partial) {
+        a.dw = ws;
+        a.part_stride = part;
+        a.e.alpha = 1.0f;
+        a.e.scale = nullptr;
+        a.e.atomic = 0;
+        a.e.vec = 1;
+    } else if (split == 1) {
+        a.e.atomic = 1;   // accumulate onto dw
+    }
     dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
+    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
 }
 
 }  // namespace detr
@@ -495,8 +512,8 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         a.M = d->N * d->Ho * d->Wo;
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
-        if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, s);
-        else launch_wgrad<64, 64, 2, 2>(a, d->split, s);
+        if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
+        else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         DETR_LAUNCH_CHECK("conv3x3 wgrad");
         return 0;
     }

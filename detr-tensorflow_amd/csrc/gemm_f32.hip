@@ -13,6 +13,7 @@ struct GemmArgs {
     int batch_inner;
     long long sA0, sA1, sB0, sB1, sC0, sC1;
     int split_k;
+    long long part_stride;   // partial-slab stride (deterministic split-K), 0 otherwise
     int tiles_m, tiles_n;
     int a_vec, b_vec;
     EpiArgs e;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     const int z0 = zb / g.batch_inner, z1 = zb % g.batch_inner;
     const float *A = g.A + z0 * g.sA0 + z1 * g.sA1;
     const float *B = g.B + z0 * g.sB0 + z1 * g.sB1;
-    float *C = g.C + z0 * g.sC0 + z1 * g.sC1;
+    float *C = g.C + z0 * g.sC0 + z1 * g.sC1 + (long long)split * g.part_stride;
 
     const int nkt = (g.K + GEMM_BK - 1) / GEMM_BK;
     const int per = (nkt + g.split_k - 1) / g.split_k;
@@ -87,6 +88,50 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
+                                                            int rows, int cols, float *__restrict__ C, long long ldc,
+                                                            float alpha, const float *__restrict__ scale, int vec) {
+    if (vec) {
+        const int c4n = cols >> 2;
+        const long long total = (long long)rows * c4n;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n) * 4;
+            const float *p = ws + (long long)r * cols + c;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < splits; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + k * part_stride);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (scale) sc = *reinterpret_cast<const float4 *>(scale + c);
+            float4 *dst = reinterpret_cast<float4 *>(C + (long long)r * ldc + c);
+            float4 o = *dst;
+            o.x += alpha * sc.x * s.x; o.y += alpha * sc.y * s.y; o.z += alpha * sc.z * s.z; o.w += alpha * sc.w * s.w;
+            *dst = o;
+        }
+    } else {
+        const long long total = (long long)rows * cols;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += ws[k * part_stride + i];
+            C[(long long)r * ldc + c] += alpha * (scale ? scale[c] : 1.0f) * s;
+        }
+    }
+}
+
+void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
+                          float alpha, const float *scale, hipStream_t stream) {
+    const int vec = (cols % 4 == 0) && (ldc % 4 == 0) && (part_stride % 4 == 0) && aligned16(ws) && aligned16(C) &&
+                    (!scale || aligned16(scale));
+    const long long total = (long long)rows * (vec ? cols / 4 : cols);
+    long long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols, C,
+                       ldc, alpha, scale, vec);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
     GemmArgs a = g;
@@ -111,7 +156,12 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     DETR_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
     const int batch = d->batch > 0 ? d->batch : 1;
     const int inner = d->batch_inner > 0 ? d->batch_inner : 1;
-    const int split = d->split_k > 1 ? d->split_k : 1;
+    int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > 1) {   // no empty splits: recompute the effective count from the K tiles each split gets
+        const int nkt = cdiv(d->K, GEMM_BK);
+        const int per = cdiv(nkt, split);
+        split = cdiv(nkt, per);
+    }
     if (split > 1) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0,
                      "gemm: split_k allows only scale/alpha in the epilogue");
@@ -126,6 +176,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     g.batch_inner = inner;
     g.sA0 = d->sA0; g.sA1 = d->sA1; g.sB0 = d->sB0; g.sB1 = d->sB1; g.sC0 = d->sC0; g.sC1 = d->sC1;
     g.split_k = split;
+    g.part_stride = 0;
     g.tiles_m = g.tiles_n = 0;
     auto strides_ok = [](long long ld, long long s0, long long s1) { return (ld % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0); };
     g.a_vec = aligned16(d->A) && strides_ok(d->lda, d->sA0, d->sA1);
@@ -144,6 +195,19 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
     hipStream_t s = (hipStream_t)stream;
+    const long long part = (long long)d->M * d->N;
+    const bool partial = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace) &&
+                         d->workspace_bytes >= (long long)split * part * 4;
+    EpiArgs final_e = g.e;
+    if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
+        g.C = d->workspace;
+        g.ldc = d->N;
+        g.part_stride = part;
+        g.e.alpha = 1.0f;
+        g.e.scale = nullptr;
+        g.e.atomic = 0;
+        g.e.vec = (d->N % 4 == 0);
+    }
     // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
     if (split > 1 && d->M <= 64 && d->N >= 256) {
@@ -161,5 +225,9 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     }
     DETR_LAUNCH_CHECK("gemm");
+    if (partial) {
+        launch_splitk_reduce(d->workspace, split, part, d->M, d->N, d->C, d->ldc, final_e.alpha, final_e.scale, s);
+        DETR_LAUNCH_CHECK("gemm split-k reduce");
+    }
     return 0;
 }

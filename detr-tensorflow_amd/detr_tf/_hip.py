@@ -28,7 +28,8 @@ class GemmDesc(Structure):
                 ("scale", c_void_p), ("bias", c_void_p),
                 ("residual", c_void_p), ("ldr", c_int64),
                 ("mask", c_void_p), ("ldmask", c_int64),
-                ("act", c_int32), ("split_k", c_int32)]
+                ("act", c_int32), ("split_k", c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 class Conv3x3Desc(Structure):
@@ -37,7 +38,8 @@ class Conv3x3Desc(Structure):
                 ("x", c_void_p), ("w", c_void_p), ("y", c_void_p),
                 ("alpha", c_float),
                 ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
-                ("act", c_int32), ("split", c_int32)]
+                ("act", c_int32), ("split", c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 class SetLossDesc(Structure):
@@ -127,6 +129,15 @@ class KernelProfiler:
 
 
 PROFILER = None
+WORKSPACE = None      # fp32 scratch tensor for the deterministic split-K reductions (set by the engine)
+
+
+def ensure_workspace(device, floats=64 * 1024 * 1024):
+    """One shared 256 MB scratch buffer: all launches are ordered on one stream, so sharing is safe."""
+    global WORKSPACE
+    if WORKSPACE is None or WORKSPACE.device != torch.device(device) or WORKSPACE.numel() < floats:
+        WORKSPACE = torch.empty(floats, dtype=torch.float32, device=device)
+    return WORKSPACE
 
 
 def load():
@@ -172,7 +183,7 @@ def _f32(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
          residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None):
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -188,6 +199,8 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d.residual, d.ldr = ptr(residual), ldr
     d.mask, d.ldmask = ptr(mask), ldmask
     d.act, d.split_k = act, split_k
+    ws = workspace if workspace is not None else WORKSPACE
+    d.workspace, d.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
     if ev0 is not None:
@@ -246,6 +259,7 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     d.alpha = alpha
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split
+    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
     if ev0 is not None:

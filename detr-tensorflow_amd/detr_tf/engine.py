@@ -53,6 +53,7 @@ class DetrEngine:
                  num_classes=92, nb_class=None, seed=0):
         hip.load()
         self.device = torch.device(device)
+        hip.ensure_workspace(self.device)
         self.blocks = tuple(blocks)
         self.num_enc, self.num_dec, self.Q = num_enc, num_dec, num_queries
         self.nb_class = nb_class

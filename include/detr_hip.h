@@ -63,6 +63,11 @@ typedef struct {
     const float *mask; int64_t ldmask;
     int32_t act;            /* 0 none, 1 relu, 2 sigmoid */
     int32_t split_k;        /* 0/1 = no split */
+    /* optional caller-provided scratch for DETERMINISTIC split-K: when it holds at least
+     * split_k*M*N floats (and batch == 1) every split stores its partial tile there with plain
+     * 16-byte stores and a second launch reduces them onto C (C += alpha*scale*sum); otherwise
+     * the partials are accumulated with fp32 atomics. */
+    float *workspace; int64_t workspace_bytes;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 
@@ -88,6 +93,7 @@ typedef struct {
     const float *mask;
     int32_t act;
     int32_t split;       /* wgrad: number of row splits (0 = auto) */
+    float *workspace; int64_t workspace_bytes;   /* wgrad: scratch for deterministic split reduction (see detr_gemm_desc) */
 } detr_conv3x3_desc;
 int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
 

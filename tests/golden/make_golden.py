@@ -31,14 +31,18 @@ def tiny_case():
     out = R.detr_forward(torch.from_numpy(images), P, num_enc=num_enc, num_dec=num_dec)
     total, losses = L.get_losses(out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
     total.backward()
-    matched = []
+    matched, costs = [], []
     for lvl in [out] + out["aux"]:
         for b in range(B):
-            ti, pi, sel, _, _ = L.hungarian_matching(torch.from_numpy(t_bbox[b]), torch.from_numpy(t_class[b]),
-                                                     lvl["pred_boxes"][b].detach(), lvl["pred_logits"][b].detach())
+            tbs, tcs = L.strip_header(torch.from_numpy(t_bbox[b]), torch.from_numpy(t_class[b]))
+            C = L.cost_matrix(tbs, tcs, lvl["pred_boxes"][b].detach(), lvl["pred_logits"][b].detach()).numpy()
+            rows, cols, _ = L.lsap(C)
             m = np.full(100, -1, np.int32)
-            m[pi.numpy()] = ti.numpy()
+            m[rows] = cols
             matched.append(m)
+            cp = np.zeros((100, 99), np.float32)
+            cp[:, :C.shape[1]] = C
+            costs.append(cp)
     names = [k for k in params if R.trainable(k)]
     gnorm = np.array([float(P[k].grad.norm()) for k in names], np.float64)
     # two accumulated steps (target_batch // batch_size = 2) then one Adam apply per group
@@ -63,7 +67,8 @@ def tiny_case():
         pred_logits=out["pred_logits"].detach().numpy(), pred_boxes=out["pred_boxes"].detach().numpy(),
         aux0_logits=out["aux"][0]["pred_logits"].detach().numpy(), aux0_boxes=out["aux"][0]["pred_boxes"].detach().numpy(),
         loss_keys=np.array(list(losses.keys())), loss_vals=np.array([float(v) for v in losses.values()], np.float64),
-        total=np.float64(float(total)), matched=np.stack(matched), grad_names=np.array(names), grad_norms=gnorm,
+        total=np.float64(float(total)), matched=np.stack(matched), costs=np.stack(costs),
+        grad_names=np.array(names), grad_norms=gnorm,
         **{"upd_" + k.replace("/", "."): v for k, v in upd.items()}, **inf)
 
 

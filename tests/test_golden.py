@@ -60,9 +60,17 @@ def test_hip_path_reproduces_golden(hip, gold):
     assert np.allclose(got, gold["loss_vals"], rtol=1e-3, atol=1e-4), (got, gold["loss_vals"])
     assert abs(float(total) * 2 - float(gold["total"])) < 1e-3 * float(gold["total"])     # total / gradient_aggregate
     # matched index sets: order main, aux0 ; engine levels are [aux0, main]
+    # (near-duplicate predictions of this tiny random model make the optimum non-unique at the 1e-6 level, so
+    #  the check is: a valid one-to-one matching of every target whose total cost equals the stored optimum)
     tfp = out.set_loss.matcher.tgt_for_pred.cpu().numpy().reshape(num_dec, B, 100)
-    assert np.array_equal(tfp[num_dec - 1], gold["matched"][0:B])
-    assert np.array_equal(tfp[0], gold["matched"][B:2 * B])
+    for g_idx, (lv, b) in enumerate([(num_dec - 1, bb) for bb in range(B)] + [(0, bb) for bb in range(B)]):
+        n = int(gold["t_bbox"][b, 0, 0])
+        mine, ref = tfp[lv, b], gold["matched"][g_idx]
+        C = gold["costs"][g_idx]
+        assert sorted(mine[mine >= 0].tolist()) == list(range(n))
+        cost_mine = sum(C[q, mine[q]] for q in range(100) if mine[q] >= 0)
+        cost_ref = sum(C[q, ref[q]] for q in range(100) if ref[q] >= 0)
+        assert abs(cost_mine - cost_ref) < 1e-4 * max(1.0, abs(cost_ref)), (lv, b, cost_mine, cost_ref)
     # gradient norms (this step's gradient is d(total/2))
     names = [str(n) for n in gold["grad_names"]]
     gn = np.array([float(model.engine.P.gviews[n].norm()) * 2 for n in names])

@@ -101,6 +101,45 @@ def test_gemm_split_k_accumulates(hip):
     close(C, ref, rtol=5e-5, what="gemm split-k")
 
 
+def test_split_k_deterministic_workspace_path(hip):
+    """split-K through the caller-provided workspace (partials + reduce launch): same result as the
+    atomic path, bit-identical run to run; also the conv3x3 wgrad split reduction."""
+    torch.manual_seed(13)
+    M, N, K = 147, 64, 30000
+    A, B = torch.randn(K, 160), torch.randn(K, N)
+    scale = torch.rand(N) + 0.5
+    C0 = torch.randn(M, N)
+    Ad, Bd, sd = g(A), g(B), g(scale)
+    ws = torch.empty(8 * 1024 * 1024, device=DEV)
+    outs = []
+    for rep in range(2):
+        C = g(C0.clone())
+        hip.gemm(M, N, K, Ad, 160, 0, Bd, N, 0, C, N, alpha=0.5, scale=sd, split_k=97, workspace=ws)
+        outs.append(C.clone())
+    ref = C0.double() + 0.5 * (A[:, :M].double().t() @ B.double()) * scale.double()
+    close(outs[0], ref, rtol=5e-5, what="gemm split-k (workspace)")
+    assert torch.equal(outs[0], outs[1]), "workspace split-K must be deterministic"
+    old = hip.WORKSPACE
+    try:
+        hip.WORKSPACE = ws
+        Nn, H, W, Ci, Co = 2, 30, 41, 64, 64
+        x = torch.randn(Nn, H, W, Ci, dtype=torch.float64)
+        w = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
+        z = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=1, padding=1).permute(0, 2, 3, 1)
+        dz = torch.randn_like(z)
+        z.backward(dz)
+        xd, dzd = g(x.float()), g(dz.float())
+        res = []
+        for rep in range(2):
+            dwd = torch.zeros(3, 3, Ci, Co, device=DEV)
+            hip.conv3x3(2, xd, dzd, dwd, Nn, H, W, Ci, H, W, Co, 1, scale=sd, split=7)
+            res.append(dwd)
+        close(res[0], w.grad * scale.double(), rtol=5e-5, what="conv3x3 wgrad (workspace)")
+        assert torch.equal(res[0], res[1])
+    finally:
+        hip.WORKSPACE = old
+
+
 def test_gemm_batched_attention_layout(hip):
     """scores[b,h] = Q_h K_h^T and O = P V_h on the [B, L, heads*32] layout used by the transformer."""
     torch.manual_seed(4)
