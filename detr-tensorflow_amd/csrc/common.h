@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/detr_hip.h"
 
@@ -31,6 +32,12 @@ void set_error(const char *fmt, ...);
 // out[r*ldc + c] += alpha * scale[c] * sum_s ws[s*part_stride + r*cols + c]   (gemm_f32.hip)
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
                           float alpha, const float *scale, hipStream_t stream);
+
+// tuning hook: integer environment variable (0 when unset)
+static inline int env_tile(const char *name) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -512,7 +512,10 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         a.M = d->N * d->Ho * d->Wo;
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
-        if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
+        const int wforce = env_tile("DETR_HIP_WGRAD_TILE");
+        if (wforce == 3) launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
+        else if (wforce == 1) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
+        else if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         DETR_LAUNCH_CHECK("conv3x3 wgrad");
         return 0;
@@ -533,11 +536,12 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     a.e = e;
     const bool dgrad = mode == 1;
     const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
-    if (a.Cd <= 64) {
-        launch_conv<128, 64, 2, 2>(a, dgrad, s);
-    } else if (big >= 192) {
-        launch_conv<128, 128, 2, 2>(a, dgrad, s);
-    } else {
+    const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
+    if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);
+    else if (force == 2) launch_conv<128, 64, 2, 2>(a, dgrad, s);
+    else if (force == 3) launch_conv<64, 64, 2, 2>(a, dgrad, s);
+    else {
+        (void)big;   // 64x64 measured best on every backbone shape (profiles/tune_r1.txt)
         launch_conv<64, 64, 2, 2>(a, dgrad, s);
     }
     DETR_LAUNCH_CHECK("conv3x3");

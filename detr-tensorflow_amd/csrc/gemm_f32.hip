@@ -210,18 +210,20 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     }
     // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
-    if (split > 1 && d->M <= 64 && d->N >= 256) {
-        launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);       // thin wgrad outputs: every operand is read once
-    } else if (split > 1 && d->N <= 64 && d->M > 64) {
-        launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
-    } else if (d->N <= 32) {
+    const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
+    if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
+    else if (force == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
+    else if (force == 3) launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
+    else if (force == 4) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
+    else if (force == 5) launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);
+    else if (force == 6) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
+    else if (d->N <= 32) {
         launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
-    } else if (d->N <= 64) {
-        if ((long long)cdiv(d->M, 128) * batch * split >= 128) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
-        else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
-    } else if (big_tiles >= 192) {
-        launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else {
+        // measured on MI355X (scripts/tune_gemm.py, profiles/tune_r1.txt): the 64x64 tile (one 32x32 MFMA tile
+        // per wave, 8 waves/SIMD resident) beats 128x64 by 2-10 % and 128x128 by 15-50 % on every DETR shape --
+        // fp32 MFMA needs few accumulators, so occupancy (latency hiding) and tile-count balance win.
+        (void)big_tiles;
         launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     }
     DETR_LAUNCH_CHECK("gemm");
