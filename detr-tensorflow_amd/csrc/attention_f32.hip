@@ -1,0 +1,343 @@
+// attention_f32.hip -- fused multi-head attention core (head_dim 32, fp32) for gfx950:
+//     O = softmax(Q K^T) V        (Q is already scaled by 1/sqrt(32), transformer.py:307,317,340-343)
+// and its backward, flash-style: the [T, S] score / probability tensor (283 MB per encoder layer
+// at B=8, 800x1333) never touches HBM.  Layout: batch-first token matrices [B, T, heads*32]
+// (row stride ld floats); (batch, head) select a column block of 32.
+//
+// MFMA formulation (v_mfma_f32_32x32x2_f32, exact f32).  Everything is computed TRANSPOSED so that
+// the softmax row (one query) lives in ONE lane pair (l, l^32):
+//     S^T[key][query] = K_tile (A: rows = keys, LDS) x Q^T (B: per-lane registers)
+//   C/D map: lane l holds query (l&31) and the 16 keys  kr = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+//   -> row max / row sum = 15 VALU ops + one cross-half shuffle (no LDS, no serial lanes).
+//     O^T[d][query]  += V^T (A: V[key][d] read row-wise from LDS) x P^T (B: the registers above;
+//   MFMA k-step r contracts the key pair {kr(hi=0), kr(hi=1)} which is exactly what the two lane
+//   halves hold in register r -- no data movement between QK^T and PV).
+// K/V tiles: 32 keys x 32 dims row-major with row stride 33 dwords: conflict-free for both access
+// patterns (lanes over keys at fixed d, and lanes over d at fixed key).  Double-buffered
+// global->register->LDS pipeline, one barrier per key tile; 4 waves x 32 queries per workgroup.
+#include "common.h"
+
+namespace detr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT_LD = 33;
+constexpr int AT_KEYS = 32;      // keys (or queries, in the dK/dV kernel) per LDS tile
+constexpr int AT_ROWS_WG = 128;  // queries (keys) per workgroup: 4 waves x 32
+
+struct AttnArgs {
+    const float *Q, *K, *V;      // [B, T|S, ld]
+    float *O;                    // fwd out / bwd in
+    float *LSE;                  // [B*H, T] log-sum-exp of every score row
+    const float *dO;
+    float *dQ, *dK, *dV;
+    float *delta;                // [B*H, T] rowsum(dO * O)
+    int B, H, T, S;
+    long long ld;
+};
+
+__device__ __forceinline__ int krow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// cooperative load of one 32 x 32 tile (rows row0.., zero filled past nrows) into registers / LDS
+__device__ __forceinline__ float4 tile_load(const float *base, long long ld, int row0, int nrows, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 4;
+    const int row = row0 + r;
+    if (row < nrows) return *reinterpret_cast<const float4 *>(base + (long long)row * ld + c);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void tile_store(float (*S)[AT_LD], float4 v, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 4;
+    S[r][c + 0] = v.x; S[r][c + 1] = v.y; S[r][c + 2] = v.z; S[r][c + 3] = v.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ float Ks[2][AT_KEYS][AT_LD];
+    __shared__ float Vs[2][AT_KEYS][AT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int tq = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const bool qok = tq < a.T;
+    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+
+    float q[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) q[s] = qok ? Qb[(long long)tq * a.ld + 2 * s + hi] : 0.0f;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    float m = -INFINITY, lsum = 0.0f;
+
+    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    float4 rk = tile_load(Kb, a.ld, 0, a.S, tid), rv = tile_load(Vb, a.ld, 0, a.S, tid);
+    tile_store(Ks[0], rk, tid);
+    tile_store(Vs[0], rv, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = (it + 1) < ntiles;
+        if (more) {
+            rk = tile_load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rv = tile_load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][l31][2 * st + hi], q[st], s, 0, 0, 0);
+        const int kbase = it * AT_KEYS;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (kbase + krow(r, hi) >= a.S) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);              // finite: every tile holds at least one valid key
+        const float corr = expf(m - mn);            // exp(-inf) = 0 on the first tile
+        float rs = 0.0f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = expf(s[r] - mn);
+            rs += p[r];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        lsum = lsum * corr + rs;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][krow(r, hi)][l31], p[r], o, 0, 0, 0);
+        if (more) {
+            tile_store(Ks[cur ^ 1], rk, tid);
+            tile_store(Vs[cur ^ 1], rv, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (qok) {
+        const float inv = 1.0f / lsum;
+        float *Ob = a.O + ((long long)b * a.T + tq) * a.ld + h * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
+        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m + logf(lsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 1/2: dQ (per query tile, streams the keys) and delta = rowsum(dO * O)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ float Ks[2][AT_KEYS][AT_LD];
+    __shared__ float Vs[2][AT_KEYS][AT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int tq = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const bool qok = tq < a.T;
+    const long long qoff = ((long long)b * a.T + tq) * a.ld + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+
+    float q[16], dout[16];
+    float dl = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        q[s] = qok ? a.Q[qoff + 2 * s + hi] : 0.0f;
+        dout[s] = qok ? a.dO[qoff + 2 * s + hi] : 0.0f;
+        const float ov = qok ? a.O[qoff + 2 * s + hi] : 0.0f;
+        dl += dout[s] * ov;
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const float lse = qok ? a.LSE[(long long)bh * a.T + tq] : INFINITY;
+    if (qok && hi == 0) a.delta[(long long)bh * a.T + tq] = dl;
+
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
+
+    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    float4 rk = tile_load(Kb, a.ld, 0, a.S, tid), rv = tile_load(Vb, a.ld, 0, a.S, tid);
+    tile_store(Ks[0], rk, tid);
+    tile_store(Vs[0], rv, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = (it + 1) < ntiles;
+        if (more) {
+            rk = tile_load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rv = tile_load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+        }
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][l31][2 * st + hi], q[st], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][l31][2 * st + hi], dout[st], dp, 0, 0, 0);
+        }
+        const int kbase = it * AT_KEYS;
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (kbase + krow(r, hi) < a.S) ? expf(s[r] - lse) : 0.0f;
+            ds[r] = p * (dp[r] - dl);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][krow(r, hi)][l31], ds[r], dq, 0, 0, 0);
+        if (more) {
+            tile_store(Ks[cur ^ 1], rk, tid);
+            tile_store(Vs[cur ^ 1], rv, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (qok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.dQ[qoff + krow(r, hi)] = dq[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2/2: dK, dV (per key tile, streams the queries; needs LSE and delta)
+// here the natural orientation is S[query][key]: lane l holds key (l&31) and 16 queries.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ float Qs[2][AT_KEYS][AT_LD];
+    __shared__ float Ds[2][AT_KEYS][AT_LD];
+    __shared__ float Ls[2][AT_KEYS], Dl[2][AT_KEYS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int sk = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const bool kok = sk < a.S;
+    const long long koff = ((long long)b * a.S + sk) * a.ld + h * 32;
+    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
+    const float *Db = a.dO + (long long)b * a.T * a.ld + h * 32;
+    const float *lse = a.LSE + (long long)bh * a.T;
+    const float *dlt = a.delta + (long long)bh * a.T;
+
+    float kk[16], vv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        kk[s] = kok ? a.K[koff + 2 * s + hi] : 0.0f;
+        vv[s] = kok ? a.V[koff + 2 * s + hi] : 0.0f;
+    }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.0f; dv[r] = 0.0f; }
+
+    const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
+    float4 rq = tile_load(Qb, a.ld, 0, a.T, tid), rd = tile_load(Db, a.ld, 0, a.T, tid);
+    float rl = 0.f, rdl = 0.f;
+    if (tid < AT_KEYS) {
+        rl = (tid < a.T) ? lse[tid] : INFINITY;      // +inf => p = exp(-inf) = 0 for padded queries
+        rdl = (tid < a.T) ? dlt[tid] : 0.0f;
+    }
+    tile_store(Qs[0], rq, tid);
+    tile_store(Ds[0], rd, tid);
+    if (tid < AT_KEYS) { Ls[0][tid] = rl; Dl[0][tid] = rdl; }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = (it + 1) < ntiles;
+        if (more) {
+            const int t0 = (it + 1) * AT_KEYS;
+            rq = tile_load(Qb, a.ld, t0, a.T, tid);
+            rd = tile_load(Db, a.ld, t0, a.T, tid);
+            if (tid < AT_KEYS) {
+                rl = (t0 + tid < a.T) ? lse[t0 + tid] : INFINITY;
+                rdl = (t0 + tid < a.T) ? dlt[t0 + tid] : 0.0f;
+            }
+        }
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[cur][l31][2 * st + hi], kk[st], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[cur][l31][2 * st + hi], vv[st], dp, 0, 0, 0);
+        }
+        float p[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = krow(r, hi);
+            p[r] = expf(s[r] - Ls[cur][qr]);
+            ds[r] = p[r] * (dp[r] - Dl[cur][qr]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = krow(r, hi);
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[cur][qr][l31], p[r], dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[cur][qr][l31], ds[r], dk, 0, 0, 0);
+        }
+        if (more) {
+            tile_store(Qs[cur ^ 1], rq, tid);
+            tile_store(Ds[cur ^ 1], rd, tid);
+            if (tid < AT_KEYS) { Ls[cur ^ 1][tid] = rl; Dl[cur ^ 1][tid] = rdl; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (kok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a.dK[koff + krow(r, hi)] = dk[r];
+            a.dV[koff + krow(r, hi)] = dv[r];
+        }
+    }
+}
+
+static int check_args(const float *q, const float *k, const float *v, int B, int H, int T, int S, long long ld) {
+    DETR_REQUIRE(q && k && v, "attention: null operand");
+    DETR_REQUIRE(B > 0 && H > 0 && T > 0 && S > 0, "attention: bad shape B=%d H=%d T=%d S=%d", B, H, T, S);
+    DETR_REQUIRE(ld >= (long long)H * 32 && ld % 4 == 0, "attention: row stride %lld must be >= heads*32 and a multiple of 4", ld);
+    DETR_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "attention: operands must be 16-byte aligned");
+    DETR_REQUIRE((long long)B * H <= 65535, "attention: B*H=%lld exceeds grid.y", (long long)B * H);
+    return 0;
+}
+
+}  // namespace detr
+
+using namespace detr;
+
+extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
+                                          int32_t H, int32_t T, int32_t S, int64_t ld, void *stream) {
+    if (check_args(q, k, v, B, H, T, S, ld)) return -1;
+    DETR_REQUIRE(o && lse, "attention fwd: null output");
+    AttnArgs a = {};
+    a.Q = q; a.K = k; a.V = v; a.O = o; a.LSE = lse;
+    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
+    dim3 grid((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    DETR_LAUNCH_CHECK("attention fwd");
+    return 0;
+}
+
+extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
+                                          const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
+                                          int32_t H, int32_t T, int32_t S, int64_t ld, void *stream) {
+    if (check_args(q, k, v, B, H, T, S, ld)) return -1;
+    DETR_REQUIRE(o && lse && d_o && dq && dk && dv && delta, "attention bwd: null operand");
+    DETR_REQUIRE(aligned16(d_o), "attention bwd: dO must be 16-byte aligned");
+    AttnArgs a = {};
+    a.Q = q; a.K = k; a.V = v; a.O = const_cast<float *>(o); a.LSE = const_cast<float *>(lse);
+    a.dO = d_o; a.dQ = dq; a.dK = dk; a.dV = dv; a.delta = delta;
+    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H)), dim3(256), 0, s, a);
+    DETR_LAUNCH_CHECK("attention bwd dq");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)cdiv(S, AT_ROWS_WG), (unsigned)(B * H)), dim3(256), 0, s, a);
+    DETR_LAUNCH_CHECK("attention bwd dkv");
+    return 0;
+}

@@ -15,6 +15,7 @@ Reference lines implemented (paths relative to the reference root):
   backward   what tape.gradient (detr_tf/optimizers.py:115) computes for the graph above
 """
 import math
+import os
 from ctypes import byref, c_float
 
 import numpy as np
@@ -29,6 +30,8 @@ HD = 32
 FF = 2048
 BN_EPS = 1e-5
 LN_EPS = 1e-5
+# fused flash-style attention (default) vs the materialised GEMM + softmax + GEMM path (DETR_HIP_FUSED_ATTN=0)
+FUSED_ATTENTION = os.environ.get("DETR_HIP_FUSED_ATTN", "1") != "0"
 
 
 def position_embedding_sine_host(H, W, num_pos_features=128, temperature=10000.0, eps=1e-6):
@@ -145,15 +148,21 @@ class DetrEngine:
         hip.linear_fwd(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5)          # :297,:307
         hip.linear_fwd(k_in, W[D:2 * D], bias[D:2 * D], Kb)
         hip.linear_fwd(v_in, W[2 * D:], bias[2 * D:], Vb)
-        Sp = (S + 3) // 4 * 4
-        Pm = self.buf(f"{tag}:P", (B * HEADS, T, Sp))
         BH = B * HEADS
-        hip.gemm(T, S, HD, Qb, D, 1, Kb, D, 1, Pm, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD),
-                 sC=(HEADS * T * Sp, T * Sp))                                          # :317
-        hip.call("detr_hip_softmax_rows_fwd_f32", Pm.data_ptr(), BH * T, S, Sp)         # :340
         O = self.buf(f"{tag}:O", (B * T, D))
-        hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
-                 sB=(S * D, HD), sC=(T * D, HD))                                       # :343-345
+        if FUSED_ATTENTION:
+            # fused flash-style core: the [T,S] probabilities never reach HBM (csrc/attention_f32.hip)
+            lse = self.buf(f"{tag}:lse", (BH, T))
+            hip.call("detr_hip_attention_fwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(), lse.data_ptr(),
+                     B, HEADS, T, S, D)                                                # :317,:340,:343
+        else:
+            Sp = (S + 3) // 4 * 4
+            Pm = self.buf(f"{tag}:P", (B * HEADS, T, Sp))
+            hip.gemm(T, S, HD, Qb, D, 1, Kb, D, 1, Pm, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD),
+                     sC=(HEADS * T * Sp, T * Sp))                                      # :317
+            hip.call("detr_hip_softmax_rows_fwd_f32", Pm.data_ptr(), BH * T, S, Sp)     # :340
+            hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
+                     sB=(S * D, HD), sC=(T * D, HD))                                   # :343-345
         hip.linear_fwd(O, self.P.views[f"{pfx}/out_proj_kernel"], self.P.views[f"{pfx}/out_proj_bias"], out,
                        residual=residual)                                              # :346-347
 
@@ -162,8 +171,7 @@ class DetrEngine:
         d_out: gradient of the out-projection output.  dk_in/dv_in may be accumulated onto."""
         V, G = self.P.views, self.P.gviews
         W, gW, gb = V[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
-        Qb, Kb, Vb, Pm, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "P", "O"))
-        Sp = Pm.shape[2]
+        Qb, Kb, Vb, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "O"))
         BH = B * HEADS
         # out projection
         hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"])
@@ -172,13 +180,21 @@ class DetrEngine:
         hip.linear_dgrad(d_out, V[f"{pfx}/out_proj_kernel"], dO)
         # attention core
         dQ, dK, dV = self.buf("scratch:dQ", (B * T, D)), self.buf("scratch:dK", (B * S, D)), self.buf("scratch:dV", (B * S, D))
-        dP = self.buf("scratch:dP", (BH, T, Sp))
-        sP = (HEADS * T * Sp, T * Sp)
-        hip.gemm(S, HD, T, Pm, Sp, 0, dO, D, 0, dV, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
-        hip.gemm(T, S, HD, dO, D, 1, Vb, D, 1, dP, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD), sC=sP)
-        hip.call("detr_hip_softmax_rows_bwd_f32", Pm.data_ptr(), dP.data_ptr(), BH * T, S, Sp)
-        hip.gemm(T, HD, S, dP, Sp, 1, Kb, D, 0, dQ, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(S * D, HD), sC=(T * D, HD))
-        hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
+        if FUSED_ATTENTION:
+            delta = self.buf("scratch:attn_delta", (BH, T))
+            hip.call("detr_hip_attention_bwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(),
+                     self._bufs[f"{tag}:lse"].data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
+                     delta.data_ptr(), B, HEADS, T, S, D)
+        else:
+            Pm = self._bufs[f"{tag}:P"]
+            Sp = Pm.shape[2]
+            dP = self.buf("scratch:dP", (BH, T, Sp))
+            sP = (HEADS * T * Sp, T * Sp)
+            hip.gemm(S, HD, T, Pm, Sp, 0, dO, D, 0, dV, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
+            hip.gemm(T, S, HD, dO, D, 1, Vb, D, 1, dP, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD), sC=sP)
+            hip.call("detr_hip_softmax_rows_bwd_f32", Pm.data_ptr(), dP.data_ptr(), BH * T, S, Sp)
+            hip.gemm(T, HD, S, dP, Sp, 1, Kb, D, 0, dQ, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(S * D, HD), sC=(T * D, HD))
+            hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
         # in projection: Q = (q_in Wq^T + bq) * alpha
         alpha = float(HD) ** -0.5
         hip.linear_wgrad(dQ, q_in, gW[0:D], alpha=alpha)

@@ -156,6 +156,19 @@ int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *me
                          float *scale, float *shift, int32_t C, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused multi-head attention core, head_dim 32 (detr_tf/networks/transformer.py:308-345):
+ *   o[b,t,h*32:+32] = softmax_s( q[b,t,h] . k[b,s,h] ) v[b,s,h]      (q already scaled, :307)
+ * on batch-first token matrices with row stride `ld` floats; the [T,S] probability tensor is never
+ * written to memory.  lse [B*H, T] (log-sum-exp per score row) is saved for the backward, which
+ * recomputes the probabilities; delta [B*H, T] is scratch (rowsum(dO*O)).
+ * ------------------------------------------------------------------------------------------- */
+int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse,
+                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld, void *stream);
+int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
+                               const float *d_o, float *dq, float *dk, float *dv, float *delta,
+                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,
  * detr_tf/bbox.py:29-124,171-183).  P = levels * B problems; prediction p of level lv, image b:
  *   logits + lv*sL_l + b*sL_b + q*sL_q + c ,  boxes + lv*sB_l + b*sB_b + q*sB_q + k

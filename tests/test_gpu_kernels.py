@@ -163,6 +163,40 @@ def test_gemm_batched_attention_layout(hip):
     close(o, oref, what="batched PV")
 
 
+@pytest.mark.parametrize("B,T,S", [(2, 1050, 1050), (2, 100, 1050), (3, 100, 100), (1, 37, 5), (2, 300, 1344), (1, 12, 12)])
+def test_fused_attention_fwd_bwd(hip, B, T, S):
+    """Fused attention (scores never stored) vs an fp64 torch reference, incl. ragged tiles, S < 32 and a
+    spiked key that moves the running max late in the stream (online-softmax rescale branch)."""
+    torch.manual_seed(B * 1000 + T + S)
+    H, hd = 8, 32
+    D = H * hd
+    q = torch.randn(B, T, D, dtype=torch.float64) * 0.6
+    k = torch.randn(B, S, D, dtype=torch.float64)
+    v = torch.randn(B, S, D, dtype=torch.float64)
+    k[0, S - 1, :hd] = q[0, T // 2, :hd] * 6.0          # last key dominates one query of head 0
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)
+    o = (p @ vh).transpose(1, 2).reshape(B, T, D)
+    do = torch.randn(B, T, D, dtype=torch.float64)
+    o.backward(do)
+    lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2), dim=-1)
+    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
+    od = torch.full((B, T, D), 7.0, device=DEV)
+    lse = torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
+             T, S, D)
+    close(od, o, rtol=2e-5, what="attention fwd")
+    close(lse.view(B, H, T), lse_ref, rtol=1e-5, what="attention lse")
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    delta = torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
+             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D)
+    close(dq, q.grad, rtol=5e-5, what="attention dq")
+    close(dk, k.grad, rtol=5e-5, what="attention dk")
+    close(dv, v.grad, rtol=5e-5, what="attention dv")
+
+
 def test_linear_helpers(hip):
     torch.manual_seed(5)
     M, K, N = 420, 256, 92
