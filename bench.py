@@ -185,8 +185,16 @@ def main():
                 dom = max(fam, key=lambda k: fam[k]["ms"])
                 d = fam[dom]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                traffic, traffic_src = None, None
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                if os.path.exists(tpath) and dom == "gemm_f32":
+                    with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
+                        tj = json.load(f)
+                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
                 roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                            "traffic_source": traffic_src,
+                            "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                             "launches_per_step": d["launches"] // args.steps,
                             "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                             "families": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

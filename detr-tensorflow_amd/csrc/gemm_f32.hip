@@ -88,26 +88,45 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
+// Reduction of the split-K partial slabs: 256 threads = 64 float4 outputs x 4 split groups (the groups
+// stride the split index, 4 independent loads in flight each), combined through LDS.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
                                                             int rows, int cols, float *__restrict__ C, long long ldc,
                                                             float alpha, const float *__restrict__ scale, int vec) {
+    __shared__ float4 red[4][64];
+    const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
     if (vec) {
         const int c4n = cols >> 2;
         const long long total = (long long)rows * c4n;
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-            const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n) * 4;
-            const float *p = ws + (long long)r * cols + c;
+        for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+            const long long i = base + lo;
+            const bool valid = i < total;
+            int r = 0, c = 0;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < splits; ++k) {
-                const float4 v = *reinterpret_cast<const float4 *>(p + k * part_stride);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            if (valid) {
+                r = (int)(i / c4n);
+                c = (int)(i - (long long)r * c4n) * 4;
+                const float *p = ws + (long long)r * cols + c;
+#pragma unroll 4
+                for (int k = grp; k < splits; k += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(p + k * part_stride);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
             }
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (scale) sc = *reinterpret_cast<const float4 *>(scale + c);
-            float4 *dst = reinterpret_cast<float4 *>(C + (long long)r * ldc + c);
-            float4 o = *dst;
-            o.x += alpha * sc.x * s.x; o.y += alpha * sc.y * s.y; o.z += alpha * sc.z * s.z; o.w += alpha * sc.w * s.w;
-            *dst = o;
+            red[grp][lo] = s;
+            __syncthreads();
+            if (grp == 0 && valid) {
+                const float4 s1 = red[1][lo], s2 = red[2][lo], s3 = red[3][lo];
+                s.x = (s.x + s1.x) + (s2.x + s3.x); s.y = (s.y + s1.y) + (s2.y + s3.y);
+                s.z = (s.z + s1.z) + (s2.z + s3.z); s.w = (s.w + s1.w) + (s2.w + s3.w);
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (scale) sc = *reinterpret_cast<const float4 *>(scale + c);
+                float4 *dst = reinterpret_cast<float4 *>(C + (long long)r * ldc + c);
+                float4 o = *dst;
+                o.x += alpha * sc.x * s.x; o.y += alpha * sc.y * s.y; o.z += alpha * sc.z * s.z; o.w += alpha * sc.w * s.w;
+                *dst = o;
+            }
+            __syncthreads();
         }
     } else {
         const long long total = (long long)rows * cols;
@@ -125,8 +144,8 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
     const int vec = (cols % 4 == 0) && (ldc % 4 == 0) && (part_stride % 4 == 0) && aligned16(ws) && aligned16(C) &&
                     (!scale || aligned16(scale));
     const long long total = (long long)rows * (vec ? cols / 4 : cols);
-    long long grid = (total + 255) / 256;
-    if (grid > 4096) grid = 4096;
+    long long grid = vec ? (total + 63) / 64 : (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols, C,
                        ldc, alpha, scale, vec);

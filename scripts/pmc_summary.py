@@ -1,0 +1,31 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (rocpd sqlite) per kernel name."""
+import glob
+import re
+import sqlite3
+import sys
+
+out = sys.argv[1]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    dbs = glob.glob(f"{out}/pmc_{c}/**/*.db", recursive=True)
+    if not dbs:
+        print("no db for", c)
+        continue
+    con = sqlite3.connect(dbs[0])
+    tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+    print("#", c, "tables/views:", [t for t in tabs if "counter" in t.lower() or "pmc" in t.lower()][:12])
+    view = "counters_collection" if "counters_collection" in tabs else None
+    if view is None:
+        continue
+    cols = [d[1] for d in con.execute(f"pragma table_info({view})")]
+    print("#", view, cols)
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    q = f"select {namecol}, counter_name, count(*), sum(value) from {view} group by {namecol}, counter_name"
+    for name, cn, n, v in con.execute(q):
+        res.setdefault(re.sub(r"\s+", " ", name)[:110], {})[cn] = (n, v)
+rows = sorted(res.items(), key=lambda kv: -sum(x[1] for x in kv[1].values()))
+print(f"{'kernel':110s} {'launches':>8} {'FETCH_SIZE':>14} {'WRITE_SIZE':>14}   (raw counter units; see MI355X_MICROARCH.md #HBM for the gfx950 x2 read correction)")
+for k, v in rows[:40]:
+    f = v.get("FETCH_SIZE", (0, 0))
+    w = v.get("WRITE_SIZE", (0, 0))
+    print(f"{k:110s} {max(f[0], w[0]):8d} {f[1]:14.0f} {w[1]:14.0f}")
