@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
@@ -109,10 +110,10 @@ def main():
     from detr_tf.optimizers import setup_optimizers
     from detr_tf.training_config import TrainingConfig
 
-    rank, world = parallel.init_distributed()
+    rank, world = parallel.init_distributed(backend=args.dist_backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"

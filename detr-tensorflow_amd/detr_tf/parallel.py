@@ -26,7 +26,8 @@ def init_distributed(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # one process per GPU; ranks wrap around when a test box has fewer devices than ranks (gloo only)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 

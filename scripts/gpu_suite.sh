@@ -15,6 +15,8 @@ for w in $WHAT; do
     model) timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q --no-header -p no:cacheprovider > $OUT/model.log 2>&1; echo "model rc=$?" >> $OUT/summary.txt ;;
     debug) timeout 300 python scripts/debug_grad.py > $OUT/debug.log 2>&1; echo "debug rc=$?" >> $OUT/summary.txt; tail -30 $OUT/debug.log ;;
     golden) timeout 300 python -m pytest tests/test_golden.py -m gpu -q --no-header -p no:cacheprovider > $OUT/golden.log 2>&1; echo "golden rc=$?" >> $OUT/summary.txt; tail -15 $OUT/golden.log ;;
+    dp) timeout 600 python -m pytest tests/test_gpu_dp.py -m gpu -q --no-header -p no:cacheprovider > $OUT/dp.log 2>&1; echo "dp rc=$?" >> $OUT/summary.txt; tail -12 $OUT/dp.log
+        timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --dist-backend gloo > $OUT/bench_dp2_gloo.log 2>&1; echo "bench dp2 rc=$?" >> $OUT/summary.txt; tail -3 $OUT/bench_dp2_gloo.log ;;
     smoke)timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
     bench) timeout 600 python bench.py --steps 5 --warmup 2 --dump-shapes $OUT/shapes.json > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt ;;
     fwd) timeout 300 python bench.py --steps 5 --warmup 2 --mode fwdloss --no-cpu-baseline > $OUT/bench_fwd.log 2>&1; echo "fwd rc=$?" >> $OUT/summary.txt ;;
