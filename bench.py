@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
+    ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -123,7 +124,7 @@ def main():
     cfg.batch_size = args.batch
     cfg.target_batch = None
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
-    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0)
+    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout)
     opt = setup_optimizers(model, cfg)
     if world > 1:
         # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
@@ -166,6 +167,18 @@ def main():
     dt = time.perf_counter() - t0
     _hip.PROFILER = None
     loss_val = float(last)
+    # the same step with dropout disabled (SURVEY.md 8d asks for both numbers)
+    value_nodrop = None
+    if args.mode == "train" and args.dropout > 0.0:
+        model.engine.dropout_p = 0.0
+        step(0)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(3):
+            step(i)
+        barrier()
+        value_nodrop = args.batch * world * 3 / (time.perf_counter() - t1)
+        model.engine.dropout_p = args.dropout
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -208,9 +221,10 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DETR-R50 {'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
-                                   f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout off",
+                                   f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)"},
             "loss": round(loss_val, 5),
+            "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
             "whole_step_fraction_of_f32_mfma_peak": round(value / world * gflop * scale / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }

@@ -34,6 +34,8 @@ struct AttnArgs {
     float *delta;                // [B*H, T] rowsum(dO * O)
     int B, H, T, S;
     long long ld;
+    float drop_scale;       // 1/(1-p) or 0
+    uint32_t drop_thresh, drop_seed;
 };
 
 __device__ __forceinline__ int krow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -112,6 +114,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         rs += __shfl_xor(rs, 32, 64);
         lsum = lsum * corr + rs;
         m = mn;
+        if (a.drop_scale != 0.0f) {          // dropout on the attention probabilities (after normalisation == on p)
+            const unsigned long long rowi = ((unsigned long long)bh * a.T + tq) * a.S + kbase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                p[r] = drop_keep(a.drop_seed, rowi + krow(r, hi), a.drop_thresh) ? p[r] * a.drop_scale : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
 #pragma unroll
@@ -190,7 +198,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = (kbase + krow(r, hi) < a.S) ? expf(s[r] - lse) : 0.0f;
-            ds[r] = p * (dp[r] - dl);
+            float dpr = dp[r];
+            if (a.drop_scale != 0.0f)
+                dpr = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + tq) * a.S + kbase + krow(r, hi), a.drop_thresh)
+                          ? dpr * a.drop_scale : 0.0f;
+            ds[r] = p * (dpr - dl);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -273,7 +285,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int qr = krow(r, hi);
             p[r] = expf(s[r] - Ls[cur][qr]);
-            ds[r] = p[r] * (dp[r] - Dl[cur][qr]);
+            float dpr = dp[r];
+            if (a.drop_scale != 0.0f) {
+                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * a.S + sk, a.drop_thresh);
+                dpr = keep ? dpr * a.drop_scale : 0.0f;
+                ds[r] = p[r] * (dpr - Dl[cur][qr]);
+                p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
+            } else {
+                ds[r] = p[r] * (dpr - Dl[cur][qr]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -311,13 +331,23 @@ static int check_args(const float *q, const float *k, const float *v, int B, int
 
 using namespace detr;
 
+static int set_drop(AttnArgs &a, float p, uint32_t seed) {
+    DETR_REQUIRE(p >= 0.0f && p < 1.0f, "attention: dropout p=%f out of range", p);
+    a.drop_scale = p > 0.0f ? 1.0f / (1.0f - p) : 0.0f;
+    a.drop_thresh = drop_thresh24(p);
+    a.drop_seed = seed;
+    return 0;
+}
+
 extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, void *stream) {
+                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
+                                          uint32_t dropout_seed, void *stream) {
     if (check_args(q, k, v, B, H, T, S, ld)) return -1;
     DETR_REQUIRE(o && lse, "attention fwd: null output");
     AttnArgs a = {};
     a.Q = q; a.K = k; a.V = v; a.O = o; a.LSE = lse;
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
+    if (set_drop(a, dropout_p, dropout_seed)) return -1;
     dim3 grid((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     DETR_LAUNCH_CHECK("attention fwd");
@@ -326,7 +356,8 @@ extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const 
 
 extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
                                           const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, void *stream) {
+                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
+                                          uint32_t dropout_seed, void *stream) {
     if (check_args(q, k, v, B, H, T, S, ld)) return -1;
     DETR_REQUIRE(o && lse && d_o && dq && dk && dv && delta, "attention bwd: null operand");
     DETR_REQUIRE(aligned16(d_o), "attention bwd: dO must be 16-byte aligned");
@@ -334,6 +365,7 @@ extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const 
     a.Q = q; a.K = k; a.V = v; a.O = const_cast<float *>(o); a.LSE = const_cast<float *>(lse);
     a.dO = d_o; a.dQ = dq; a.dK = dk; a.dV = dv; a.delta = delta;
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
+    if (set_drop(a, dropout_p, dropout_seed)) return -1;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq");

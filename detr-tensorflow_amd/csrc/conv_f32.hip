@@ -501,6 +501,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.mask = d->mask;
     e.act = d->act;
     e.atomic = 0;
+    e.drop_scale = 0.0f; e.drop_thresh = 0; e.drop_seed = 0;
     e.vec = (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
             (!d->residual || aligned16(d->residual)) && (!d->mask || aligned16(d->mask));   // channel counts are % 16
     if (mode == 2) {

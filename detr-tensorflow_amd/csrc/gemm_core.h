@@ -37,6 +37,9 @@ struct EpiArgs {
     int act;     // 0 none 1 relu 2 sigmoid
     int atomic;  // 1: atomicAdd into C (split-K / wgrad)
     int vec;     // 1: C / residual / mask rows and scale / bias are 16-byte aligned -> float4 epilogue
+    float drop_scale;        // 1/(1-p), 0 = no dropout; element index = row * N + col
+    uint32_t drop_thresh;    // p * 2^24
+    uint32_t drop_seed;
 };
 
 template <int BM, int BN, int WGN>
@@ -232,12 +235,18 @@ struct StageCfg {
     static constexpr int BYTES = 4 * FLOATS_PER_WAVE * 4;
 };
 
-__device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiArgs &e, float res, float msk) {
+// dropout position (transformer.py:169,174-176): with a residual, the GEMM result is dropped BEFORE the
+// residual is added (x + drop(f(x))); without one, after the activation (drop(relu(.))).
+__device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiArgs &e, float res, float msk,
+                                         unsigned long long idx) {
     v = v * sc + bi;
     v *= e.alpha;
+    const bool drop = e.drop_scale != 0.0f;
+    if (drop && e.residual) v = drop_keep(e.drop_seed, idx, e.drop_thresh) ? v * e.drop_scale : 0.0f;
     v += res;
     if (e.act == 1) v = fmaxf(v, 0.0f);
     else if (e.act == 2) v = 1.0f / (1.0f + expf(-v));
+    if (drop && !e.residual) v = drop_keep(e.drop_seed, idx, e.drop_thresh) ? v * e.drop_scale : 0.0f;
     if (e.mask) v = (msk > 0.0f) ? v : 0.0f;
     return v;
 }
@@ -264,7 +273,9 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                 stage[((r & 3) + 8 * (r >> 2) + rh) * S::LD + ni * 32 + l31] = acc[mi][ni][r];
         __syncthreads();
         const int rowbase = m0 + wm * T::WTM + mi * 32;
-#pragma unroll
+        // kept rolled on purpose: the body only touches LDS / global memory, and a small body lets the
+        // compiler fully unroll the register-indexing mi / ni / r loops above (otherwise acc spills to scratch)
+#pragma unroll 1
         for (int it = 0; it < ITERS; ++it) {
             const int idx = it * 64 + lane;
             const int rl = idx / VPR;
@@ -282,10 +293,11 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                 if (e.residual) rs = *reinterpret_cast<const float4 *>(e.residual + (long long)row * e.ldr + col);
                 if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + (long long)row * e.ldmask + col);
                 float4 o;
-                o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x);
-                o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y);
-                o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z);
-                o.w = epi_one(a.w, sc.w, bi.w, e, rs.w, mk.w);
+                const unsigned long long di = (unsigned long long)row * N + col;
+                o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x, di);
+                o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y, di + 1);
+                o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z, di + 2);
+                o.w = epi_one(a.w, sc.w, bi.w, e, rs.w, mk.w, di + 3);
                 if (e.atomic) {
                     unsafeAtomicAdd(dst + 0, o.x);
                     unsafeAtomicAdd(dst + 1, o.y);
@@ -303,7 +315,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                         const float bi = e.bias ? e.bias[col + j] : 0.0f;
                         const float rs = e.residual ? e.residual[(long long)row * e.ldr + col + j] : 0.0f;
                         const float mk = e.mask ? e.mask[(long long)row * e.ldmask + col + j] : 1.0f;
-                        const float o = epi_one(av[j], sc, bi, e, rs, mk);
+                        const float o = epi_one(av[j], sc, bi, e, rs, mk, (unsigned long long)row * N + col + j);
                         if (e.atomic) unsafeAtomicAdd(dst + j, o);
                         else dst[j] = o;
                     }

@@ -289,6 +289,12 @@ __global__ void sigmoid_bwd_kernel(const float *__restrict__ dy, const float *__
     }
 }
 
+__global__ void dropout_kernel(const float *__restrict__ x, float *__restrict__ out, long long n, float scale,
+                               uint32_t thresh, uint32_t seed) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = drop_keep(seed, (unsigned long long)i, thresh) ? x[i] * scale : 0.0f;
+}
+
 __global__ void relu_mask_kernel(const float *__restrict__ g, const float *__restrict__ ref, float *__restrict__ out,
                                  long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -410,6 +416,14 @@ extern "C" int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz,
                        (long long)n);
     DETR_LAUNCH_CHECK("sigmoid_bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t seed, void *stream) {
+    DETR_REQUIRE(x && out && n > 0 && p >= 0.0f && p < 1.0f, "dropout: bad args");
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n,
+                       1.0f / (1.0f - p), drop_thresh24(p), seed);
+    DETR_LAUNCH_CHECK("dropout");
     return 0;
 }
 

@@ -29,7 +29,8 @@ class GemmDesc(Structure):
                 ("residual", c_void_p), ("ldr", c_int64),
                 ("mask", c_void_p), ("ldmask", c_int64),
                 ("act", c_int32), ("split_k", c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64),
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32)]
 
 
 class Conv3x3Desc(Structure):
@@ -65,8 +66,10 @@ _SIGNATURES = {
     "detr_hip_layernorm_bwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_void_p],
     "detr_hip_softmax_rows_fwd_f32": [f32p, c_int64, c_int32, c_int64, c_void_p],
     "detr_hip_softmax_rows_bwd_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_void_p],
-    "detr_hip_attention_fwd_f32": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p],
-    "detr_hip_attention_bwd_f32": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p],
+    "detr_hip_attention_fwd_f32": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,
+                                   ctypes.c_uint32, c_void_p],
+    "detr_hip_attention_bwd_f32": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_float, ctypes.c_uint32, c_void_p],
+    "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],
     "detr_hip_add_f32": [f32p, f32p, f32p, c_int64, c_void_p],
@@ -185,7 +188,7 @@ def _f32(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
          residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0):
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -201,6 +204,7 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d.residual, d.ldr = ptr(residual), ldr
     d.mask, d.ldmask = ptr(mask), ldmask
     d.act, d.split_k = act, split_k
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
     ws = workspace if workspace is not None else WORKSPACE
     d.workspace, d.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
@@ -219,12 +223,13 @@ def pick_split_k(M, N, K, max_split=1024):
     return int(max(1, min(want, max_split, ktiles // 8 if ktiles >= 16 else 1)))
 
 
-def linear_fwd(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0):
+def linear_fwd(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0):
     """out = act((x @ W^T + b) * alpha + residual); W is (out, in) like custom_layers.Linear."""
     M, K = x2d.shape
     N = w_out_in.shape[0]
     gemm(M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0),
-         alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act)
+         alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act,
+         dropout_p=dropout_p, dropout_seed=dropout_seed)
 
 
 def linear_dgrad(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):

@@ -68,6 +68,10 @@ class DetrEngine:
         self.bn_scale, self.bn_shift = {}, {}
         self.fold_bn()
         self.weights_dirty = True        # scaled conv kernels must be refreshed after every optimiser step
+        self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
+        self.dropout_seed = 0x5EED       # base seed; advanced by the step counter
+        self._step_no = 0
+        self._drop = (0.0, 0)
 
     # ---- buffers ------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
@@ -140,7 +144,7 @@ class DetrEngine:
         hip.call("detr_hip_add_bcast_f32", x.data_ptr(), p.data_ptr(), out.data_ptr(), x.numel(), p.numel())
 
     # ---- attention --------------------------------------------------------------------------------
-    def _mha_fwd(self, tag, pfx, q_in, k_in, v_in, B, T, S, out, residual):
+    def _mha_fwd(self, tag, pfx, q_in, k_in, v_in, B, T, S, out, residual, seed=0):
         """MultiHeadAttention.call transformer.py:285-356 + the residual add of the caller.
         q_in [B*T,256], k_in/v_in [B*S,256]; out = attn(q,k,v) @ Wo^T + bo + residual."""
         W, bias = self.P.views[f"{pfx}/in_proj_kernel"], self.P.views[f"{pfx}/in_proj_bias"]
@@ -153,8 +157,9 @@ class DetrEngine:
         if FUSED_ATTENTION:
             # fused flash-style core: the [T,S] probabilities never reach HBM (csrc/attention_f32.hip)
             lse = self.buf(f"{tag}:lse", (BH, T))
+            dp, dbase = self._drop
             hip.call("detr_hip_attention_fwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(), lse.data_ptr(),
-                     B, HEADS, T, S, D)                                                # :317,:340,:343
+                     B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)        # :317,:340,:341,:343
         else:
             Sp = (S + 3) // 4 * 4
             Pm = self.buf(f"{tag}:P", (B * HEADS, T, Sp))
@@ -164,15 +169,23 @@ class DetrEngine:
             hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
                      sB=(S * D, HD), sC=(T * D, HD))                                   # :343-345
         hip.linear_fwd(O, self.P.views[f"{pfx}/out_proj_kernel"], self.P.views[f"{pfx}/out_proj_bias"], out,
-                       residual=residual)                                              # :346-347
+                       residual=residual, dropout_p=self._drop[0], dropout_seed=self._drop[1] + seed + 1)   # :346-347 + :169
 
-    def _mha_bwd(self, tag, pfx, d_out, q_in, k_in, v_in, B, T, S, dq_in, dk_in, dv_in, dk_accum=False, dv_accum=False):
+
+    def _mha_bwd(self, tag, pfx, d_out, q_in, k_in, v_in, B, T, S, dq_in, dk_in, dv_in, dk_accum=False, dv_accum=False,
+                 seed=0):
         """Backward of _mha_fwd w.r.t. q_in, k_in, v_in and the MHA parameters.
         d_out: gradient of the out-projection output.  dk_in/dv_in may be accumulated onto."""
         V, G = self.P.views, self.P.gviews
         W, gW, gb = V[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
         Qb, Kb, Vb, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "O"))
         BH = B * HEADS
+        dp, dbase = self._drop
+        if dp > 0.0:    # gradient through the dropout that follows the out-projection (same mask as the forward)
+            d_drop = self.buf("scratch:d_drop", d_out.shape)
+            hip.call("detr_hip_dropout_f32", d_out.data_ptr(), d_drop.data_ptr(), d_out.numel(), c_float(dp),
+                     (dbase + seed + 1) & 0xFFFFFFFF)
+            d_out = d_drop
         # out projection
         hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"])
         self._colsum(d_out, G[f"{pfx}/out_proj_bias"])
@@ -184,7 +197,7 @@ class DetrEngine:
             delta = self.buf("scratch:attn_delta", (BH, T))
             hip.call("detr_hip_attention_bwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(),
                      self._bufs[f"{tag}:lse"].data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                     delta.data_ptr(), B, HEADS, T, S, D)
+                     delta.data_ptr(), B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)
         else:
             Pm = self._bufs[f"{tag}:P"]
             Sp = Pm.shape[2]
@@ -207,20 +220,30 @@ class DetrEngine:
         hip.linear_dgrad(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None)
         hip.linear_dgrad(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)
 
-    def _ffn_fwd(self, tag, pfx, x, out_pre_ln):
+    def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0):
         V = self.P.views
+        dp, dbase = self._drop
         h = self.buf(f"{tag}:h", (x.shape[0], FF))
-        hip.linear_fwd(x, V[f"{pfx}/linear1/kernel"], V[f"{pfx}/linear1/bias"], h, act=1)
-        hip.linear_fwd(h, V[f"{pfx}/linear2/kernel"], V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x)
+        hip.linear_fwd(x, V[f"{pfx}/linear1/kernel"], V[f"{pfx}/linear1/bias"], h, act=1, dropout_p=dp,
+                       dropout_seed=dbase + seed)                                      # :172-174
+        hip.linear_fwd(h, V[f"{pfx}/linear2/kernel"], V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
+                       dropout_seed=dbase + seed + 1)                                  # :175-176
 
-    def _ffn_bwd(self, tag, pfx, d_f, x, dx):
-        """d_f: grad of (linear2(relu(linear1(x))) + x); dx = full gradient w.r.t. x."""
+    def _ffn_bwd(self, tag, pfx, d_f, x, dx, seed=0):
+        """d_f: grad of (drop(linear2(drop(relu(linear1(x))))) + x); dx = full gradient w.r.t. x."""
         V, G = self.P.views, self.P.gviews
-        h = self._bufs[f"{tag}:h"]
-        hip.linear_wgrad(d_f, h, G[f"{pfx}/linear2/kernel"])
-        self._colsum(d_f, G[f"{pfx}/linear2/bias"])
+        h = self._bufs[f"{tag}:h"]                 # post-ReLU, post-dropout hidden activation
+        dp, dbase = self._drop
+        d_y = d_f
+        if dp > 0.0:
+            d_y = self.buf("scratch:d_ffn_drop", d_f.shape)
+            hip.call("detr_hip_dropout_f32", d_f.data_ptr(), d_y.data_ptr(), d_f.numel(), c_float(dp),
+                     (dbase + seed + 1) & 0xFFFFFFFF)
+        hip.linear_wgrad(d_y, h, G[f"{pfx}/linear2/kernel"])
+        self._colsum(d_y, G[f"{pfx}/linear2/bias"])
         dh = self.buf("scratch:dh", h.shape)
-        hip.linear_dgrad(d_f, V[f"{pfx}/linear2/kernel"], dh, mask=h)
+        # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
+        hip.linear_dgrad(d_y, V[f"{pfx}/linear2/kernel"], dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
         hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"])
         self._colsum(dh, G[f"{pfx}/linear1/bias"])
         hip.linear_dgrad(dh, V[f"{pfx}/linear1/kernel"], dx, residual=d_f)
@@ -231,6 +254,13 @@ class DetrEngine:
         Returns (logits [Lv,B,Q,C], boxes [Lv,B,Q,4]) views of engine buffers."""
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
+        if training and self.dropout_p > 0.0:
+            assert FUSED_ATTENTION, "training-mode dropout is implemented in the fused attention path only"
+            self._step_no += 1
+            self._drop = (float(self.dropout_p), (self.dropout_seed + 7919 * self._step_no) & 0xFFFFFFFF)
+        else:
+            self._drop = (0.0, 0)
+        dp, dseed = self._drop
         B, H, W, _ = images.shape
         self._shape = (B, H, W)
         self.images = images
@@ -300,11 +330,11 @@ class DetrEngine:
             qk = self.buf(f"{tag}:qk", (B * L, D))
             self._add_bcast(x, pos, qk)
             a = self.buf(f"{tag}:a", (B * L, D))
-            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, qk, x, B, L, L, a, residual=x)
+            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, qk, x, B, L, L, a, residual=x, seed=16 * i)
             x1 = self.buf(f"{tag}:x1", (B * L, D))
             self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1")
             f = self.buf(f"{tag}:f", (B * L, D))
-            self._ffn_fwd(tag, pfx, x1, f)
+            self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2)
             x2 = self.buf(f"{tag}:x2", (B * L, D))
             self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2")
             x = x2
@@ -322,17 +352,18 @@ class DetrEngine:
             qin = self.buf(f"{tag}:qin", (B * Q, D))
             self._add_bcast(tgt, qpos, qin)
             a1 = self.buf(f"{tag}:a1", (B * Q, D))
-            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, qin, tgt, B, Q, Q, a1, residual=tgt)
+            ds = 16 * (32 + i)
+            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, qin, tgt, B, Q, Q, a1, residual=tgt, seed=ds)
             t1 = self.buf(f"{tag}:t1", (B * Q, D))
             self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1")
             q2 = self.buf(f"{tag}:q2", (B * Q, D))
             self._add_bcast(t1, qpos, q2)
             a2 = self.buf(f"{tag}:a2", (B * Q, D))
-            self._mha_fwd(f"{tag}:ca", f"{pfx}/multihead_attn", q2, mem_pos, memory, B, Q, L, a2, residual=t1)
+            self._mha_fwd(f"{tag}:ca", f"{pfx}/multihead_attn", q2, mem_pos, memory, B, Q, L, a2, residual=t1, seed=ds + 2)
             t2 = self.buf(f"{tag}:t2", (B * Q, D))
             self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2")
             f = self.buf(f"{tag}:f", (B * Q, D))
-            self._ffn_fwd(tag, pfx, t2, f)
+            self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4)
             t3 = self.buf(f"{tag}:t3", (B * Q, D))
             self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
             self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
@@ -430,13 +461,14 @@ class DetrEngine:
                 self._add(d_t3, d_next, d_t3)
             d_f = self.buf("scratch:d_f", (BQ, D))
             self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3")
+            ds = 16 * (32 + i)
             d_t2 = self.buf("scratch:d_t2", (BQ, D))
-            self._ffn_bwd(tag, pfx, d_f, t2, d_t2)
+            self._ffn_bwd(tag, pfx, d_f, t2, d_t2, seed=ds + 4)
             d_a2 = self.buf("scratch:d_a2", (BQ, D))
             self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2")
             d_q2 = self.buf("scratch:d_q2", (BQ, D))
             self._mha_bwd(f"{tag}:ca", f"{pfx}/multihead_attn", d_a2, q2, mem_pos, memory, B, Q, L, d_q2, d_mem, d_mem,
-                          dk_accum=True, dv_accum=True)
+                          dk_accum=True, dv_accum=True, seed=ds + 2)
             self._colsum(d_q2.view(B, Q * D), g_qpos.view(Q * D))          # d query_pos (sum over the batch)
             d_t1 = self.buf("scratch:d_t1", (BQ, D))
             self._add(d_q2, d_a2, d_t1)                                    # q2 = t1 + qpos ; a2 = ... + t1
@@ -445,7 +477,7 @@ class DetrEngine:
             d_qin = self.buf("scratch:d_qin", (BQ, D))
             d_kin = self.buf("scratch:d_kin", (BQ, D))
             d_vin = self.buf("scratch:d_vin", (BQ, D))
-            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a1, qin, qin, tgt, B, Q, Q, d_qin, d_kin, d_vin)
+            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a1, qin, qin, tgt, B, Q, Q, d_qin, d_kin, d_vin, seed=ds)
             self._add(d_qin, d_kin, d_qin)                                 # q and k share qin = tgt + qpos
             self._colsum(d_qin.view(B, Q * D), g_qpos.view(Q * D))
             d_tgt = self.buf(f"scratch:d_tgt{i & 1}", (BQ, D))
@@ -461,13 +493,13 @@ class DetrEngine:
             d_f = self.buf("scratch:e_d_f", (B * L, D))
             self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2")
             d_x1 = self.buf("scratch:e_d_x1", (B * L, D))
-            self._ffn_bwd(tag, pfx, d_f, x1, d_x1)
+            self._ffn_bwd(tag, pfx, d_f, x1, d_x1, seed=16 * i + 2)
             d_a = self.buf("scratch:e_d_a", (B * L, D))
             self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1")
             d_q = self.buf("scratch:e_d_q", (B * L, D))
             d_k = self.buf("scratch:e_d_k", (B * L, D))
             d_v = self.buf("scratch:e_d_v", (B * L, D))
-            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a, qk, qk, x_in, B, L, L, d_q, d_k, d_v)
+            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a, qk, qk, x_in, B, L, L, d_q, d_k, d_v, seed=16 * i)
             d_xn = self.buf(f"scratch:e_d_x{i & 1}", (B * L, D))
             self._add(d_q, d_k, d_xn)
             self._add(d_xn, d_v, d_xn)

@@ -29,7 +29,7 @@ class _Layer:
 
 class DetrModel:
     def __init__(self, include_top=True, nb_class=None, num_decoder_layers=6, num_encoder_layers=6, num_queries=100,
-                 backbone="resnet50", device=None, seed=0):
+                 backbone="resnet50", device=None, seed=0, dropout=0.1):
         device = device or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None)
         if device is None:
             raise RuntimeError("DETR HIP model needs a GPU: the hot path has no CPU fallback")
@@ -38,6 +38,7 @@ class DetrModel:
         self.headless = (not include_top) and nb_class is None
         self.name = "detr" if self.headless else "detr_finetuning"
         self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed)
+        self.engine.dropout_p = float(dropout)  # Transformer(dropout=0.1), applied when called with training=True
         self.dp = None                        # parallel.DataParallel when training on several GPUs
         self.device = self.engine.device
 
@@ -95,15 +96,16 @@ class DetrModel:
 
 
 def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_backbone=False, num_decoder_layers=6,
-                   num_encoder_layers=6, num_queries=100, backbone="resnet50", device=None, seed=0):
+                   num_encoder_layers=6, num_queries=100, backbone="resnet50", device=None, seed=0, dropout=0.1):
     """Same arguments and three output modes as the reference (detr.py:116-204); `num_queries`,
     `backbone` ("resnet50" | "resnet101", resnet_backbone.py:35-66), `device` and `seed` are
-    extensions (the reference never exposes num_queries / ResNet101)."""
+    extensions (the reference never exposes num_queries / ResNet101); `dropout` is the
+    transformer dropout rate of training mode (the reference hard-codes 0.1, transformer.py:9)."""
     if tf_backbone:
         raise NotImplementedError("tf_backbone=True (keras.applications ResNet50) is not on the HIP hot path yet")
     model = DetrModel(include_top=include_top, nb_class=nb_class, num_decoder_layers=num_decoder_layers,
                       num_encoder_layers=num_encoder_layers, num_queries=num_queries, backbone=backbone, device=device,
-                      seed=seed)
+                      seed=seed, dropout=dropout)
     if weights is not None:
         if isinstance(weights, str) and not weights.endswith(".npz"):
             raise NotImplementedError(f'weights="{weights}": the reference downloads a TF checkpoint (weights.py:5-11); '

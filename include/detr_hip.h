@@ -68,6 +68,10 @@ typedef struct {
      * 16-byte stores and a second launch reduces them onto C (C += alpha*scale*sum); otherwise
      * the partials are accumulated with fp32 atomics. */
     float *workspace; int64_t workspace_bytes;
+    /* fused dropout (training mode, transformer.py:169,174-176): keep-mask = counter hash of
+     * (dropout_seed, row*N + col), kept values scaled by 1/(1-p); applied before the residual add when a
+     * residual is given, otherwise after the activation.  0 = off. */
+    float dropout_p; uint32_t dropout_seed;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 
@@ -146,6 +150,8 @@ int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n
 int detr_hip_add_f32(const float *a, const float *b, float *out, int64_t n, void *stream);
 /* dz[i] = dy[i] * y[i] * (1 - y[i]) */
 int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *dz, int64_t n, void *stream);
+/* out[i] = keep(seed, i) ? x[i] / (1-p) : 0   -- the dropout mask of detr_gemm_desc regenerated on a gradient */
+int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t seed, void *stream);
 /* out[i] = (ref[i] > 0) ? g[i] : 0 */
 int detr_hip_relu_mask_f32(const float *g, const float *ref, float *out, int64_t n, void *stream);
 /* w_out[k, co] = w[k, co] * scale[co]   (frozen-BN scale folded into conv kernels, HWIO flat) */
@@ -163,10 +169,13 @@ int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *me
  * recomputes the probabilities; delta [B*H, T] is scratch (rowsum(dO*O)).
  * ------------------------------------------------------------------------------------------- */
 int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse,
-                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld, void *stream);
+                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
+                               float dropout_p, uint32_t dropout_seed, void *stream);
 int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
                                const float *d_o, float *dq, float *dk, float *dv, float *delta,
-                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld, void *stream);
+                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
+                               float dropout_p, uint32_t dropout_seed, void *stream);
+/* attention-probability dropout (transformer.py:341): element index ((b*H + h)*T + t)*S + s of `dropout_seed` */
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,

@@ -239,7 +239,7 @@ def layer_norm(x, P, p):
     return F.layer_norm(x, (x.shape[-1],), P[f"{p}/gamma"], P[f"{p}/beta"], LN_EPS)
 
 
-def multi_head_attention(query, key, value, P, p, num_heads=8):
+def multi_head_attention(query, key, value, P, p, num_heads=8, drop=None, seed=0):
     """MultiHeadAttention.call transformer.py:285-356 (attn_mask None, key-padding branch
     disabled :322-337, dropout = identity)."""
     T, B, D = query.shape
@@ -254,29 +254,42 @@ def multi_head_attention(query, key, value, P, p, num_heads=8):
     WK = WK.reshape(S, B * num_heads, hd).transpose(0, 1)
     WV = WV.reshape(S, B * num_heads, hd).transpose(0, 1)
     w = torch.softmax(WQ @ WK.transpose(1, 2), dim=-1)        # :317,340
+    if drop is not None:
+        w = drop(seed + 0, w, "flat")                         # :341 dropout on the attention weights
     o = (w @ WV).transpose(0, 1).reshape(T, B, D)             # :343-345
-    return o @ P[f"{p}/out_proj_kernel"].t() + P[f"{p}/out_proj_bias"]   # :346-347
+    out = o @ P[f"{p}/out_proj_kernel"].t() + P[f"{p}/out_proj_bias"]   # :346-347
+    if drop is not None:
+        out = drop(seed + 1, out, "lbc")                      # the caller's self.dropout(attn_output) :169,215,226
+    return out
 
 
-def encoder_layer(src, pos, P, p):
-    """EncoderLayer.call transformer.py:157-179 (post-norm)."""
+def _ffn(x, P, p, drop, seed):
+    h = torch.relu(linear(x, P, f"{p}/linear1"))
+    if drop is not None:
+        h = drop(seed + 0, h, "lbc")                          # :174 / :230
+    y = linear(h, P, f"{p}/linear2")
+    if drop is not None:
+        y = drop(seed + 1, y, "lbc")                          # :176 / :232
+    return y
+
+
+def encoder_layer(src, pos, P, p, drop=None, seed=0):
+    """EncoderLayer.call transformer.py:157-179 (post-norm); dropout sites seed+0..3."""
     q = k = src + pos
-    src = layer_norm(src + multi_head_attention(q, k, src, P, f"{p}/self_attn"), P, f"{p}/norm1")
-    x = linear(torch.relu(linear(src, P, f"{p}/linear1")), P, f"{p}/linear2")
-    return layer_norm(src + x, P, f"{p}/norm2")
+    src = layer_norm(src + multi_head_attention(q, k, src, P, f"{p}/self_attn", drop=drop, seed=seed), P, f"{p}/norm1")
+    return layer_norm(src + _ffn(src, P, p, drop, seed + 2), P, f"{p}/norm2")
 
 
-def decoder_layer(tgt, memory, pos, qpos, P, p):
-    """DecoderLayer.call transformer.py:207-234."""
+def decoder_layer(tgt, memory, pos, qpos, P, p, drop=None, seed=0):
+    """DecoderLayer.call transformer.py:207-234; dropout sites seed+0..5."""
     q = k = tgt + qpos
-    tgt = layer_norm(tgt + multi_head_attention(q, k, tgt, P, f"{p}/self_attn"), P, f"{p}/norm1")
-    tgt = layer_norm(tgt + multi_head_attention(tgt + qpos, memory + pos, memory, P, f"{p}/multihead_attn"),
-                     P, f"{p}/norm2")
-    x = linear(torch.relu(linear(tgt, P, f"{p}/linear1")), P, f"{p}/linear2")
-    return layer_norm(tgt + x, P, f"{p}/norm3")
+    tgt = layer_norm(tgt + multi_head_attention(q, k, tgt, P, f"{p}/self_attn", drop=drop, seed=seed), P, f"{p}/norm1")
+    tgt = layer_norm(tgt + multi_head_attention(tgt + qpos, memory + pos, memory, P, f"{p}/multihead_attn", drop=drop,
+                                                seed=seed + 2), P, f"{p}/norm2")
+    return layer_norm(tgt + _ffn(tgt, P, p, drop, seed + 4), P, f"{p}/norm3")
 
 
-def transformer(src_nhwc, pos_nhwc, query_embed, P, num_enc=6, num_dec=6, taps=None):
+def transformer(src_nhwc, pos_nhwc, query_embed, P, num_enc=6, num_dec=6, taps=None, drop=None):
     """Transformer.call transformer.py:29-57; returns hs [num_dec, B, Q, 256]."""
     B, H, W, D = src_nhwc.shape
     src = src_nhwc.reshape(B, H * W, D).transpose(0, 1)
@@ -285,14 +298,14 @@ def transformer(src_nhwc, pos_nhwc, query_embed, P, num_enc=6, num_dec=6, taps=N
     tgt = torch.zeros_like(qpos)
     x = src
     for i in range(num_enc):
-        x = encoder_layer(x, pos, P, f"transformer/encoder/layer_{i}")
+        x = encoder_layer(x, pos, P, f"transformer/encoder/layer_{i}", drop, 16 * i)
     memory = x
     if taps is not None:
         taps["memory"] = memory
     inter = []
     x = tgt
     for i in range(num_dec):
-        x = decoder_layer(x, memory, pos, qpos, P, f"transformer/decoder/layer_{i}")
+        x = decoder_layer(x, memory, pos, qpos, P, f"transformer/decoder/layer_{i}", drop, 16 * (32 + i))
         inter.append(layer_norm(x, P, "transformer/decoder/norm"))     # :121-125
     hs = torch.stack(inter, 0)                                          # [num_dec, Q, B, D]
     return hs.transpose(1, 2)                                           # :53
@@ -301,7 +314,7 @@ def transformer(src_nhwc, pos_nhwc, query_embed, P, num_enc=6, num_dec=6, taps=N
 # --------------------------------------------------------------------------------------
 # full model  (detr_tf/networks/detr.py:116-204)
 # --------------------------------------------------------------------------------------
-def detr_hs(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=None):
+def detr_hs(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=None, drop=None):
     """The inner Keras model "detr": images -> hs  (detr.py:170-177)."""
     x = backbone(images_nhwc, P, blocks, taps)
     B, H, W, _ = x.shape
@@ -310,12 +323,13 @@ def detr_hs(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=N
     if taps is not None:
         taps["input_proj"] = proj
         taps["pos"] = pos
-    return transformer(proj, pos, P["query_embed/kernel"], P, num_enc, num_dec, taps)
+    return transformer(proj, pos, P["query_embed/kernel"], P, num_enc, num_dec, taps, drop)
 
 
-def detr_forward(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=None):
-    """get_detr_model(include_top=True) output dict (detr.py:181-204)."""
-    hs = detr_hs(images_nhwc, P, blocks, num_enc, num_dec, taps)
+def detr_forward(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=None, drop=None):
+    """get_detr_model(include_top=True) output dict (detr.py:181-204).  `drop`: optional
+    oracle.dropout_ref.Dropper for training-mode parity (None = dropout off / inference)."""
+    hs = detr_hs(images_nhwc, P, blocks, num_enc, num_dec, taps, drop)
     if taps is not None:
         taps["hs"] = hs
     if "class_embed/kernel" in P:

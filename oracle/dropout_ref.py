@@ -1,0 +1,52 @@
+"""ORACLE (test infrastructure only) -- the counter-hash dropout masks of the HIP path, restated in numpy.
+
+The reference uses Keras Dropout(0.1) in training mode (transformer.py:149,196,248: on the attention
+probabilities :341, after every attention block and inside the FFN :169-176,216-232).  TensorFlow's RNG
+stream cannot be reproduced (and TF is absent), so parity under dropout is defined with the MASKS of the
+HIP path: keep(seed, idx) = (hash32(seed, idx) >> 8) >= p * 2^24, kept values scaled by 1/(1-p)
+(csrc/common.h::drop_hash).  With these masks the oracle and the device compute the same function."""
+import numpy as np
+import torch
+
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def drop_hash(seed, idx):
+    idx = idx.astype(np.uint64)
+    x = (idx & M32) ^ np.uint64(seed & 0xFFFFFFFF)
+    x ^= ((idx >> np.uint64(32)) * np.uint64(0x9E3779B9)) & M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def keep_mask(seed, idx, p):
+    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    return (drop_hash(seed, idx) >> np.uint64(8)) >= thresh
+
+
+class Dropper:
+    """drop(seed, x, layout): layout "lbc" = sequence-first activations [L,B,C] whose device twin is the
+    batch-first matrix [B*L, C] (element index (b*L+l)*C+c); "flat" = row-major index of x itself
+    (attention probabilities [B*H, T, S])."""
+
+    def __init__(self, p, base_seed):
+        self.p, self.base = float(p), int(base_seed)
+
+    def __call__(self, seed_off, x, layout):
+        if self.p <= 0.0:
+            return x
+        shp = tuple(x.shape)
+        if layout == "lbc":
+            L, B, C = shp
+            l, b, c = np.meshgrid(np.arange(L), np.arange(B), np.arange(C), indexing="ij")
+            idx = (b * L + l) * C + c
+        else:
+            idx = np.arange(int(np.prod(shp))).reshape(shp)
+        keep = keep_mask((self.base + seed_off) & 0xFFFFFFFF, idx, self.p)
+        scale = np.float32(1.0) / (np.float32(1.0) - np.float32(self.p))
+        m = torch.from_numpy(keep.astype(np.float32) * float(scale)).to(x.dtype)
+        return x * m

@@ -48,7 +48,7 @@ def test_hip_path_reproduces_golden(hip, gold):
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
     cfg.batch_size, cfg.target_batch = 2, 4                       # gradient_aggregate = 2
     params = R.make_params(seed, num_enc=num_enc, num_dec=num_dec)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=num_enc, num_decoder_layers=num_dec)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=num_enc, num_decoder_layers=num_dec, dropout=0.0)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
     out, total, log, steps = training.run_train_step(model, gold["images"], gold["t_bbox"], gold["t_class"], opt, cfg)

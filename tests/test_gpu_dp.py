@@ -35,7 +35,7 @@ def _make(cfg_only=False):
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
     cfg.target_batch = None
     params = R.make_params(12, num_enc=1, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, device="cuda:0")
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, device="cuda:0", dropout=0.0)
     model.load_weights(params)
     images = np.random.default_rng(4).normal(size=(2, 96, 128, 3)).astype(np.float32)
     t_bbox, t_class = L.make_targets(2, seed=40, force_full=False)

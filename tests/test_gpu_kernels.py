@@ -185,13 +185,13 @@ def test_fused_attention_fwd_bwd(hip, B, T, S):
     od = torch.full((B, T, D), 7.0, device=DEV)
     lse = torch.zeros(B * H, T, device=DEV)
     hip.call("detr_hip_attention_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
-             T, S, D)
+             T, S, D, ctypes.c_float(0.0), 0)
     close(od, o, rtol=2e-5, what="attention fwd")
     close(lse.view(B, H, T), lse_ref, rtol=1e-5, what="attention lse")
     dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
     delta = torch.zeros(B * H, T, device=DEV)
     hip.call("detr_hip_attention_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
-             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D)
+             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(0.0), 0)
     close(dq, q.grad, rtol=5e-5, what="attention dq")
     close(dk, k.grad, rtol=5e-5, what="attention dk")
     close(dv, v.grad, rtol=5e-5, what="attention dv")
@@ -563,3 +563,59 @@ def test_clip_adam_vs_oracle(hip):
             opts[gi].apply({i: grads[i] for i in range(len(shapes)) if groups[i] == gi}, params)
         ref = np.concatenate([params[i].ravel() for i in range(len(shapes))])
         close(flat, torch.tensor(ref), rtol=1e-5, what=f"adam step {step}")
+
+
+# ------------------------------------------------------------------------------------------
+# dropout (training mode): device masks == the numpy restatement of the counter hash
+# ------------------------------------------------------------------------------------------
+def test_dropout_gemm_epilogue_and_elementwise(hip):
+    from oracle import dropout_ref as DR
+    torch.manual_seed(21)
+    M, N, K, p, seed = 333, 256, 64, 0.1, 0xABCDE
+    x, W, b, R = torch.randn(M, K), torch.randn(N, K), torch.randn(N), torch.randn(M, N)
+    xd, Wd, bd, Rd = g(x), g(W), g(b), g(R)
+    keep = torch.from_numpy(DR.keep_mask(seed, np.arange(M * N).reshape(M, N), p))
+    assert 0.88 < float(keep.float().mean()) < 0.92
+    scale = 1.0 / (1.0 - p)
+    lin = x.double() @ W.double().t() + b.double()
+    # with a residual: x + drop(f(x))
+    y = torch.zeros(M, N, device=DEV)
+    hip.linear_fwd(xd, Wd, bd, y, residual=Rd, dropout_p=p, dropout_seed=seed)
+    close(y, torch.where(keep, lin * scale, torch.zeros_like(lin)) + R.double(), what="gemm dropout before residual")
+    # without: drop(relu(f(x)))
+    hip.linear_fwd(xd, Wd, bd, y, act=1, dropout_p=p, dropout_seed=seed)
+    close(y, torch.where(keep, lin.clamp_min(0) * scale, torch.zeros_like(lin)), what="gemm dropout after relu")
+    gsrc = torch.randn(M, N)
+    gd, out = g(gsrc), torch.zeros(M, N, device=DEV)
+    hip.call("detr_hip_dropout_f32", gd.data_ptr(), out.data_ptr(), M * N, ctypes.c_float(p), seed)
+    close(out, torch.where(keep, gsrc.double() * scale, torch.zeros(M, N, dtype=torch.float64)), rtol=1e-6, what="dropout_f32")
+
+
+@pytest.mark.parametrize("B,T,S", [(2, 100, 333), (1, 70, 1050)])
+def test_fused_attention_dropout(hip, B, T, S):
+    from oracle import dropout_ref as DR
+    torch.manual_seed(T + S)
+    H, hd, p, seed = 8, 32, 0.1, 77
+    D = H * hd
+    q = (torch.randn(B, T, D, dtype=torch.float64) * 0.5).requires_grad_(True)
+    k = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    v = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    w = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)                       # [B,H,T,S]
+    keep = torch.from_numpy(DR.keep_mask(seed, np.arange(B * H * T * S).reshape(B, H, T, S), p))
+    wd = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
+    o = (wd @ vh).transpose(1, 2).reshape(B, T, D)
+    do = torch.randn(B, T, D, dtype=torch.float64)
+    o.backward(do)
+    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
+    od, lse = torch.zeros(B, T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
+             T, S, D, ctypes.c_float(p), seed)
+    close(od, o, rtol=3e-5, what="attention+dropout fwd")
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    delta = torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
+             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(p), seed)
+    close(dq, q.grad, rtol=5e-5, what="attention+dropout dq")
+    close(dk, k.grad, rtol=5e-5, what="attention+dropout dk")
+    close(dv, v.grad, rtol=5e-5, what="attention+dropout dv")

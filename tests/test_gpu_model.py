@@ -57,7 +57,7 @@ def small():
     from oracle import detr_ref as R, set_loss_ref as L
     cfg = _cfg()
     params = R.make_params(3)
-    model = get_detr_model(cfg, include_top=True)
+    model = get_detr_model(cfg, include_top=True, dropout=0.0)
     missing = model.load_weights(params)
     assert not missing, missing
     rng = np.random.default_rng(11)
@@ -136,7 +136,7 @@ def test_backward_small_shapes_vs_oracle(hip):
     from oracle import detr_ref as R, set_loss_ref as L
     cfg = _cfg()
     params = R.make_params(5, num_enc=1, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
     images = np.random.default_rng(2).normal(size=(2, 96, 128, 3)).astype(np.float32)
@@ -152,6 +152,41 @@ def test_backward_small_shapes_vs_oracle(hip):
     assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
 
 
+def test_training_mode_dropout_vs_oracle_with_same_masks(hip):
+    """model(images, training=True) applies the reference's Dropout(0.1) sites (transformer.py:169-176,216-232,341)
+    with counter-hash masks; the oracle, given the same masks (oracle/dropout_ref.py), must produce the same
+    loss and gradients."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, dropout_ref as DR, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(8, num_enc=2, num_dec=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=2, num_decoder_layers=2)       # dropout = 0.1
+    assert model.engine.dropout_p == pytest.approx(0.1)
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    images = np.random.default_rng(6).normal(size=(2, 128, 160, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=50, force_full=False)
+    out, total, log, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    p, seed = model.engine._drop
+    assert p == pytest.approx(0.1)
+    P = R.to_torch(params, requires_grad=True)
+    ref_out = R.detr_forward(torch.from_numpy(images), P, num_enc=2, num_dec=2, drop=DR.Dropper(p, seed))
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    ref_total.backward()
+    torch.cuda.synchronize()
+    assert _rel(out["pred_logits"], ref_out["pred_logits"]) < 2e-4
+    assert abs(float(total) - float(ref_total)) <= 1e-3 * abs(float(ref_total))
+    rows = _grad_report(model.engine, P)
+    bad = [r for r in rows if r[0] > 1.0]
+    assert not bad, f"gradient mismatch under dropout: {bad[:10]}"
+    # eval mode ignores dropout: same output as a dropout-free model
+    o_eval = model(images, training=False)
+    ref_eval = R.detr_forward(torch.from_numpy(images), R.to_torch(params), num_enc=2, num_dec=2)
+    assert _rel(o_eval["pred_logits"], ref_eval["pred_logits"]) < 2e-4
+
+
 def test_train_steps_vs_oracle_adam(hip):
     """Two full train steps (forward, set loss, backward, per-tensor clipnorm, 3x Adam) on a reduced
     depth model vs the oracle optimiser; also the accumulate/apply cadence with target_batch."""
@@ -163,7 +198,7 @@ def test_train_steps_vs_oracle_adam(hip):
     cfg.backbone_lr.assign(1e-4)
     cfg.transformers_lr.assign(1e-3)
     params = R.make_params(5, num_enc=1, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
     rng = np.random.default_rng(2)
@@ -216,7 +251,7 @@ def test_gradient_accumulation_cadence(hip):
     cfg = _cfg()
     cfg.batch_size, cfg.target_batch = 2, 4
     params = R.make_params(6, num_enc=1, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
     images = np.random.default_rng(3).normal(size=(2, 64, 96, 3)).astype(np.float32)
@@ -269,7 +304,7 @@ def test_c2_full_size_forward_loss_parity(hip):
     from oracle import detr_ref as R, set_loss_ref as L
     cfg = _cfg(train=False)
     params = R.make_params(0)
-    model = get_detr_model(cfg, include_top=True)
+    model = get_detr_model(cfg, include_top=True, dropout=0.0)
     model.load_weights(params)
     B = 8
     images = np.random.default_rng(1234).normal(size=(B, 800, 1333, 3)).astype(np.float32)
