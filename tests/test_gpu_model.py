@@ -35,8 +35,8 @@ def _grad_report(engine, P_ref, rtol=2e-3):
     # Pointwise comparison of two fp32 implementations is ill-posed at ReLU boundaries: a pre-activation
     # that rounds to +1e-8 in one and -1e-8 in the other switches a whole unit's gradient on/off (observed:
     # one pixel of layer3/0 at 96x128, 1 % of that tensor's max).  So the criterion per tensor is the
-    # relative L2 error (<= 5e-3; a wrong tile / dropped term / wrong pixel row gives >= 5e-2) plus a loose
-    # max-abs bound (<= 3e-2 of the tensor max).
+    # relative L2 error (<= 1e-2: single flips were measured at 5.7e-3; a wrong tile / dropped term / wrong pixel
+    # row gives >= 5e-2) plus a loose max-abs bound (<= 3e-2 of the tensor max).
     gmax = max(float(P_ref[n].grad.abs().max()) for n in engine.P.gviews)
     rows = []
     for name, gv in engine.P.gviews.items():
@@ -45,7 +45,7 @@ def _grad_report(engine, P_ref, rtol=2e-3):
         err = float(d.abs().max())
         l2 = float(d.norm()) / (float(ref.norm()) + 1e-6 * gmax * math.sqrt(ref.numel()))
         tol = 3e-2 * float(ref.abs().max()) + 1e-6 * gmax
-        rows.append((max(err / tol, l2 / 5e-3), name, err, float(ref.abs().max()), l2))
+        rows.append((max(err / tol, l2 / 1e-2), name, err, float(ref.abs().max()), l2))
     rows.sort(reverse=True)
     return rows
 
