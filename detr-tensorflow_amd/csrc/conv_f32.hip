@@ -5,6 +5,7 @@
 //     over the zero-padded map + its backward, stride-2 subsample gather/scatter.
 // Reference: detr_tf/networks/resnet_backbone.py:11-32,98-137 (see include/detr_hip.h).
 #include "gemm_core.h"
+#include "gemm_bf16_core.h"
 
 namespace detr {
 
@@ -301,6 +302,237 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16-compute variants (fp32 storage, bf16 MFMA; see gemm_bf16_core.h).  Channel counts must be % 32.
+// ------------------------------------------------------------------------------------------------
+template <int BM, bool DGRAD>
+struct LoaderConvAb {
+    static constexpr int NV = BM / 32;
+    int n_[NV], h_[NV], w_[NV];
+    bool ok[NV];
+    int kq, tid;
+
+    __device__ __forceinline__ void init(const ConvArgs &a, int m0, int tid_) {
+        tid = tid_;
+        kq = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            ok[i] = m < a.M;
+            const int mm = ok[i] ? m : 0;
+            const int wd = mm % a.Wd;
+            const int t = mm / a.Wd;
+            const int hd = t % a.Hd;
+            n_[i] = t / a.Hd;
+            h_[i] = DGRAD ? hd + a.pad : hd * a.stride - a.pad;
+            w_[i] = DGRAD ? wd + a.pad : wd * a.stride - a.pad;
+        }
+    }
+    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
+        const int tap = kt / cpt;
+        const int c0 = (kt - tap * cpt) * BF_BK + kq;
+        const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int hs, ws;
+            bool v = ok[i];
+            if (DGRAD) {
+                const int th = h_[i] - kh, tw = w_[i] - kw;
+                v = v && th >= 0 && tw >= 0;
+                if (a.stride == 2) {
+                    v = v && ((th & 1) == 0) && ((tw & 1) == 0);
+                    hs = th >> 1;
+                    ws = tw >> 1;
+                } else {
+                    hs = th;
+                    ws = tw;
+                }
+                v = v && hs < a.Hs && ws < a.Ws;
+            } else {
+                hs = h_[i] + kh;
+                ws = w_[i] + kw;
+                v = v && hs >= 0 && ws >= 0 && hs < a.Hs && ws < a.Ws;
+            }
+            if (v) r[i] = *reinterpret_cast<const float4 *>(a.src + (((long long)n_[i] * a.Hs + hs) * a.Ws + ws) * a.Cs + c0);
+            else r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint2 *>(&S[row][kq]) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
+    BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = id % a.tiles_n, tm = id / a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int cpt = a.Cs / BF_BK;
+    const int nkt = 9 * cpt;
+    const long long tapstride = (long long)a.Ci * a.Co;
+    LoaderConvAb<BM, DGRAD> la;
+    la.init(a, m0, tid);
+    using LB = typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNb<BN>>::type;
+    constexpr int NRB = DGRAD ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
+    LB lb;
+    lb.init(a.w, a.Co, n0, a.Cd, true, tid);
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 ra[LoaderConvAb<BM, DGRAD>::NV], rb[NRB];
+    auto load_b = [&](int kt) {
+        const int tap = kt / cpt;
+        lb.ptr = a.w + tap * tapstride;
+        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb);
+    };
+    la.load(a, 0, cpt, ra);
+    load_b(0);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (more) {
+            la.load(a, kt + 1, cpt, ra);
+            load_b(kt + 1);
+        }
+        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, wave, a.e);
+}
+
+// wgrad: A'[i = ci][k = m] gathered, MN-contiguous pairs of reduction rows
+template <int BM>
+struct LoaderWgradAb {
+    static constexpr int NU = BM / 64;
+    int n_[NU], h_[NU], w_[NU], m_[NU];
+    int tid, ci0, kh, kw;
+
+    __device__ __forceinline__ void init(const ConvWgradArgs &a, int ci0_, int tap, int m_begin, int tid_) {
+        tid = tid_; ci0 = ci0_;
+        kh = tap / 3; kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int m = m_begin + 2 * (u & 15);
+            m_[i] = m;
+            w_[i] = m % a.Wo;
+            const int t = m / a.Wo;
+            h_[i] = t % a.Ho;
+            n_[i] = t / a.Ho;
+        }
+    }
+    __device__ __forceinline__ float4 fetch(const ConvWgradArgs &a, int n, int h, int w, int m, int m_end, int c) const {
+        const int hs = h * a.stride - a.pad + kh, ws = w * a.stride - a.pad + kw;
+        if (m < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci)
+            return *reinterpret_cast<const float4 *>(a.x + (((long long)n * a.Hi + hs) * a.Wi + ws) * a.Ci + c);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[2 * NU]) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int c = ci0 + (u >> 4) * 4;
+            r[2 * i] = fetch(a, n_[i], h_[i], w_[i], m_[i], m_end, c);
+            int w1 = w_[i] + 1, h1 = h_[i], n1 = n_[i];       // the next output pixel (row m + 1)
+            if (w1 >= a.Wo) { w1 = 0; h1 += 1; if (h1 >= a.Ho) { h1 = 0; n1 += 1; } }
+            r[2 * i + 1] = fetch(a, n1, h1, w1, m_[i] + 1, m_end, c);
+        }
+    }
+    __device__ __forceinline__ void advance(const ConvWgradArgs &a) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            m_[i] += BF_BK;
+            w_[i] += BF_BK;
+            while (w_[i] >= a.Wo) { w_[i] -= a.Wo; h_[i] += 1; }
+            while (h_[i] >= a.Ho) { h_[i] -= a.Ho; n_[i] += 1; }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[2 * NU]) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int kp = u & 15, m4 = (u >> 4) * 4;
+            const float4 p = r[2 * i], q = r[2 * i + 1];
+            *reinterpret_cast<unsigned *>(&S[m4 + 0][2 * kp]) = pack_bf16(p.x, q.x);
+            *reinterpret_cast<unsigned *>(&S[m4 + 1][2 * kp]) = pack_bf16(p.y, q.y);
+            *reinterpret_cast<unsigned *>(&S[m4 + 2][2 * kp]) = pack_bf16(p.z, q.z);
+            *reinterpret_cast<unsigned *>(&S[m4 + 3][2 * kp]) = pack_bf16(p.w, q.w);
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvWgradArgs a) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
+    BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tn = blockIdx.x % a.tiles_n, tm = blockIdx.x / a.tiles_n;
+    const int ci0 = tm * BM, co0 = tn * BN;
+    const int tap = blockIdx.y;
+    const int m_begin = blockIdx.z * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    if (m_begin >= m_end) return;
+    const int nkt = (m_end - m_begin + BF_BK - 1) / BF_BK;
+    LoaderWgradAb<BM> la;
+    la.init(a, ci0, tap, m_begin, tid);
+    LoaderMNb<BN> lb;
+    lb.init(a.dy, a.Co, co0, a.Co, true, tid);
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 ra[2 * LoaderWgradAb<BM>::NU], rb[2 * LoaderMNb<BN>::NU];
+    la.load(a, m_end, ra);
+    lb.load(m_begin, m_end, rb);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (more) {
+            la.advance(a);
+            la.load(a, m_end, ra);
+            lb.load(m_begin + (kt + 1) * BF_BK, m_end, rb);
+        }
+        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem / pooling / subsample elementwise kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void stem_im2col_kernel(const float *__restrict__ img, float *__restrict__ col, int N, int H, int W,
@@ -433,6 +665,16 @@ static inline int ew_grid(long long total, int block) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
+static void launch_conv_bf16(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+    ConvArgs a = a0;
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cd, BN);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
+}
+
+template <int BM, int BN, int WGM, int WGN>
 static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     ConvArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
@@ -443,7 +685,7 @@ static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s) {
+static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false) {
     ConvWgradArgs a = a0;
     a.tiles_m = cdiv(a.Ci, BM);
     a.tiles_n = cdiv(a.Co, BN);
@@ -455,7 +697,7 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
         if (split < 1) split = 1;
     }
     int rps = cdiv(a.M, split);
-    rps = ((rps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+    rps = ((rps + BF_BK - 1) / BF_BK) * BF_BK;       // multiple of both K tiles (16 and 32)
     a.rows_per_split = rps;
     split = cdiv(a.M, rps);
     const long long part = 9LL * a.Ci * a.Co;
@@ -474,7 +716,8 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
         a.e.atomic = 1;   // accumulate onto dw
     }
     dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
+    if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
 }
 
@@ -513,6 +756,13 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         a.M = d->N * d->Ho * d->Wo;
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
+        const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
+        if (bf) {
+            if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, true);
+            else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, true);
+            DETR_LAUNCH_CHECK("conv3x3 wgrad bf16");
+            return 0;
+        }
         const int wforce = env_tile("DETR_HIP_WGRAD_TILE");
         if (wforce == 3) launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         else if (wforce == 1) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
@@ -538,7 +788,10 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     const bool dgrad = mode == 1;
     const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
-    if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);
+    if (d->compute == 1 && a.Cs % 32 == 0 && a.Cd % 32 == 0) {
+        if (force == 3 || (force == 0 && (a.Cd <= 64 || big < 128))) launch_conv_bf16<64, 64, 2, 2>(a, dgrad, s);
+        else launch_conv_bf16<128, 128, 2, 2>(a, dgrad, s);
+    } else if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);
     else if (force == 2) launch_conv<128, 64, 2, 2>(a, dgrad, s);
     else if (force == 3) launch_conv<64, 64, 2, 2>(a, dgrad, s);
     else {

@@ -1,0 +1,148 @@
+// gemm_bf16_core.h -- bf16-COMPUTE tile engine (fp32 storage, bf16 MFMA, fp32 accumulate) for gfx950.
+//
+// Used when the engine runs in precision="bf16" (BASELINE.json config C3): operands stay fp32 in HBM and are
+// rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS; v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA
+// rate) accumulates in fp32; the epilogue (scale/bias/residual/activation/mask/dropout, float4 stores through
+// LDS) is the fp32 one from gemm_core.h.  With fp32 storage these kernels are HBM / L2 bound, not MFMA bound.
+//
+// LDS image: [row][k] with k contiguous, 32 k per tile, row stride 40 bf16 = 80 B.  A 32x32x16 fragment is 8
+// consecutive k of one row = one ds_read_b128; 80 B = 5 sixteen-byte slots per row and gcd(5,16) = 1, so the 16
+// lanes of every ds_read_b128 service group (distinct rows mod 16) hit 16 distinct slots: conflict free.
+//   * K-contiguous fp32 operand ([mn][k]): float4 global load -> 4 bf16 -> one ds_write_b64.
+//   * MN-contiguous fp32 operand ([k][mn], e.g. HWIO kernels, weight-gradient operands): each lane loads the
+//     float4 of TWO consecutive k rows and writes four packed (k, k+1) words to four LDS rows; lanes are ordered
+//     k-pair fastest so that a half-wave writes 32 distinct banks.
+#pragma once
+#include "gemm_core.h"
+
+namespace detr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BF_BK = 32;
+constexpr int BF_LD = 40;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+
+template <int BM, int BN>
+struct BfSmem {
+    unsigned short A[2][BM][BF_LD];
+    unsigned short B[2][BN][BF_LD];
+};
+
+template <int BM, int BN, int WGN>
+struct BfSmemBytes {
+    static constexpr int TILES = (int)sizeof(BfSmem<BM, BN>);
+    static constexpr int STAGE = 4 * 32 * (BN / WGN + 4) * 4;
+    static constexpr int VALUE = TILES > STAGE ? TILES : STAGE;
+};
+
+// fp32 operand stored [mn][k] (k contiguous). Thread t: rows (t>>3) + 32*i, k offset (t&7)*4.
+template <int BMN>
+struct LoaderKb {
+    static constexpr int NV = BMN / 32;
+    const float *ptr;
+    long long off[NV];
+    bool ok[NV];
+    bool vec;
+    int kq, tid;
+
+    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, bool vec_, int tid_) {
+        ptr = p; vec = vec_; tid = tid_;
+        kq = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int g = mn0 + (tid >> 3) + 32 * i;
+            ok[i] = g < MN;
+            off[i] = (long long)g * ld;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            r[i] = ok[i] ? ld4_guard(ptr + off[i] + k, K - k, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint2 *>(&S[row][kq]) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+        }
+    }
+};
+
+// fp32 operand stored [k][mn] (mn contiguous). Unit u = t + 256*i: k pair kp = u & 15, column group (u >> 4)*4.
+template <int BMN>
+struct LoaderMNb {
+    static constexpr int NU = BMN / 64;
+    const float *ptr;
+    long long ld;
+    int mn0, MN;
+    bool vec;
+    int tid;
+
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, bool vec_, int tid_) {
+        ptr = p; ld = ld_; mn0 = mn0_; MN = MN_; vec = vec_; tid = tid_;
+    }
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[2 * NU]) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int k = k0 + 2 * (u & 15);
+            const int col = mn0 + (u >> 4) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (k + h < K && col < MN) r[2 * i + h] = ld4_guard(ptr + (long long)(k + h) * ld + col, MN - col, vec);
+                else r[2 * i + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[2 * NU]) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int kp = u & 15;
+            const int m4 = (u >> 4) * 4;
+            const float4 a = r[2 * i], b = r[2 * i + 1];
+            *reinterpret_cast<unsigned *>(&S[m4 + 0][2 * kp]) = pack_bf16(a.x, b.x);
+            *reinterpret_cast<unsigned *>(&S[m4 + 1][2 * kp]) = pack_bf16(a.y, b.y);
+            *reinterpret_cast<unsigned *>(&S[m4 + 2][2 * kp]) = pack_bf16(a.z, b.z);
+            *reinterpret_cast<unsigned *>(&S[m4 + 3][2 * kp]) = pack_bf16(a.w, b.w);
+        }
+    }
+};
+
+// one 32-deep K tile: 2 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.
+// operand map: lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31].
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BF_LD], const unsigned short (*Bs)[BF_LD],
+                                               f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                               int wm, int wn, int lane) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    const int l31 = lane & 31;
+    const int kh = (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BF_BK; ks += 16) {
+        bf16x8 a[T::TM], b[T::TN];
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi)
+            a[mi] = *reinterpret_cast<const bf16x8 *>(&As[wm * T::WTM + mi * 32 + l31][ks + kh]);
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni)
+            b[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh]);
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+}  // namespace detr

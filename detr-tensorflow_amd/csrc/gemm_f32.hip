@@ -2,6 +2,7 @@
 // Replaces every tf.matmul / 1x1 Conv2D / Linear of the reference's hot path and their
 // gradients (see include/detr_hip.h for the reference lines).
 #include "gemm_core.h"
+#include "gemm_bf16_core.h"
 
 namespace detr {
 
@@ -78,6 +79,69 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
             lb.load((kt + 1) * GEMM_BK, g.K, rb);
         }
         mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        if (more) {
+            la.store(sm.A[cur ^ 1], ra);
+            lb.store(sm.B[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
+}
+
+// bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
+    BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = id % g.tiles_n, tm = id / g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const int split = z % g.split_k;
+    const int zb = z / g.split_k;
+    const int z0 = zb / g.batch_inner, z1 = zb % g.batch_inner;
+    const float *A = g.A + z0 * g.sA0 + z1 * g.sA1;
+    const float *B = g.B + z0 * g.sB0 + z1 * g.sB1;
+    float *C = g.C + z0 * g.sC0 + z1 * g.sC1 + (long long)split * g.part_stride;
+    const int nkt = (g.K + BF_BK - 1) / BF_BK;
+    const int per = (nkt + g.split_k - 1) / g.split_k;
+    const int kt0 = split * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    using LA = typename std::conditional<AK, LoaderKb<BM>, LoaderMNb<BM>>::type;
+    using LB = typename std::conditional<BKC, LoaderKb<BN>, LoaderMNb<BN>>::type;
+    constexpr int NRA = AK ? LoaderKb<BM>::NV : 2 * LoaderMNb<BM>::NU;
+    constexpr int NRB = BKC ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
+    LA la;
+    LB lb;
+    la.init(A, g.lda, m0, g.M, g.a_vec != 0, tid);
+    lb.init(B, g.ldb, n0, g.N, g.b_vec != 0, tid);
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 ra[NRA], rb[NRB];
+    la.load(kt0 * BF_BK, g.K, ra);
+    lb.load(kt0 * BF_BK, g.K, rb);
+    la.store(sm.A[0], ra);
+    lb.store(sm.B[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) {
+            la.load((kt + 1) * BF_BK, g.K, ra);
+            lb.load((kt + 1) * BF_BK, g.K, rb);
+        }
+        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
@@ -165,6 +229,20 @@ static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool
     return 0;
 }
 
+template <int BM, int BN, int WGM, int WGN>
+static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
+    GemmArgs a = g;
+    a.tiles_m = cdiv(g.M, BM);
+    a.tiles_n = cdiv(g.N, BN);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
+    dim3 block(GEMM_THREADS);
+    if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+    return 0;
+}
+
 }  // namespace detr
 
 using namespace detr;
@@ -176,8 +254,9 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     const int batch = d->batch > 0 ? d->batch : 1;
     const int inner = d->batch_inner > 0 ? d->batch_inner : 1;
     int split = d->split_k > 1 ? d->split_k : 1;
+    const bool bf16c = d->compute == 1;
     if (split > 1) {   // no empty splits: recompute the effective count from the K tiles each split gets
-        const int nkt = cdiv(d->K, GEMM_BK);
+        const int nkt = cdiv(d->K, bf16c ? BF_BK : GEMM_BK);
         const int per = cdiv(nkt, split);
         split = cdiv(nkt, per);
     }
@@ -237,7 +316,12 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
     const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
-    if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
+    if (bf16c) {
+        // bf16 MFMA is 16x faster per flop: larger tiles are needed to amortise loads / barriers
+        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
+        if (force == 3 || (force == 0 && (d->N <= 64 || d->M <= 64 || t128 < 128))) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
+        else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
+    } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (force == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
     else if (force == 3) launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     else if (force == 4) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);

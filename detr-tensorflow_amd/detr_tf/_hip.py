@@ -30,7 +30,7 @@ class GemmDesc(Structure):
                 ("mask", c_void_p), ("ldmask", c_int64),
                 ("act", c_int32), ("split_k", c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
-                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32)]
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32)]
 
 
 class Conv3x3Desc(Structure):
@@ -40,7 +40,7 @@ class Conv3x3Desc(Structure):
                 ("alpha", c_float),
                 ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
                 ("act", c_int32), ("split", c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32)]
 
 
 class SetLossDesc(Structure):
@@ -134,6 +134,7 @@ class KernelProfiler:
 
 
 PROFILER = None
+COMPUTE_BF16 = 0      # default compute mode of gemm / conv3x3: 0 = exact fp32 MFMA, 1 = bf16 MFMA (fp32 storage)
 WORKSPACE = None      # fp32 scratch tensor for the deterministic split-K reductions (set by the engine)
 
 
@@ -188,7 +189,7 @@ def _f32(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
          residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0, compute=None):
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -205,6 +206,7 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d.mask, d.ldmask = ptr(mask), ldmask
     d.act, d.split_k = act, split_k
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
+    d.compute = COMPUTE_BF16 if compute is None else int(compute)
     ws = workspace if workspace is not None else WORKSPACE
     d.workspace, d.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
@@ -258,7 +260,7 @@ def linear_wgrad(dy2d, x2d, dw_out_in, *, alpha=1.0):
 # conv
 # ------------------------------------------------------------------------------------------
 def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.0, scale=None, bias=None,
-            residual=None, mask=None, act=0, split=0):
+            residual=None, mask=None, act=0, split=0, compute=None):
     d = Conv3x3Desc()
     d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.stride, d.pad = N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
@@ -266,6 +268,7 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split
     d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
+    d.compute = COMPUTE_BF16 if compute is None else int(compute)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
     if ev0 is not None:

@@ -72,6 +72,9 @@ typedef struct {
      * (dropout_seed, row*N + col), kept values scaled by 1/(1-p); applied before the residual add when a
      * residual is given, otherwise after the activation.  0 = off. */
     float dropout_p; uint32_t dropout_seed;
+    /* 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA with fp32 storage / accumulation (BASELINE config C3:
+     * operands are rounded to bf16 on their way into LDS) */
+    int32_t compute;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 
@@ -98,6 +101,7 @@ typedef struct {
     int32_t act;
     int32_t split;       /* wgrad: number of row splits (0 = auto) */
     float *workspace; int64_t workspace_bytes;   /* wgrad: scratch for deterministic split reduction (see detr_gemm_desc) */
+    int32_t compute;     /* 0 = exact fp32 MFMA, 1 = bf16 MFMA (see detr_gemm_desc) */
 } detr_conv3x3_desc;
 int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
 

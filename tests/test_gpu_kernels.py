@@ -619,3 +619,81 @@ def test_fused_attention_dropout(hip, B, T, S):
     close(dq, q.grad, rtol=5e-5, what="attention+dropout dq")
     close(dk, k.grad, rtol=5e-5, what="attention+dropout dk")
     close(dv, v.grad, rtol=5e-5, what="attention+dropout dv")
+
+
+# ------------------------------------------------------------------------------------------
+# bf16-compute mode (fp32 storage, bf16 MFMA, fp32 accumulate): exact vs a reference whose OPERANDS are rounded
+# to bf16 (the only rounding the kernel adds), so layout / indexing bugs cannot hide behind a loose tolerance
+# ------------------------------------------------------------------------------------------
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 92, 256), (1000, 256, 147), (77, 40, 33), (8400, 256, 2048), (130, 512, 100)])
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_bf16_compute_layouts(hip, M, N, K, ak, bk):
+    torch.manual_seed(M + N + K + ak * 2 + bk)
+    A, B = torch.randn(M, K), torch.randn(K, N)
+    ref = _bf(A) @ _bf(B)
+    lda, ldb = (K if ak else M) + 4, (K if bk else N) + 4
+    Am = torch.zeros((M, lda) if ak else (K, lda))
+    Bm = torch.zeros((N, ldb) if bk else (K, ldb))
+    if ak:
+        Am[:, :K] = A
+    else:
+        Am[:, :M] = A.t()
+    if bk:
+        Bm[:, :K] = B.t()
+    else:
+        Bm[:, :N] = B
+    Ad, Bd = g(Am), g(Bm)
+    bias, R = torch.randn(N), torch.randn(M, N)
+    bd, Rd = g(bias), g(R)
+    C = torch.full((M, N + 4), 7.0, device=DEV)
+    hip.gemm(M, N, K, Ad, lda, ak, Bd, ldb, bk, C, N + 4, bias=bd, residual=Rd, ldr=N, act=1, compute=1)
+    close(C[:, :N], (ref + bias.double() + R.double()).clamp_min(0), rtol=2e-5, what=f"bf16c gemm {M}x{N}x{K} ak={ak} bk={bk}")
+    assert float((C[:, N:] - 7.0).abs().max()) == 0.0
+
+
+def test_gemm_bf16_compute_split_k(hip):
+    torch.manual_seed(31)
+    M, N, K = 256, 512, 20000
+    A, B = torch.randn(K, M), torch.randn(K, N)
+    scale = torch.rand(N) + 0.5
+    Ad, Bd, sd = g(A), g(B), g(scale)
+    ws = torch.empty(16 * 1024 * 1024, device=DEV)
+    C = torch.zeros(M, N, device=DEV)
+    hip.gemm(M, N, K, Ad, M, 0, Bd, N, 0, C, N, scale=sd, split_k=24, workspace=ws, compute=1)
+    close(C, (_bf(A).t() @ _bf(B)) * scale.double(), rtol=5e-5, what="bf16c split-k")
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 50, 84, 256, 256, 1),
+                                                (1, 25, 42, 512, 512, 2), (2, 9, 11, 32, 64, 1)])
+def test_conv3x3_bf16_compute_all_modes(hip, N, H, W, Ci, Co, stride):
+    torch.manual_seed(N + H + W + Ci + stride + 100)
+    x = _bf(torch.randn(N, H, W, Ci)).requires_grad_(True)                  # operands already on the bf16 grid:
+    w = _bf(torch.randn(3, 3, Ci, Co) / (3 * Ci ** 0.5)).requires_grad_(True)  # the kernel's rounding is then exact
+    scale, shift = torch.rand(Co, dtype=torch.float64) + 0.5, torch.randn(Co, dtype=torch.float64)
+    z = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=stride, padding=1).permute(0, 2, 3, 1)
+    Ho, Wo = z.shape[1], z.shape[2]
+    y = torch.relu(z * scale + shift)
+    xd, wd = g(x.detach().float()), g(w.detach().float())
+    sd, hd_ = g(scale.float()), g(shift.float())
+    yd = torch.zeros(N, Ho, Wo, Co, device=DEV)
+    hip.conv3x3(0, xd, wd, yd, N, H, W, Ci, Ho, Wo, Co, stride, scale=sd, bias=hd_, act=1, compute=1)
+    close(yd, y, rtol=3e-5, what="bf16c conv3x3 fwd")
+    dz = _bf(torch.randn(N, Ho, Wo, Co))
+    z.backward(dz)
+    dzd = g(dz.float())
+    dxd = torch.zeros(N, H, W, Ci, device=DEV)
+    hip.conv3x3(1, dzd, wd, dxd, N, H, W, Ci, Ho, Wo, Co, stride, compute=1)
+    close(dxd, x.grad, rtol=3e-5, what="bf16c conv3x3 dgrad")
+    ws = torch.empty(32 * 1024 * 1024, device=DEV)
+    old = hip.WORKSPACE
+    try:
+        hip.WORKSPACE = ws
+        dwd = torch.zeros(3, 3, Ci, Co, device=DEV)
+        hip.conv3x3(2, xd, dzd, dwd, N, H, W, Ci, Ho, Wo, Co, stride, scale=sd, compute=1)
+        close(dwd, w.grad * scale, rtol=5e-5, what="bf16c conv3x3 wgrad")
+    finally:
+        hip.WORKSPACE = old
