@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
     ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 storage/accumulation (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -124,7 +126,7 @@ def main():
     cfg.batch_size = args.batch
     cfg.target_batch = None
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
-    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout)
+    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=args.precision)
     opt = setup_optimizers(model, cfg)
     if world > 1:
         # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
@@ -205,7 +207,20 @@ def main():
                     with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
                         tj = json.load(f)
                     traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
-                roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                if args.precision == "bf16":
+                    # fp32 storage + bf16 MFMA: the GEMM-class kernels are HBM bound -> algorithmic bytes / time
+                    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                    roofline = {"bound": "hbm", "kernel": dom + " (bf16 compute)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                                "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                                "tflops": round(ach, 2), "launches_per_step": d["launches"] // args.steps,
+                                "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                                "families": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                                 "launches_per_step": v["launches"] // args.steps} for k, v in fam.items()}}
+                else:
+                  roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                             "traffic_source": traffic_src,
                             "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
@@ -219,7 +234,7 @@ def main():
                       else "images/sec forward+set-loss, DETR-R50 800x1333 bs=8/GPU",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"DETR-R50 {'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)"},

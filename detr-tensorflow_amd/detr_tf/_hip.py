@@ -104,16 +104,16 @@ class KernelProfiler:
         ev.record()
         return ev
 
-    def end(self, family, flops, ev0, sig=None):
+    def end(self, family, flops, ev0, sig=None, nbytes=0.0):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.records.append((family, flops, ev0, ev1, sig))
+        self.records.append((family, flops, ev0, ev1, sig, nbytes))
 
     def by_shape(self, top=40):
         """Per (family, shape signature) totals, sorted by time: where the GEMM time goes."""
         torch.cuda.synchronize()
         agg = {}
-        for fam, flops, e0, e1, sig in self.records:
+        for fam, flops, e0, e1, sig, _nb in self.records:
             d = agg.setdefault((fam, sig), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
@@ -125,11 +125,12 @@ class KernelProfiler:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, e0, e1, _sig in self.records:
-            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for fam, flops, e0, e1, _sig, nb in self.records:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
+            d["bytes"] += nb
         return out
 
 
@@ -214,7 +215,8 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     if ev0 is not None:
         PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0,
                      f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
-                     f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")
+                     f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}",
+                     4.0 * batch * (M * K + K * N + M * N * (1 + (residual is not None) + (mask is not None))))
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -274,7 +276,8 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     if ev0 is not None:
         rows = N * (Hi * Wi if mode == 1 else Ho * Wo)
         PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0,
-                     f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}")
+                     f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}",
+                     4.0 * (N * Hi * Wi * Ci + N * Ho * Wo * Co + 9 * Ci * Co + (rows * (Ci if mode == 1 else Co) if mask is not None else 0)))
 
 
 def call(name, *args):

@@ -68,6 +68,7 @@ class DetrEngine:
         self.bn_scale, self.bn_shift = {}, {}
         self.fold_bn()
         self.weights_dirty = True        # scaled conv kernels must be refreshed after every optimiser step
+        self.compute = 0                 # 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA, fp32 storage (config C3)
         self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
         self.dropout_seed = 0x5EED       # base seed; advanced by the step counter
         self._step_no = 0
@@ -250,6 +251,21 @@ class DetrEngine:
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, images, training=False):
+        """See _forward_impl.  GEMM / conv compute mode: self.compute (0 = exact fp32, 1 = bf16 MFMA)."""
+        hip.COMPUTE_BF16 = self.compute
+        try:
+            return self._forward_impl(images, training)
+        finally:
+            hip.COMPUTE_BF16 = 0
+
+    def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
+        hip.COMPUTE_BF16 = self.compute
+        try:
+            return self._backward_impl(d_logits, d_boxes, backbone, on_bucket)
+        finally:
+            hip.COMPUTE_BF16 = 0
+
+    def _forward_impl(self, images, training=False):
         """images: CUDA fp32 NHWC [B,H,W,3] (already normalised, processing.py:12-16).
         Returns (logits [Lv,B,Q,C], boxes [Lv,B,Q,4]) views of engine buffers."""
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[3] == 3
@@ -369,6 +385,7 @@ class DetrEngine:
             self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
             tgt = t3
         # ---------------- heads (detr.py:181-204 / :94-114) ----------------
+        hip.COMPUTE_BF16 = 0          # the heads, like LayerNorm / softmax / the set loss, always run in exact fp32
         Lv = self.num_dec
         R = Lv * B * Q
         hs2 = hs.view(R, D)
@@ -395,7 +412,7 @@ class DetrEngine:
     def zero_grad(self):
         hip.zero_(self.P.grad)
 
-    def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
+    def _backward_impl(self, d_logits, d_boxes, backbone=True, on_bucket=None):
         """d_logits [Lv,B,Q,C], d_boxes [Lv,B,Q,4] (contiguous CUDA fp32): gradients of the scalar
         loss w.r.t. the head outputs.  Parameter gradients are ACCUMULATED into P.grad.
         on_bucket(i) is called when gradient bucket i (ParamStore.bucket_bounds) is final."""
@@ -409,6 +426,7 @@ class DetrEngine:
         db = d_boxes.reshape(R, 4)
         boxes, t_a, t_b = self._bufs["head:boxes"], self._bufs["head:t1"], self._bufs["head:t2"]
         # ---------------- heads ----------------
+        hip.COMPUTE_BF16 = 0
         dz3 = self.buf("scratch:dz3", (R, 4))
         hip.call("detr_hip_sigmoid_bwd_f32", db.data_ptr(), boxes.data_ptr(), dz3.data_ptr(), R * 4)
         d_hs = self.buf("scratch:d_hs", (R, D))
@@ -440,6 +458,7 @@ class DetrEngine:
             dense_bwd(dt_a, hs2, "pos_layer/dense_0", d_hs)
             dense_bwd(dl, hs2, "cls_layer", d_hs, residual=d_hs)
         d_hs3 = d_hs.view(Lv, B * Q, D)
+        hip.COMPUTE_BF16 = self.compute
         # ---------------- decoder ----------------
         feat, Hf, Wf, L = self._feat_meta
         memory = self._bufs[f"enc{self.num_enc - 1}:x2"] if self.num_enc > 0 else self._bufs["enc:src0"]

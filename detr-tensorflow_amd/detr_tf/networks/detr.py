@@ -29,7 +29,7 @@ class _Layer:
 
 class DetrModel:
     def __init__(self, include_top=True, nb_class=None, num_decoder_layers=6, num_encoder_layers=6, num_queries=100,
-                 backbone="resnet50", device=None, seed=0, dropout=0.1):
+                 backbone="resnet50", device=None, seed=0, dropout=0.1, precision="fp32"):
         device = device or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None)
         if device is None:
             raise RuntimeError("DETR HIP model needs a GPU: the hot path has no CPU fallback")
@@ -38,6 +38,10 @@ class DetrModel:
         self.headless = (not include_top) and nb_class is None
         self.name = "detr" if self.headless else "detr_finetuning"
         self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (exact, parity mode) or 'bf16' (bf16 MFMA, fp32 storage/accumulate)")
+        self.engine.compute = 1 if precision == "bf16" else 0
+        self.precision = precision
         self.engine.dropout_p = float(dropout)  # Transformer(dropout=0.1), applied when called with training=True
         self.dp = None                        # parallel.DataParallel when training on several GPUs
         self.device = self.engine.device
@@ -96,7 +100,8 @@ class DetrModel:
 
 
 def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_backbone=False, num_decoder_layers=6,
-                   num_encoder_layers=6, num_queries=100, backbone="resnet50", device=None, seed=0, dropout=0.1):
+                   num_encoder_layers=6, num_queries=100, backbone="resnet50", device=None, seed=0, dropout=0.1,
+                   precision="fp32"):
     """Same arguments and three output modes as the reference (detr.py:116-204); `num_queries`,
     `backbone` ("resnet50" | "resnet101", resnet_backbone.py:35-66), `device` and `seed` are
     extensions (the reference never exposes num_queries / ResNet101); `dropout` is the
@@ -105,7 +110,7 @@ def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_ba
         raise NotImplementedError("tf_backbone=True (keras.applications ResNet50) is not on the HIP hot path yet")
     model = DetrModel(include_top=include_top, nb_class=nb_class, num_decoder_layers=num_decoder_layers,
                       num_encoder_layers=num_encoder_layers, num_queries=num_queries, backbone=backbone, device=device,
-                      seed=seed, dropout=dropout)
+                      seed=seed, dropout=dropout, precision=precision)
     if weights is not None:
         if isinstance(weights, str) and not weights.endswith(".npz"):
             raise NotImplementedError(f'weights="{weights}": the reference downloads a TF checkpoint (weights.py:5-11); '

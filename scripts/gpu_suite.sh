@@ -19,6 +19,7 @@ for w in $WHAT; do
         timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --dist-backend gloo > $OUT/bench_dp2_gloo.log 2>&1; echo "bench dp2 rc=$?" >> $OUT/summary.txt; tail -3 $OUT/bench_dp2_gloo.log ;;
     smoke)timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
     bench) timeout 600 python bench.py --steps 5 --warmup 2 --dump-shapes $OUT/shapes.json > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt ;;
+    bench16) timeout 600 python bench.py --steps 5 --warmup 2 --precision bf16 --no-cpu-baseline --dump-shapes $OUT/shapes_bf16.json > $OUT/bench_bf16.log 2>&1; echo "bench16 rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_bf16.log | cut -c1-400 ;;
     fwd) timeout 300 python bench.py --steps 5 --warmup 2 --mode fwdloss --no-cpu-baseline > $OUT/bench_fwd.log 2>&1; echo "fwd rc=$?" >> $OUT/summary.txt ;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof -o prof -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events > /root/repo/$OUT/prof.log 2>&1); echo "prof rc=$?" >> $OUT/summary.txt
           python scripts/prof_summary.py $OUT/prof/prof_results.db 3 > $OUT/prof_summary.txt 2>&1 ;;

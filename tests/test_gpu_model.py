@@ -187,6 +187,42 @@ def test_training_mode_dropout_vs_oracle_with_same_masks(hip):
     assert _rel(o_eval["pred_logits"], ref_eval["pred_logits"]) < 2e-4
 
 
+def test_bf16_compute_mode_deviation_from_fp32_oracle(hip):
+    """precision="bf16" (bf16 MFMA on fp32-stored operands, fp32 accumulate; LayerNorm, softmax/attention, heads,
+    matching and loss stay fp32 -- BASELINE config C3).  Not a parity mode: the test bounds and REPORTS the deviation
+    from the fp32 oracle (forward 3e-2 of the logit scale, loss 2e-2 rel, gradients 10 % relative L2 per tensor)."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(3)
+    model = get_detr_model(cfg, include_top=True, dropout=0.0, precision="bf16")
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    images = np.random.default_rng(11).normal(size=(2, 128, 160, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=21, force_full=False)
+    out, total, log, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    P = R.to_torch(params, requires_grad=True)
+    ref_out = R.detr_forward(torch.from_numpy(images), P)
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    ref_total.backward()
+    torch.cuda.synchronize()
+    dev_logits = _rel(out["pred_logits"], ref_out["pred_logits"])
+    dev_boxes = _rel(out["pred_boxes"], ref_out["pred_boxes"])
+    dev_loss = abs(float(total) - float(ref_total)) / abs(float(ref_total))
+    l2 = []
+    for name, gv in model.engine.P.gviews.items():
+        ref = P[name].grad.double()
+        if float(ref.norm()) > 1e-8:
+            l2.append((float((gv.detach().cpu().double() - ref).norm() / ref.norm()), name))
+    l2.sort(reverse=True)
+    print(f"bf16-compute deviation: logits {dev_logits:.2e} boxes {dev_boxes:.2e} loss {dev_loss:.2e} worst grad L2 {l2[:3]}")
+    assert dev_logits < 3e-2 and dev_boxes < 3e-2, (dev_logits, dev_boxes)
+    assert dev_loss < 2e-2, dev_loss
+    assert np.median([v for v, _ in l2]) < 3e-2 and l2[len(l2) // 20][0] < 0.1, l2[:8]
+
+
 def test_train_steps_vs_oracle_adam(hip):
     """Two full train steps (forward, set loss, backward, per-tensor clipnorm, 3x Adam) on a reduced
     depth model vs the oracle optimiser; also the accumulate/apply cadence with target_batch."""
