@@ -307,6 +307,23 @@ __global__ void scale_cols_kernel(const float *__restrict__ w, const float *__re
         o[i] = w[i] * scale[i % cols];
 }
 
+// o[c][r] = w[r][c] * scale[c]  (transposed scaled copy: K-contiguous B operand for the bf16 1x1-conv forward)
+__global__ void scale_cols_t_kernel(const float *__restrict__ w, const float *__restrict__ scale, float *__restrict__ o,
+                                    int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? w[(long long)r * cols + c] * (scale ? scale[c] : 1.0f) : 0.0f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) o[(long long)c * rows + r] = tile[tx][j];
+    }
+}
+
 __global__ void bn_fold_kernel(const float *__restrict__ weight, const float *__restrict__ bias,
                                const float *__restrict__ mean, const float *__restrict__ var, float *__restrict__ scale,
                                float *__restrict__ shift, int C, float eps) {
@@ -442,6 +459,15 @@ extern "C" int detr_hip_scale_cols_f32(const float *w, const float *scale, float
     hipLaunchKernelGGL(scale_cols_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, scale, w_out, n,
                        cols);
     DETR_LAUNCH_CHECK("scale_cols");
+    return 0;
+}
+
+extern "C" int detr_hip_scale_cols_t_f32(const float *w, const float *scale, float *w_out_t, int32_t rows, int32_t cols,
+                                         void *stream) {
+    DETR_REQUIRE(w && w_out_t && rows > 0 && cols > 0, "scale_cols_t: bad args");
+    dim3 grid((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32));
+    hipLaunchKernelGGL(scale_cols_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, scale, w_out_t, rows, cols);
+    DETR_LAUNCH_CHECK("scale_cols_t");
     return 0;
 }
 

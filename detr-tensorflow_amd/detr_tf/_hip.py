@@ -76,6 +76,7 @@ _SIGNATURES = {
     "detr_hip_sigmoid_bwd_f32": [f32p, f32p, f32p, c_int64, c_void_p],
     "detr_hip_relu_mask_f32": [f32p, f32p, f32p, c_int64, c_void_p],
     "detr_hip_scale_cols_f32": [f32p, f32p, f32p, c_int64, c_int32, c_void_p],
+    "detr_hip_scale_cols_t_f32": [f32p, f32p, f32p, c_int32, c_int32, c_void_p],
     "detr_hip_bn_fold_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_float, c_void_p],
     "detr_hip_match_cost_f32": [POINTER(SetLossDesc), f32p, c_void_p],
     "detr_hip_assign_f32": [f32p, c_int32, c_int32, c_int32, f32p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -221,6 +222,10 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
 
 def pick_split_k(M, N, K, max_split=1024):
     """Reduction-heavy GEMMs (weight gradients): split K so that ~1000 workgroups exist."""
+    if COMPUTE_BF16 and N >= 128:               # bf16 split-K runs 128x128 tiles, ~512 workgroups measured best
+        tiles = -(-M // 128) * -(-N // 128)
+        ktiles = -(-K // 32)
+        return int(max(1, min(max(1, 512 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
     tiles = -(-M // 64) * -(-N // 64)           # the kernel uses 64x64 tiles
     want = max(1, 1024 // max(tiles, 1))        # ~1024 workgroups measured best (512..2048 within 5 %)
     ktiles = -(-K // 16)

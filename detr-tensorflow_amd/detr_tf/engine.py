@@ -110,6 +110,21 @@ class DetrEngine:
                      w.numel() // co, co)
         return ws
 
+    def _conv1x1_fwd(self, x, M, cin, cout, conv_name, bn_name, out, residual=None, act=1):
+        """1x1 conv + frozen BN (+ residual) (+ ReLU) as one GEMM (resnet_backbone.py:119-121,128-135).
+        fp32 mode: B = scaled kernel [cin][cout] (N contiguous).  bf16 mode: a transposed scaled copy
+        [cout][cin] keeps BOTH operands K-contiguous (128-byte row segments: measured 1.5x faster loads)."""
+        ws = self._scaled_kernel(conv_name, bn_name)
+        shift = self.bn_shift[bn_name]
+        ldr = cout if residual is not None else 0
+        if self.compute == 1:
+            wst = self.buf(f"wst:{conv_name}", (cout, cin))
+            if self.weights_dirty:
+                hip.call("detr_hip_scale_cols_t_f32", ws.data_ptr(), None, wst.data_ptr(), cin, cout)
+            hip.gemm(M, cout, cin, x, cin, 1, wst, cin, 1, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
+        else:
+            hip.gemm(M, cout, cin, x, cin, 1, ws, cout, 0, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
+
     # ---- small helpers ----------------------------------------------------------------------------
     @staticmethod
     def _wgrad(M_out, N_out, K_red, A, lda, Bm, ldb, C, ldc, scale=None, alpha=1.0):
@@ -304,8 +319,7 @@ class DetrEngine:
                 ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
                 M_in, M_out = B * h * w, B * ho * wo
                 y1 = self.buf(f"{p}:y1", (B, h, w, d1))
-                hip.gemm(M_in, d1, cin, x, cin, 1, self._scaled_kernel(f"{p}/conv1/kernel", f"{p}/bn1"), d1, 0, y1, d1,
-                         bias=self.bn_shift[f"{p}/bn1"], act=1)
+                self._conv1x1_fwd(x, M_in, cin, d1, f"{p}/conv1/kernel", f"{p}/bn1", y1)
                 y2 = self.buf(f"{p}:y2", (B, ho, wo, d1))
                 hip.conv3x3(0, y1, self._scaled_kernel(f"{p}/conv2/kernel", f"{p}/bn2"), y2, B, h, w, d1, ho, wo, d1,
                             stride, bias=self.bn_shift[f"{p}/bn2"], act=1)
@@ -316,14 +330,11 @@ class DetrEngine:
                     else:
                         xs = x
                     idn = self.buf(f"{p}:idn", (B, ho, wo, d2))
-                    hip.gemm(M_out, d2, cin, xs, cin, 1,
-                             self._scaled_kernel(f"{p}/downsample_0/kernel", f"{p}/downsample_1"), d2, 0, idn, d2,
-                             bias=self.bn_shift[f"{p}/downsample_1"])
+                    self._conv1x1_fwd(xs, M_out, cin, d2, f"{p}/downsample_0/kernel", f"{p}/downsample_1", idn, act=0)
                 else:
                     xs, idn = None, x
                 out = self.buf(f"{p}:out", (B, ho, wo, d2))
-                hip.gemm(M_out, d2, d1, y2, d1, 1, self._scaled_kernel(f"{p}/conv3/kernel", f"{p}/bn3"), d2, 0, out, d2,
-                         bias=self.bn_shift[f"{p}/bn3"], residual=idn, ldr=d2, act=1)
+                self._conv1x1_fwd(y2, M_out, d1, d2, f"{p}/conv3/kernel", f"{p}/bn3", out, residual=idn)
                 self._block_meta.append(dict(p=p, x=x, xs=xs, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, cin=cin,
                                              d1=d1, d2=d2, stride=stride, first=(b == 0)))
                 x, h, w, cin = out, ho, wo, d2

@@ -161,6 +161,9 @@ int detr_hip_relu_mask_f32(const float *g, const float *ref, float *out, int64_t
 /* w_out[k, co] = w[k, co] * scale[co]   (frozen-BN scale folded into conv kernels, HWIO flat) */
 int detr_hip_scale_cols_f32(const float *w, const float *scale, float *w_out, int64_t rows, int32_t cols,
                             void *stream);
+/* w_out_t[co, k] = w[k, co] * scale[co] (scale may be NULL): transposed copy, i.e. a K-contiguous GEMM B operand */
+int detr_hip_scale_cols_t_f32(const float *w, const float *scale, float *w_out_t, int32_t rows, int32_t cols,
+                              void *stream);
 /* frozen BN vectors -> (scale, shift)  custom_layers.py:21-23 */
 int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *mean, const float *var,
                          float *scale, float *shift, int32_t C, float eps, void *stream);

@@ -83,6 +83,21 @@ def conv_case(N, H, W, Ci, Co, stride, mode, tiles=(0, 1, 2, 3)):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fwd", "wgrad", "attn", "conv"]
+    if "bf16" in which:       # bf16-compute kernels: tiles 1 (=128x128) and 3 (=64x64) exist
+        hip.COMPUTE_BF16 = 1
+        which = [w for w in which if w != "bf16"] or ["fwd", "wgrad", "conv"]
+        for (M, N, K, ak, bk, res) in [(33600, 256, 1024, 1, 0, False), (33600, 1024, 256, 1, 0, True), (33600, 256, 1024, 1, 1, False),
+                                       (133600, 512, 128, 1, 0, True), (133600, 128, 512, 1, 0, False), (534400, 256, 64, 1, 0, True),
+                                       (534400, 64, 256, 1, 0, False), (8400, 256, 256, 1, 1, False), (8400, 2048, 256, 1, 1, False),
+                                       (8400, 256, 2048, 1, 1, True), (800, 256, 2048, 1, 1, True)]:
+            gemm_case(M, N, K, ak, bk, res=res, tiles=(1, 3))
+        for (M, N, K, sks) in [(256, 256, 8400, (8, 16, 32, 64)), (256, 1024, 33600, (8, 16, 32)), (64, 256, 534400, (64, 128, 256)),
+                               (128, 512, 133600, (32, 64, 128)), (147, 64, 2134400, (128, 341, 682)), (2048, 256, 8400, (4, 8, 16))]:
+            gemm_case(M, N, K, 0, 0, splits=sks, tiles=(1, 3))
+        for mode in (0, 1):
+            for shp in [(8, 50, 84, 256, 256, 1), (8, 25, 42, 512, 512, 1), (8, 100, 167, 128, 128, 1), (8, 200, 334, 64, 64, 1)]:
+                conv_case(*shp, mode, tiles=(1, 3))
+        sys.exit(0)
     if "fwd" in which:
         gemm_case(33600, 256, 1024, 1, 0)
         gemm_case(33600, 1024, 256, 1, 0, res=True)
