@@ -128,7 +128,7 @@ def main():
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
     model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=args.precision)
     opt = setup_optimizers(model, cfg)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
         dist.broadcast(model.engine.P.flat, src=0)
         for raw in model.engine.P.bn_raw.values():

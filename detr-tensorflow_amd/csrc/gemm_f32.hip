@@ -321,7 +321,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
         // measured (profiles/tune_bf16_r1.txt): 128x128 wins for long-K / split-K problems with N >= 128, 64x64 (7 waves
         // per SIMD) for short K (<= 256), thin outputs and small grids, where latency hiding matters more than reuse
-        const bool small = (split > 1) ? (d->N < 128) : (d->N <= 64 || d->M <= 64 || d->K <= 256 || t128 < 512);
+        const bool small = (split > 1) ? (d->N < 128 || (long long)d->M * d->N <= 65536) : (d->N <= 64 || d->M <= 64 || d->K <= 256 || t128 < 512);
         if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);

@@ -111,6 +111,28 @@ __global__ __launch_bounds__(256) void match_cost_kernel(SetLossArgs a, float *_
 // K13: rectangular LSAP, one wave per problem.  Rows of the (transposed) problem = targets,
 // columns = predictions; column j lives on lane j&63, slot j>>6.
 // ------------------------------------------------------------------------------------------------
+// min over the 64 lanes of a double, returned wave-uniform.  Row-shift DPP scan inside each row of
+// 16 lanes, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63 (the gfx9 wave64
+// reduction idiom); ~20 VALU ops instead of 12 dependent ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_min_step(double x) {
+    const double inf = (double)INFINITY;
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(inf), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(inf), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return fmin(x, __hiloint2double(hi, lo));
+}
+__device__ __forceinline__ double wave_min_f64_dpp(double x) {
+    x = dpp_min_step<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_min_step<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_min_step<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_min_step<0x118, 0xf>(x);   // row_shr:8
+    x = dpp_min_step<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x = dpp_min_step<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
 template <int MAXCPL>
 __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ cost, int Q, int ldc,
                                                     const float *__restrict__ t_bbox, int B, int R,
@@ -190,24 +212,20 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64);
-                const int oj = __shfl_xor(bestj, o, 64);
-                const int of = __shfl_xor(bestfree, o, 64);
-                if (ob < best || (ob == best && (of > bestfree || (of == bestfree && oj < bestj)))) {
-                    best = ob;
-                    bestj = oj;
-                    bestfree = of;
-                }
-            }
-            minVal = best;
+            // wave argmin: DPP min of the value, then a ballot picks the owner lane (free columns
+            // first, as SciPy's tie rule prefers a column that ends the search)
+            const double gmin = wave_min_f64_dpp(best);
+            minVal = gmin;
             if (!(minVal < (double)INFINITY)) {
                 infeasible = true;
                 break;
             }
-            const int jstar = bestj;
-            const int ownl = jstar & 63, owns = jstar >> 6;
+            const bool cand = (best == gmin);
+            const unsigned long long mfree = __ballot(cand && bestfree);
+            const unsigned long long mall = __ballot(cand);
+            const int ownl = __ffsll((long long)(mfree ? mfree : mall)) - 1;
+            const int jstar = __builtin_amdgcn_readlane(bestj, ownl);
+            const int owns = jstar >> 6;
             int r4 = -1;
 #pragma unroll
             for (int s = 0; s < MAXCPL; ++s) {
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
                     r4 = row4col[s];
                 }
             }
-            r4 = __shfl(r4, ownl, 64);
+            r4 = __builtin_amdgcn_readlane(r4, ownl);
             if (r4 == -1) {
                 sink = jstar;
                 break;
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
 #pragma unroll
             for (int s = 0; s < MAXCPL; ++s)
                 if (s == owns) pi = path[s];
-            pi = __shfl(pi, ownl, 64);
+            pi = __builtin_amdgcn_readlane(pi, __builtin_amdgcn_readfirstlane(ownl));
 #pragma unroll
             for (int s = 0; s < MAXCPL; ++s)
                 if (s == owns && lane == ownl) row4col[s] = pi;

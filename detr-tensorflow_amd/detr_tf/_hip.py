@@ -221,15 +221,17 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
 
 
 def pick_split_k(M, N, K, max_split=1024):
-    """Reduction-heavy GEMMs (weight gradients): split K so that ~1000 workgroups exist."""
-    if COMPUTE_BF16 and N >= 128:               # bf16 split-K runs 128x128 tiles, ~512 workgroups measured best
+    """Reduction-heavy GEMMs (weight gradients): split K so that enough workgroups exist to fill 256 CUs."""
+    if COMPUTE_BF16 and N >= 128 and M * N > 65536:   # bf16 split-K runs 128x128 tiles, ~512 workgroups measured best
         tiles = -(-M // 128) * -(-N // 128)
         ktiles = -(-K // 32)
         return int(max(1, min(max(1, 512 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
-    tiles = -(-M // 64) * -(-N // 64)           # the kernel uses 64x64 tiles
-    want = max(1, 1024 // max(tiles, 1))        # ~1024 workgroups measured best (512..2048 within 5 %)
-    ktiles = -(-K // 16)
-    return int(max(1, min(want, max_split, ktiles // 8 if ktiles >= 16 else 1)))
+    # 64x64 tiles (fp32 always; bf16 for small outputs, see gemm_f32.hip): ~1024 workgroups measured best
+    tiles = -(-M // 64) * -(-N // 64)
+    want = max(1, 1024 // max(tiles, 1))
+    ktiles = -(-K // (32 if COMPUTE_BF16 else 16))
+    cap = ktiles // 8 if ktiles >= 64 else ktiles // 4      # short reductions: 4 k-tiles per split are enough
+    return int(max(1, min(want, max_split, cap)))
 
 
 def linear_fwd(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0):

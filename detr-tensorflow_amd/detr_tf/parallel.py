@@ -20,8 +20,11 @@ def init_distributed(backend=None):
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    force = os.environ.get("DETR_DP_FORCE") == "1"     # single-rank group: exercises the RCCL path on a 1-GPU box
+    if world <= 1 and not force:
         return 0, 1
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -45,18 +48,19 @@ class DataParallel:
         self.bounds = list(bucket_bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DETR_DP_FORCE") == "1")
         self.works = []
         self.cuda = grad_flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
 
     def reduce_sums(self, sums):
         """All-reduce of the loss normalisers (tiny, on the compute stream)."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
 
     def on_bucket(self, i):
         """Called by the engine when gradient bucket i is final: launch its all-reduce."""
-        if self.world <= 1:
+        if not self.active:
             return
         lo, hi = self.bounds[i]
         if hi <= lo:
