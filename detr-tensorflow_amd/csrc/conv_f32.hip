@@ -28,11 +28,13 @@ struct ConvArgs {
 template <int BM, bool DGRAD>
 struct LoaderConvA {
     static constexpr int NV = BM / 64;
+    BufSrc src;
     int n_[NV], h_[NV], w_[NV];
     bool ok[NV];
     int kq, tid;
 
     __device__ __forceinline__ void init(const ConvArgs &a, int m0, int tid_) {
+        src.init(a.src, (long long)a.N * a.Hs * a.Ws * a.Cs);
         tid = tid_;
         kq = (tid & 3) * 4;
 #pragma unroll
@@ -44,15 +46,11 @@ struct LoaderConvA {
             const int t = mm / a.Wd;
             const int hd = t % a.Hd;
             n_[i] = t / a.Hd;
-            if (DGRAD) {
-                h_[i] = hd + a.pad;
-                w_[i] = wd + a.pad;
-            } else {
-                h_[i] = hd * a.stride - a.pad;
-                w_[i] = wd * a.stride - a.pad;
-            }
+            h_[i] = DGRAD ? hd + a.pad : hd * a.stride - a.pad;
+            w_[i] = DGRAD ? wd + a.pad : wd * a.stride - a.pad;
         }
     }
+    // halo / stride-parity / tile-edge lanes take the out-of-range offset: the descriptor returns zeros, no branch
     __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * GEMM_BK + kq;
@@ -78,12 +76,8 @@ struct LoaderConvA {
                 ws = w_[i] + kw;
                 v = v && hs >= 0 && ws >= 0 && hs < a.Hs && ws < a.Ws;
             }
-            if (v) {
-                const long long off = (((long long)n_[i] * a.Hs + hs) * a.Ws + ws) * a.Cs + c0;
-                r[i] = *reinterpret_cast<const float4 *>(a.src + off);
-            } else {
-                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const unsigned off = ((unsigned)((n_[i] * a.Hs + hs) * a.Ws + ws) * (unsigned)a.Cs + (unsigned)c0) * 4u;
+            r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
     template <int LD>
@@ -120,7 +114,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     //                    dgrad B[k=co][n=ci] = w[tap][ci][co]  (k contiguous, ld = Co, K = Co)
     using LB = typename std::conditional<DGRAD, LoaderK<BN>, LoaderMN<BN>>::type;
     LB lb;
-    lb.init(a.w, a.Co, n0, a.Cd, true, tid);
+    lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);   // one descriptor over the 9 taps
 
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -133,8 +127,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     float4 ra[LoaderConvA<BM, DGRAD>::NV], rb[LB::NV];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
-        lb.ptr = a.w + tap * tapstride;
-        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb);
+        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb, (unsigned)(tap * tapstride * 4));
     };
     la.load(a, 0, cpt, ra);
     load_b(0);
@@ -179,11 +172,13 @@ struct LoaderWgradA {
     static constexpr int VPR = BM / 4;
     static constexpr int TOTAL = GEMM_BK * VPR;
     static constexpr int NV = (TOTAL >= GEMM_THREADS) ? TOTAL / GEMM_THREADS : 1;
+    BufSrc src;
     int n_[NV], h_[NV], w_[NV];  // output-pixel coordinates of this entry's current reduction row
     int m_[NV];
     int tid, ci0, kh, kw;
 
     __device__ __forceinline__ void init(const ConvWgradArgs &a, int ci0_, int tap, int m_begin, int tid_) {
+        src.init(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci);
         tid = tid_;
         ci0 = ci0_;
         kh = tap / 3;
@@ -210,12 +205,8 @@ struct LoaderWgradA {
             const int ws = w_[i] * a.stride - a.pad + kw;
             const bool v = (idx < TOTAL) && (m_[i] < m_end) && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi &&
                            (ci0 + c4 < a.Ci);
-            if (v) {
-                const long long off = (((long long)n_[i] * a.Hi + hs) * a.Wi + ws) * a.Ci + ci0 + c4;
-                r[i] = *reinterpret_cast<const float4 *>(a.x + off);
-            } else {
-                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const unsigned off = ((unsigned)((n_[i] * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)(ci0 + c4)) * 4u;
+            r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
     __device__ __forceinline__ void advance(const ConvWgradArgs &a) {
@@ -265,7 +256,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
     LoaderWgradA<BM> la;
     la.init(a, ci0, tap, m_begin, tid);
     LoaderMN<BN> lb;
-    lb.init(a.dy, a.Co, co0, a.Co, true, tid);
+    lb.init(a.dy, a.Co, co0, a.Co, a.M, true, tid);
 
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -307,11 +298,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
 template <int BM, bool DGRAD>
 struct LoaderConvAb {
     static constexpr int NV = BM / 32;
+    BufSrc src;
     int n_[NV], h_[NV], w_[NV];
     bool ok[NV];
     int kq, tid;
 
     __device__ __forceinline__ void init(const ConvArgs &a, int m0, int tid_) {
+        src.init(a.src, (long long)a.N * a.Hs * a.Ws * a.Cs);
         tid = tid_;
         kq = (tid & 7) * 4;
 #pragma unroll
@@ -327,6 +320,7 @@ struct LoaderConvAb {
             w_[i] = DGRAD ? wd + a.pad : wd * a.stride - a.pad;
         }
     }
+    // halo / stride-parity / tile-edge lanes take the out-of-range offset: the descriptor returns zeros, no branch
     __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BF_BK + kq;
@@ -352,8 +346,8 @@ struct LoaderConvAb {
                 ws = w_[i] + kw;
                 v = v && hs >= 0 && ws >= 0 && hs < a.Hs && ws < a.Ws;
             }
-            if (v) r[i] = *reinterpret_cast<const float4 *>(a.src + (((long long)n_[i] * a.Hs + hs) * a.Ws + ws) * a.Cs + c0);
-            else r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = ((unsigned)((n_[i] * a.Hs + hs) * a.Ws + ws) * (unsigned)a.Cs + (unsigned)c0) * 4u;
+            r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
     __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NV]) const {
@@ -383,7 +377,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     using LB = typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNb<BN>>::type;
     constexpr int NRB = DGRAD ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
     LB lb;
-    lb.init(a.w, a.Co, n0, a.Cd, true, tid);
+    lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);   // one descriptor over the 9 taps
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
@@ -394,8 +388,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     float4 ra[LoaderConvAb<BM, DGRAD>::NV], rb[NRB];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
-        lb.ptr = a.w + tap * tapstride;
-        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb);
+        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)(tap * tapstride * 4));
     };
     la.load(a, 0, cpt, ra);
     load_b(0);
@@ -424,10 +417,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
 template <int BM>
 struct LoaderWgradAb {
     static constexpr int NU = BM / 64;
+    BufSrc src;
     int n_[NU], h_[NU], w_[NU], m_[NU];
     int tid, ci0, kh, kw;
 
     __device__ __forceinline__ void init(const ConvWgradArgs &a, int ci0_, int tap, int m_begin, int tid_) {
+        src.init(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci);
         tid = tid_; ci0 = ci0_;
         kh = tap / 3; kw = tap - kh * 3;
 #pragma unroll
@@ -443,9 +438,9 @@ struct LoaderWgradAb {
     }
     __device__ __forceinline__ float4 fetch(const ConvWgradArgs &a, int n, int h, int w, int m, int m_end, int c) const {
         const int hs = h * a.stride - a.pad + kh, ws = w * a.stride - a.pad + kw;
-        if (m < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci)
-            return *reinterpret_cast<const float4 *>(a.x + (((long long)n * a.Hi + hs) * a.Wi + ws) * a.Ci + c);
-        return make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool v = m < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci;
+        const unsigned off = ((unsigned)((n * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)c) * 4u;
+        return src.ld4(v ? off : BUF_OOB);
     }
     __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[2 * NU]) const {
 #pragma unroll
@@ -498,7 +493,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvW
     LoaderWgradAb<BM> la;
     la.init(a, ci0, tap, m_begin, tid);
     LoaderMNb<BN> lb;
-    lb.init(a.dy, a.Co, co0, a.Co, true, tid);
+    lb.init(a.dy, a.Co, co0, a.Co, a.M, true, tid);
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
@@ -735,6 +730,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
                  d->pad, d->stride);
     DETR_REQUIRE(d->x && d->w && d->y, "conv3x3: null operand");
     DETR_REQUIRE(aligned16(d->x) && aligned16(d->w) && aligned16(d->y), "conv3x3: operands must be 16-byte aligned");
+    DETR_REQUIRE((long long)d->N * d->Hi * d->Wi * d->Ci * 4 <= BUF_MAX_BYTES &&
+                     (long long)d->N * d->Ho * d->Wo * d->Co * 4 <= BUF_MAX_BYTES,
+                 "conv3x3: a tensor spans more than 4 GB (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
     EpiArgs e;
     e.alpha = d->alpha;

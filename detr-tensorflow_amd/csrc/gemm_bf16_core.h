@@ -47,27 +47,33 @@ struct BfSmemBytes {
 template <int BMN>
 struct LoaderKb {
     static constexpr int NV = BMN / 32;
-    const float *ptr;
-    long long off[NV];
-    bool ok[NV];
+    BufSrc src;
+    unsigned off[NV];      // byte offset of the row, BUF_OOB for rows outside the operand
     bool vec;
     int kq, tid;
 
-    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, bool vec_, int tid_) {
-        ptr = p; vec = vec_; tid = tid_;
+    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, int K, bool vec_, int tid_,
+                                         long long extent_elems = 0) {
+        src.init(p, extent_elems > 0 ? extent_elems : (long long)(MN - 1) * ld + K);
+        vec = vec_; tid = tid_;
         kq = (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int g = mn0 + (tid >> 3) + 32 * i;
-            ok[i] = g < MN;
-            off[i] = (long long)g * ld;
+            off[i] = g < MN ? (unsigned)((long long)g * ld * 4) : BUF_OOB;
         }
     }
-    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV], unsigned base = 0) const {
         const int k = k0 + kq;
+        if (vec) {       // wave-uniform: one scalar branch per tile load, none per float4
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            r[i] = ok[i] ? ld4_guard(ptr + off[i] + k, K - k, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NV; ++i)
+                r[i] = src.ld4_vec(off[i] + base + 4u * (unsigned)k, off[i] != BUF_OOB ? K - k : 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                r[i] = src.ld4_scalar(off[i] + base + 4u * (unsigned)k, off[i] != BUF_OOB ? K - k : 0);
+        }
     }
     __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NV]) const {
 #pragma unroll
@@ -82,16 +88,20 @@ struct LoaderKb {
 template <int BMN>
 struct LoaderMNb {
     static constexpr int NU = BMN / 64;
-    const float *ptr;
-    long long ld;
+    BufSrc src;
+    unsigned ld4b;         // row stride in bytes
     int mn0, MN;
     bool vec;
     int tid;
 
-    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, bool vec_, int tid_) {
-        ptr = p; ld = ld_; mn0 = mn0_; MN = MN_; vec = vec_; tid = tid_;
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, int K, bool vec_, int tid_,
+                                         long long extent_elems = 0) {
+        src.init(p, extent_elems > 0 ? extent_elems : (long long)(K - 1) * ld_ + MN_);
+        ld4b = (unsigned)(ld_ * 4); mn0 = mn0_; MN = MN_; vec = vec_; tid = tid_;
     }
-    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[2 * NU]) const {
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[2 * NU], unsigned base = 0) const {
+        unsigned o[2 * NU];
+        int nv[2 * NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + 256 * i;
@@ -99,9 +109,16 @@ struct LoaderMNb {
             const int col = mn0 + (u >> 4) * 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (k + h < K && col < MN) r[2 * i + h] = ld4_guard(ptr + (long long)(k + h) * ld + col, MN - col, vec);
-                else r[2 * i + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                o[2 * i + h] = base + (unsigned)(k + h) * ld4b + 4u * (unsigned)col;
+                nv[2 * i + h] = k + h < K ? MN - col : 0;
             }
+        }
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < 2 * NU; ++j) r[j] = src.ld4_vec(o[j], nv[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * NU; ++j) r[j] = src.ld4_scalar(o[j], nv[j]);
         }
     }
     __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[2 * NU]) const {

@@ -68,19 +68,42 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-__device__ __forceinline__ float4 ld4_guard(const float *p, int nvalid, bool vec) {
-    // nvalid = number of in-range elements starting at p (may be <= 0)
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid >= 4 && vec) {
-        v = *reinterpret_cast<const float4 *>(p);
-    } else {
-        if (nvalid > 0) v.x = p[0];
-        if (nvalid > 1) v.y = p[1];
-        if (nvalid > 2) v.z = p[2];
-        if (nvalid > 3) v.w = p[3];
+// ---------------------------------------------------------------------------------------------
+// Operand access through a buffer descriptor (SRSRC): out-of-range lanes get the offset BUF_OOB, which
+// the hardware bounds check turns into a zero result.  A guarded tile load is therefore one
+// v_cndmask + buffer_load_dwordx4, with no exec-mask branch per load (the plain `if (ok) v = *p`
+// form compiled to a saveexec/branch tree per float4 and a vmcnt(0) between the A and B loads).
+// The descriptor base is wave-uniform (kernel argument + blockIdx-derived offsets); operands are
+// < 4 GB (checked by the host dispatch) so byte offsets fit the 32-bit voffset.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+constexpr long long BUF_MAX_BYTES = 0xFFFFFFF0ll;
+
+struct BufSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void init(const float *base, long long elems) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(unsigned)(elems * 4), 0x00020000);
     }
-    return v;
-}
+    __device__ __forceinline__ float4 ld4(unsigned voff) const {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+    __device__ __forceinline__ float ld1(unsigned voff) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+    }
+    // four consecutive floats at byte offset voff, of which the first nvalid (may be <= 0 or > 4) exist
+    __device__ __forceinline__ float4 ld4_vec(unsigned voff, int nvalid) const {
+        return ld4(nvalid >= 4 ? voff : BUF_OOB);                // vec mode: extents are multiples of 4 (host check)
+    }
+    __device__ __forceinline__ float4 ld4_scalar(unsigned voff, int nvalid) const {
+        float4 v;
+        v.x = ld1(nvalid > 0 ? voff : BUF_OOB);
+        v.y = ld1(nvalid > 1 ? voff + 4u : BUF_OOB);
+        v.z = ld1(nvalid > 2 ? voff + 8u : BUF_OOB);
+        v.w = ld1(nvalid > 3 ? voff + 12u : BUF_OOB);
+        return v;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Loader for an operand stored [mn][k] with k contiguous (row stride ld).
@@ -89,15 +112,16 @@ __device__ __forceinline__ float4 ld4_guard(const float *p, int nvalid, bool vec
 template <int BMN>
 struct LoaderK {
     static constexpr int NV = (BMN >= 64) ? BMN / 64 : 1;
-    const float *ptr;
-    long long off[NV];
-    bool ok[NV];
+    BufSrc src;
+    unsigned off[NV];      // byte offset of the row, BUF_OOB for rows outside the operand
     bool vec;
     int kq;
     int tid;
 
-    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, bool vec_, int tid_) {
-        ptr = p;
+    // extent_elems > 0 overrides the descriptor size (conv: one descriptor over all 9 taps)
+    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, int K, bool vec_, int tid_,
+                                         long long extent_elems = 0) {
+        src.init(p, extent_elems > 0 ? extent_elems : (long long)(MN - 1) * ld + K);
         vec = vec_;
         tid = tid_;
         kq = (tid & 3) * 4;
@@ -105,15 +129,19 @@ struct LoaderK {
         for (int i = 0; i < NV; ++i) {
             const int row = (tid >> 2) + 64 * i;
             const int g = mn0 + row;
-            ok[i] = (row < BMN) && (g < MN);
-            off[i] = (long long)g * ld;
+            off[i] = ((row < BMN) && (g < MN)) ? (unsigned)((long long)g * ld * 4) : BUF_OOB;
         }
     }
-    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV], unsigned base = 0) const {
         const int k = k0 + kq;
+        if (vec) {       // wave-uniform: one scalar branch per tile load, none per float4
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            r[i] = ok[i] ? ld4_guard(ptr + off[i] + k, K - k, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NV; ++i)
+                r[i] = src.ld4_vec(off[i] + base + 4u * (unsigned)k, off[i] != BUF_OOB ? K - k : 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                r[i] = src.ld4_scalar(off[i] + base + 4u * (unsigned)k, off[i] != BUF_OOB ? K - k : 0);
         }
     }
     template <int LD>
@@ -140,21 +168,24 @@ struct LoaderMN {
     static constexpr int VPR = BMN / 4;
     static constexpr int TOTAL = GEMM_BK * VPR;
     static constexpr int NV = (TOTAL >= GEMM_THREADS) ? TOTAL / GEMM_THREADS : 1;
-    const float *ptr;
-    long long ld;
+    BufSrc src;
+    unsigned ld4b;         // row stride in bytes
     int mn0, MN;
     bool vec;
     int tid;
 
-    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, bool vec_, int tid_) {
-        ptr = p;
-        ld = ld_;
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, int K, bool vec_, int tid_,
+                                         long long extent_elems = 0) {
+        src.init(p, extent_elems > 0 ? extent_elems : (long long)(K - 1) * ld_ + MN_);
+        ld4b = (unsigned)(ld_ * 4);
         mn0 = mn0_;
         MN = MN_;
         vec = vec_;
         tid = tid_;
     }
-    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV]) const {
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NV], unsigned base = 0) const {
+        unsigned o[NV];
+        int nv[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + GEMM_THREADS * i;
@@ -162,11 +193,15 @@ struct LoaderMN {
             const int c4 = (idx % VPR) * 4;
             const int k = k0 + kr;
             const int col = mn0 + c4;
-            if (idx < TOTAL && k < K && col < MN) {
-                r[i] = ld4_guard(ptr + (long long)k * ld + col, MN - col, vec);
-            } else {
-                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            o[i] = base + (unsigned)k * ld4b + 4u * (unsigned)col;
+            nv[i] = (idx < TOTAL && k < K) ? MN - col : 0;
+        }
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r[i] = src.ld4_vec(o[i], nv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r[i] = src.ld4_scalar(o[i], nv[i]);
         }
     }
     template <int LD>

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     using LB = typename std::conditional<BKC, LoaderK<BN>, LoaderMN<BN>>::type;
     LA la;
     LB lb;
-    la.init(A, g.lda, m0, g.M, g.a_vec != 0, tid);
-    lb.init(B, g.ldb, n0, g.N, g.b_vec != 0, tid);
+    la.init(A, g.lda, m0, g.M, g.K, g.a_vec != 0, tid);
+    lb.init(B, g.ldb, n0, g.N, g.K, g.b_vec != 0, tid);
 
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
     constexpr int NRB = BKC ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
     LA la;
     LB lb;
-    la.init(A, g.lda, m0, g.M, g.a_vec != 0, tid);
-    lb.init(B, g.ldb, n0, g.N, g.b_vec != 0, tid);
+    la.init(A, g.lda, m0, g.M, g.K, g.a_vec != 0, tid);
+    lb.init(B, g.ldb, n0, g.N, g.K, g.b_vec != 0, tid);
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
@@ -264,6 +264,11 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0,
                      "gemm: split_k allows only scale/alpha in the epilogue");
     }
+    {   // operands are addressed through 32-bit buffer offsets (gemm_core.h BufSrc)
+        const long long ea = d->a_kcontig ? (long long)(d->M - 1) * d->lda + d->K : (long long)(d->K - 1) * d->lda + d->M;
+        const long long eb = d->b_kcontig ? (long long)(d->N - 1) * d->ldb + d->K : (long long)(d->K - 1) * d->ldb + d->N;
+        DETR_REQUIRE(ea * 4 <= BUF_MAX_BYTES && eb * 4 <= BUF_MAX_BYTES, "gemm: an operand spans more than 4 GB");
+    }
     DETR_REQUIRE((long long)batch * split <= 65535, "gemm: batch*split_k=%lld exceeds grid.z", (long long)batch * split);
 
     GemmArgs g;
@@ -277,8 +282,10 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     g.part_stride = 0;
     g.tiles_m = g.tiles_n = 0;
     auto strides_ok = [](long long ld, long long s0, long long s1) { return (ld % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0); };
-    g.a_vec = aligned16(d->A) && strides_ok(d->lda, d->sA0, d->sA1);
-    g.b_vec = aligned16(d->B) && strides_ok(d->ldb, d->sB0, d->sB1);
+    // vec: float4 tile loads; the extent along the contiguous axis must be a multiple of 4 so that a float4 is
+    // entirely inside or outside the operand (branch-free guarded loads, gemm_core.h ld4_sel)
+    g.a_vec = aligned16(d->A) && strides_ok(d->lda, d->sA0, d->sA1) && ((d->a_kcontig ? d->K : d->M) % 4 == 0);
+    g.b_vec = aligned16(d->B) && strides_ok(d->ldb, d->sB0, d->sB1) && ((d->b_kcontig ? d->K : d->N) % 4 == 0);
     g.e.alpha = d->alpha;
     g.e.scale = d->scale;
     g.e.bias = d->bias;
@@ -321,7 +328,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
         // measured (profiles/tune_bf16_r1.txt): 128x128 wins for long-K / split-K problems with N >= 128, 64x64 (7 waves
         // per SIMD) for short K (<= 256), thin outputs and small grids, where latency hiding matters more than reuse
-        const bool small = (split > 1) ? (d->N < 128 || (long long)d->M * d->N <= 65536) : (d->N <= 64 || d->M <= 64 || d->K <= 256 || t128 < 512);
+        const bool small = (split > 1) ? (d->N < 128 || ((long long)d->M * d->N <= 65536 && d->K < 16384)) : (d->N <= 64 || d->M <= 64 || d->K <= 256 || t128 < 512);
         if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
