@@ -787,7 +787,8 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
     if (d->compute == 1 && a.Cs % 32 == 0 && a.Cd % 32 == 0) {
-        if (force == 3 || (force == 0 && (a.Cd <= 64 || big < 128))) launch_conv_bf16<64, 64, 2, 2>(a, dgrad, s);
+        if (force == 3 || (force == 0 && (a.Cd <= 64 || big < 128 || (dgrad && (a.Cd <= 128 || big < 512)))))
+            launch_conv_bf16<64, 64, 2, 2>(a, dgrad, s);
         else launch_conv_bf16<128, 128, 2, 2>(a, dgrad, s);
     } else if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);
     else if (force == 2) launch_conv<128, 64, 2, 2>(a, dgrad, s);

@@ -324,11 +324,11 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
     const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
     if (bf16c) {
-        // bf16 MFMA is 16x faster per flop: larger tiles are needed to amortise loads / barriers
-        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
-        // measured (profiles/tune_bf16_r1.txt): 128x128 wins for long-K / split-K problems with N >= 128, 64x64 (7 waves
-        // per SIMD) for short K (<= 256), thin outputs and small grids, where latency hiding matters more than reuse
-        const bool small = (split > 1) ? (d->N < 128 || ((long long)d->M * d->N <= 65536 && d->K < 16384)) : (d->N <= 64 || d->M <= 64 || d->K <= 256 || t128 < 512);
+        // measured with the buffer-descriptor loaders (profiles/tune_bf16_r1b.txt): the 64x64 tile (8 waves/SIMD)
+        // wins every non-split shape of the step; 128x128 (2 waves/SIMD, 4x the operand reuse) only pays for split-K
+        // weight gradients with a >= 128x128 output and enough work per tile
+        const bool small = (split > 1) ? !(d->M >= 128 && d->N >= 128 && ((long long)d->M * d->N > 65536 || d->K >= 16384))
+                                       : true;
         if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);

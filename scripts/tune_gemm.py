@@ -91,7 +91,7 @@ if __name__ == "__main__":
                                        (534400, 64, 256, 1, 0, False), (8400, 256, 256, 1, 1, False), (8400, 2048, 256, 1, 1, False),
                                        (8400, 256, 2048, 1, 1, True), (800, 256, 2048, 1, 1, True)]:
             gemm_case(M, N, K, ak, bk, res=res, tiles=(1, 3))
-        for (M, N, K, sks) in [(256, 256, 8400, (8, 16, 32, 64)), (256, 1024, 33600, (8, 16, 32)), (64, 256, 534400, (64, 128, 256)),
+        for (M, N, K, sks) in [(256, 256, 800, (1, 3, 6, 12)), (256, 256, 8400, (8, 16, 32, 64)), (256, 1024, 33600, (8, 16, 32)), (64, 256, 534400, (64, 128, 256)),
                                (128, 512, 133600, (32, 64, 128)), (147, 64, 2134400, (128, 341, 682)), (2048, 256, 8400, (4, 8, 16))]:
             gemm_case(M, N, K, 0, 0, splits=sks, tiles=(1, 3))
         for mode in (0, 1):
