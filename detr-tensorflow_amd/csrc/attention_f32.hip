@@ -12,6 +12,10 @@
 //     O^T[d][query]  += V^T (A: V[key][d] read row-wise from LDS) x P^T (B: the registers above;
 //   MFMA k-step r contracts the key pair {kr(hi=0), kr(hi=1)} which is exactly what the two lane
 //   halves hold in register r -- no data movement between QK^T and PV).
+// Softmax arithmetic: Q (or, in the dK/dV kernel, K) is pre-multiplied by log2(e) in registers so that every
+// exponential is one v_exp_f32 (exp2); LSE is stored in natural-log units.  The key-bound masks run only in the
+// last key tile (wave-uniform branch), and the dropout hash is evaluated once per PAIR of adjacent keys
+// (common.h drop_hash: 16 bits per element; element index = row * Sp + key, Sp = S rounded up to even).
 // K/V tiles: 32 keys x 32 dims row-major with row stride 33 dwords: conflict-free for both access
 // patterns (lanes over keys at fixed d, and lanes over d at fixed key).  Double-buffered
 // global->register->LDS pipeline, one barrier per key tile; 4 waves x 32 queries per workgroup.
@@ -39,6 +43,23 @@ struct AttnArgs {
 };
 
 __device__ __forceinline__ int krow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+constexpr float AT_LOG2E = 1.4426950408889634f;
+constexpr float AT_LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
+
+// keep flags of the 16 scores a lane holds (keys kbase + krow(r, hi), r = 0..15): adjacent keys (r, r+1), r even,
+// share one hash.  rowbase = row * Sp (even), bit r of the result = keep.
+__device__ __forceinline__ uint32_t keep_bits16(uint32_t seed, unsigned long long rowbase, int kbase, int hi, uint32_t thresh16) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const uint32_t h = drop_hash(seed, (rowbase + (unsigned)(kbase + krow(r, hi))) >> 1);
+        bits |= ((h & 0xFFFFu) >= thresh16 ? 1u : 0u) << r;
+        bits |= ((h >> 16) >= thresh16 ? 1u : 0u) << (r + 1);
+    }
+    return bits;
+}
 
 // cooperative load of one 32 x 32 tile (rows row0.., zero filled past nrows) into registers / LDS
 __device__ __forceinline__ float4 tile_load(const float *base, long long ld, int row0, int nrows, int tid) {
@@ -69,12 +90,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     float q[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) q[s] = qok ? Qb[(long long)tq * a.ld + 2 * s + hi] : 0.0f;
+    for (int s = 0; s < 16; ++s) q[s] = qok ? Qb[(long long)tq * a.ld + 2 * s + hi] * AT_LOG2E : 0.0f;   // scores in log2 units
 
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
     float m = -INFINITY, lsum = 0.0f;
+    const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
     float4 rk = tile_load(Kb, a.ld, 0, a.S, tid), rv = tile_load(Vb, a.ld, 0, a.S, tid);
@@ -95,30 +117,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int st = 0; st < 16; ++st)
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][l31][2 * st + hi], q[st], s, 0, 0, 0);
         const int kbase = it * AT_KEYS;
-        float mx = -INFINITY;
+        if (kbase + AT_KEYS > a.S) {                // ragged last tile only (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (kbase + krow(r, hi) >= a.S) s[r] = -INFINITY;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r)
+                if (kbase + krow(r, hi) >= a.S) s[r] = -INFINITY;
         }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);              // finite: every tile holds at least one valid key
-        const float corr = expf(m - mn);            // exp(-inf) = 0 on the first tile
+        const float corr = fast_exp2(m - mn);       // exp2(-inf) = 0 on the first tile
         float rs = 0.0f;
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p[r] = expf(s[r] - mn);
+            p[r] = fast_exp2(s[r] - mn);
             rs += p[r];
         }
         rs += __shfl_xor(rs, 32, 64);
         lsum = lsum * corr + rs;
         m = mn;
         if (a.drop_scale != 0.0f) {          // dropout on the attention probabilities (after normalisation == on p)
-            const unsigned long long rowi = ((unsigned long long)bh * a.T + tq) * a.S + kbase;
+            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                p[r] = drop_keep(a.drop_seed, rowi + krow(r, hi), a.drop_thresh) ? p[r] * a.drop_scale : 0.0f;
+            for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         float *Ob = a.O + ((long long)b * a.T + tq) * a.ld + h * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
-        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m + logf(lsum);
+        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);   // natural-log units
     }
 }
 
@@ -160,14 +183,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     float dl = 0.0f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        q[s] = qok ? a.Q[qoff + 2 * s + hi] : 0.0f;
+        q[s] = qok ? a.Q[qoff + 2 * s + hi] * AT_LOG2E : 0.0f;      // scores in log2 units (q feeds only s)
         dout[s] = qok ? a.dO[qoff + 2 * s + hi] : 0.0f;
         const float ov = qok ? a.O[qoff + 2 * s + hi] : 0.0f;
         dl += dout[s] * ov;
     }
     dl += __shfl_xor(dl, 32, 64);
-    const float lse = qok ? a.LSE[(long long)bh * a.T + tq] : INFINITY;
+    const float lse = qok ? a.LSE[(long long)bh * a.T + tq] * AT_LOG2E : INFINITY;
     if (qok && hi == 0) a.delta[(long long)bh * a.T + tq] = dl;
+    const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     f32x16 dq;
 #pragma unroll
@@ -195,14 +219,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
         const int kbase = it * AT_KEYS;
         float ds[16];
+        if (a.drop_scale != 0.0f) {
+            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (kbase + krow(r, hi) < a.S) ? expf(s[r] - lse) : 0.0f;
-            float dpr = dp[r];
-            if (a.drop_scale != 0.0f)
-                dpr = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + tq) * a.S + kbase + krow(r, hi), a.drop_thresh)
-                          ? dpr * a.drop_scale : 0.0f;
-            ds[r] = p * (dpr - dl);
+            for (int r = 0; r < 16; ++r) dp[r] = ((keep >> r) & 1u) ? dp[r] * a.drop_scale : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] - lse) * (dp[r] - dl);
+        if (kbase + AT_KEYS > a.S) {                // ragged last tile only: keys past S contribute nothing
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + krow(r, hi) >= a.S) ds[r] = 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -238,11 +265,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const float *Db = a.dO + (long long)b * a.T * a.ld + h * 32;
     const float *lse = a.LSE + (long long)bh * a.T;
     const float *dlt = a.delta + (long long)bh * a.T;
+    const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
     float kk[16], vv[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        kk[s] = kok ? a.K[koff + 2 * s + hi] : 0.0f;
+        kk[s] = kok ? a.K[koff + 2 * s + hi] * AT_LOG2E : 0.0f;     // scores in log2 units (kk feeds only s)
         vv[s] = kok ? a.V[koff + 2 * s + hi] : 0.0f;
     }
     f32x16 dk, dv;
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     float4 rq = tile_load(Qb, a.ld, 0, a.T, tid), rd = tile_load(Db, a.ld, 0, a.T, tid);
     float rl = 0.f, rdl = 0.f;
     if (tid < AT_KEYS) {
-        rl = (tid < a.T) ? lse[tid] : INFINITY;      // +inf => p = exp(-inf) = 0 for padded queries
+        rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
         rdl = (tid < a.T) ? dlt[tid] : 0.0f;
     }
     tile_store(Qs[0], rq, tid);
@@ -268,7 +296,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             rq = tile_load(Qb, a.ld, t0, a.T, tid);
             rd = tile_load(Db, a.ld, t0, a.T, tid);
             if (tid < AT_KEYS) {
-                rl = (t0 + tid < a.T) ? lse[t0 + tid] : INFINITY;
+                rl = (t0 + tid < a.T) ? lse[t0 + tid] * AT_LOG2E : INFINITY;
                 rdl = (t0 + tid < a.T) ? dlt[t0 + tid] : 0.0f;
             }
         }
@@ -284,10 +312,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = krow(r, hi);
-            p[r] = expf(s[r] - Ls[cur][qr]);
+            p[r] = fast_exp2(s[r] - Ls[cur][qr]);
             float dpr = dp[r];
             if (a.drop_scale != 0.0f) {
-                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * a.S + sk, a.drop_thresh);
+                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * Sp + sk, a.drop_thresh);
                 dpr = keep ? dpr * a.drop_scale : 0.0f;
                 ds[r] = p[r] * (dpr - Dl[cur][qr]);
                 p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
@@ -334,7 +362,7 @@ using namespace detr;
 static int set_drop(AttnArgs &a, float p, uint32_t seed) {
     DETR_REQUIRE(p >= 0.0f && p < 1.0f, "attention: dropout p=%f out of range", p);
     a.drop_scale = p > 0.0f ? 1.0f / (1.0f - p) : 0.0f;
-    a.drop_thresh = drop_thresh24(p);
+    a.drop_thresh = drop_thresh16(p);
     a.drop_seed = seed;
     return 0;
 }

@@ -43,21 +43,25 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Counter-based dropout: element `idx` of dropout site `seed` is kept iff the top 24 bits of a 32-bit
-// integer hash are >= thresh24 = p * 2^24.  Forward and backward kernels regenerate the same mask from
+// integer hash are >= thresh16 = p * 2^16.  Forward and backward kernels regenerate the same mask from
 // (seed, idx); tests/oracle restate the same hash in numpy (Keras Dropout semantics: kept values are
 // scaled by 1/(1-p); the reference's TF RNG stream itself is not reproducible).
-__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, unsigned long long idx) {
-    uint32_t x = (uint32_t)idx ^ seed;
-    x ^= (uint32_t)(idx >> 32) * 0x9E3779B9u;
+// One 32-bit hash serves the element PAIR (idx & ~1, idx | 1): the low / high 16 bits are compared with
+// thresh16 = p * 2^16 (p = 0.1 -> 6553/65536).  Kernels whose lanes own adjacent elements (attention
+// probabilities, float4 epilogues) therefore evaluate one hash per two elements.
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, unsigned long long pair) {
+    uint32_t x = (uint32_t)pair ^ seed;
+    x ^= (uint32_t)(pair >> 32) * 0x9E3779B9u;
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, unsigned long long idx, uint32_t thresh24) {
-    return (drop_hash(seed, idx) >> 8) >= thresh24;
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, unsigned long long idx, uint32_t thresh16) {
+    const uint32_t h = drop_hash(seed, idx >> 1);
+    return ((idx & 1ull) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
 }
-static inline uint32_t drop_thresh24(float p) { return (uint32_t)(p * 16777216.0f); }
+static inline uint32_t drop_thresh16(float p) { return (uint32_t)(p * 65536.0f); }
 
 // wave64 reductions (all 64 lanes participate)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -297,7 +297,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     if (d->dropout_p > 0.0f) {
         DETR_REQUIRE(d->dropout_p < 1.0f && split == 1 && batch == 1, "gemm: dropout needs 0<p<1, no split-K, no batch");
         g.e.drop_scale = 1.0f / (1.0f - d->dropout_p);
-        g.e.drop_thresh = drop_thresh24(d->dropout_p);
+        g.e.drop_thresh = drop_thresh16(d->dropout_p);
         g.e.drop_seed = d->dropout_seed;
     }
     g.e.vec = aligned16(d->C) && (d->ldc % 4 == 0) && (d->sC0 % 4 == 0) && (d->sC1 % 4 == 0) &&

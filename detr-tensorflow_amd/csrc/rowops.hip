@@ -439,7 +439,7 @@ extern "C" int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *
 extern "C" int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t seed, void *stream) {
     DETR_REQUIRE(x && out && n > 0 && p >= 0.0f && p < 1.0f, "dropout: bad args");
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n,
-                       1.0f / (1.0f - p), drop_thresh24(p), seed);
+                       1.0f / (1.0f - p), drop_thresh16(p), seed);
     DETR_LAUNCH_CHECK("dropout");
     return 0;
 }

@@ -255,7 +255,7 @@ def multi_head_attention(query, key, value, P, p, num_heads=8, drop=None, seed=0
     WV = WV.reshape(S, B * num_heads, hd).transpose(0, 1)
     w = torch.softmax(WQ @ WK.transpose(1, 2), dim=-1)        # :317,340
     if drop is not None:
-        w = drop(seed + 0, w, "flat")                         # :341 dropout on the attention weights
+        w = drop(seed + 0, w, "attn")                         # :341 dropout on the attention weights
     o = (w @ WV).transpose(0, 1).reshape(T, B, D)             # :343-345
     out = o @ P[f"{p}/out_proj_kernel"].t() + P[f"{p}/out_proj_bias"]   # :346-347
     if drop is not None:

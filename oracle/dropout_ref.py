@@ -3,8 +3,8 @@
 The reference uses Keras Dropout(0.1) in training mode (transformer.py:149,196,248: on the attention
 probabilities :341, after every attention block and inside the FFN :169-176,216-232).  TensorFlow's RNG
 stream cannot be reproduced (and TF is absent), so parity under dropout is defined with the MASKS of the
-HIP path: keep(seed, idx) = (hash32(seed, idx) >> 8) >= p * 2^24, kept values scaled by 1/(1-p)
-(csrc/common.h::drop_hash).  With these masks the oracle and the device compute the same function."""
+HIP path: one hash32(seed, idx >> 1) per element pair, its low (even idx) / high (odd idx) 16 bits compared
+with p * 2^16; kept values scaled by 1/(1-p) (csrc/common.h::drop_hash, drop_keep).  With these masks the oracle and the device compute the same function."""
 import numpy as np
 import torch
 
@@ -24,14 +24,24 @@ def drop_hash(seed, idx):
 
 
 def keep_mask(seed, idx, p):
-    thresh = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
-    return (drop_hash(seed, idx) >> np.uint64(8)) >= thresh
+    idx = np.asarray(idx).astype(np.uint64)
+    thresh = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    h = drop_hash(seed, idx >> np.uint64(1))
+    half = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return half >= thresh
+
+
+def attn_index(BH, T, S):
+    """Element index of the attention-probability dropout (attention_f32.hip): rows padded to an even length."""
+    Sp = (S + 1) & ~1
+    r, k = np.meshgrid(np.arange(BH * T), np.arange(S), indexing="ij")
+    return (r * Sp + k).reshape(BH, T, S)
 
 
 class Dropper:
     """drop(seed, x, layout): layout "lbc" = sequence-first activations [L,B,C] whose device twin is the
-    batch-first matrix [B*L, C] (element index (b*L+l)*C+c); "flat" = row-major index of x itself
-    (attention probabilities [B*H, T, S])."""
+    batch-first matrix [B*L, C] (element index (b*L+l)*C+c); "flat" = row-major index of x itself; "attn" =
+    attention probabilities [B*H, T, S] with the row stride padded to an even length (attn_index)."""
 
     def __init__(self, p, base_seed):
         self.p, self.base = float(p), int(base_seed)
@@ -44,6 +54,8 @@ class Dropper:
             L, B, C = shp
             l, b, c = np.meshgrid(np.arange(L), np.arange(B), np.arange(C), indexing="ij")
             idx = (b * L + l) * C + c
+        elif layout == "attn":
+            idx = attn_index(*shp)
         else:
             idx = np.arange(int(np.prod(shp))).reshape(shp)
         keep = keep_mask((self.base + seed_off) & 0xFFFFFFFF, idx, self.p)

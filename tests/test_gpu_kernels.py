@@ -602,7 +602,7 @@ def test_fused_attention_dropout(hip, B, T, S):
     v = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
     qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
     w = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)                       # [B,H,T,S]
-    keep = torch.from_numpy(DR.keep_mask(seed, np.arange(B * H * T * S).reshape(B, H, T, S), p))
+    keep = torch.from_numpy(DR.keep_mask(seed, DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
     wd = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
     o = (wd @ vh).transpose(1, 2).reshape(B, T, D)
     do = torch.randn(B, T, D, dtype=torch.float64)
