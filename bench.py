@@ -98,11 +98,13 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
     ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 storage/accumulation (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the 3 extra fp32-parity-mode steps of a bf16 run")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--event-steps", type=int, default=1, help="timed steps (the last ones) whose launches carry HIP events")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
@@ -159,11 +161,16 @@ def main():
     for i in range(args.warmup):
         last = step(i)
     barrier()
+    # HIP events around every GEMM / conv launch (roofline leg) cost ~4 us of host time per event (~3.5 ms per step),
+    # so they are recorded in the LAST `event_steps` timed steps only; the other timed steps run uninstrumented.
     prof = None
-    if not args.no_kernel_events and rank == 0:
-        prof = _hip.PROFILER = _hip.KernelProfiler()
+    ev_steps = 0 if (args.no_kernel_events or rank != 0) else max(1, min(args.event_steps, args.steps))
+    if ev_steps:
+        prof = _hip.KernelProfiler()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if prof is not None and i == args.steps - ev_steps:
+            _hip.PROFILER = prof
         last = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
@@ -181,6 +188,20 @@ def main():
         barrier()
         value_nodrop = args.batch * world * 3 / (time.perf_counter() - t1)
         model.engine.dropout_p = args.dropout
+    # fp32 parity mode (exact-f32 MFMA everywhere: the mode the oracle parity tests run in), reported beside the headline
+    value_fp32 = None
+    if args.mode == "train" and args.precision == "bf16" and world == 1 and not args.no_fp32_leg:
+        model = opt = None
+        torch.cuda.empty_cache()
+        model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision="fp32")
+        opt = setup_optimizers(model, cfg)
+        step(0)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(3):
+            step(1 + i)
+        barrier()
+        value_fp32 = args.batch * 3 / (time.perf_counter() - t1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -196,39 +217,42 @@ def main():
             fam = prof.summary()
             if args.dump_shapes:
                 with open(args.dump_shapes, "w") as f:
-                    json.dump({"steps": args.steps, "rows": prof.by_shape(60)}, f, indent=1)
+                    json.dump({"steps": ev_steps, "rows": prof.by_shape(60)}, f, indent=1)
             if fam:
                 dom = max(fam, key=lambda k: fam[k]["ms"])
                 d = fam[dom]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 traffic, traffic_src = None, None
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic_bf16.json" if args.precision == "bf16" else "r01_traffic.json")
                 if os.path.exists(tpath) and dom == "gemm_f32":
                     with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
                         tj = json.load(f)
-                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+                    traffic = round(tj["traffic_bytes_per_launch"])
+                    traffic_src = f"profiles/{os.path.basename(tpath)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                 if args.precision == "bf16":
                     # fp32 storage + bf16 MFMA: the GEMM-class kernels are HBM bound -> algorithmic bytes / time
                     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                     roofline = {"bound": "hbm", "kernel": dom + " (bf16 compute)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                                "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                                "tflops": round(ach, 2), "launches_per_step": d["launches"] // args.steps,
+                                "tflops": round(ach, 2), "launches_per_step": d["launches"] // ev_steps,
                                 "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                                "families": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
+                                "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
                                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                  "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                                 "launches_per_step": v["launches"] // args.steps} for k, v in fam.items()}}
+                                                 "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}
                 else:
                   roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                             "traffic_source": traffic_src,
                             "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
-                            "launches_per_step": d["launches"] // args.steps,
+                            "launches_per_step": d["launches"] // ev_steps,
                             "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                            "families": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                            "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
+                            "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                             "launches_per_step": v["launches"] // args.steps} for k, v in fam.items()}}
+                                             "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}
         res = {
             "metric": "images/sec training step, DETR-R50 800x1333 bs=8/GPU" if args.mode == "train"
                       else "images/sec forward+set-loss, DETR-R50 800x1333 bs=8/GPU",
@@ -240,6 +264,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)"},
             "loss": round(loss_val, 5),
             "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
+            "images_per_sec_fp32_parity_mode": round(value_fp32, 3) if value_fp32 else None,
             "whole_step_fraction_of_f32_mfma_peak": round(value / world * gflop * scale / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }

@@ -27,7 +27,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AT_LD = 33;
 constexpr int AT_KEYS = 32;      // keys (or queries, in the dK/dV kernel) per LDS tile
-constexpr int AT_ROWS_WG = 128;  // queries (keys) per workgroup: 4 waves x 32
 
 struct AttnArgs {
     const float *Q, *K, *V;      // [B, T|S, ld]
@@ -61,28 +60,42 @@ __device__ __forceinline__ uint32_t keep_bits16(uint32_t seed, unsigned long lon
     return bits;
 }
 
-// cooperative load of one 32 x 32 tile (rows row0.., zero filled past nrows) into registers / LDS
-__device__ __forceinline__ float4 tile_load(const float *base, long long ld, int row0, int nrows, int tid) {
-    const int r = tid >> 3, c = (tid & 7) * 4;
-    const int row = row0 + r;
-    if (row < nrows) return *reinterpret_cast<const float4 *>(base + (long long)row * ld + c);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ void tile_store(float (*S)[AT_LD], float4 v, int tid) {
-    const int r = tid >> 3, c = (tid & 7) * 4;
-    S[r][c + 0] = v.x; S[r][c + 1] = v.y; S[r][c + 2] = v.z; S[r][c + 3] = v.w;
-}
+// cooperative load of one 32 x 32 tile (rows row0.., zero filled past nrows) into registers / LDS by a workgroup of
+// NW waves: 256 float4 per tile, 4 / NW per thread
+template <int NW>
+struct Tile {
+    static constexpr int LPT = 4 / NW;
+    float4 v[LPT];
+    __device__ __forceinline__ void load(const float *base, long long ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int u = tid + 64 * NW * i;
+            const int r = u >> 3, c = (u & 7) * 4;
+            const int row = row0 + r;
+            v[i] = (row < nrows) ? *reinterpret_cast<const float4 *>(base + (long long)row * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float (*S)[AT_LD], int tid) const {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int u = tid + 64 * NW * i;
+            const int r = u >> 3, c = (u & 7) * 4;
+            S[r][c + 0] = v[i].x; S[r][c + 1] = v[i].y; S[r][c + 2] = v[i].z; S[r][c + 3] = v[i].w;
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     __shared__ float Ks[2][AT_KEYS][AT_LD];
     __shared__ float Vs[2][AT_KEYS][AT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int tq = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
     const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
     const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
@@ -99,16 +112,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
-    float4 rk = tile_load(Kb, a.ld, 0, a.S, tid), rv = tile_load(Vb, a.ld, 0, a.S, tid);
-    tile_store(Ks[0], rk, tid);
-    tile_store(Vs[0], rv, tid);
+    Tile<NW> rk, rv;
+    rk.load(Kb, a.ld, 0, a.S, tid);
+    rv.load(Vb, a.ld, 0, a.S, tid);
+    rk.store(Ks[0], tid);
+    rv.store(Vs[0], tid);
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk = tile_load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv = tile_load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
         }
         f32x16 s;
 #pragma unroll
@@ -149,8 +164,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r)
             o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][krow(r, hi)][l31], p[r], o, 0, 0, 0);
         if (more) {
-            tile_store(Ks[cur ^ 1], rk, tid);
-            tile_store(Vs[cur ^ 1], rv, tid);
+            rk.store(Ks[cur ^ 1], tid);
+            rv.store(Vs[cur ^ 1], tid);
         }
         __syncthreads();
         cur ^= 1;
@@ -167,13 +182,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward 1/2: dQ (per query tile, streams the keys) and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ float Ks[2][AT_KEYS][AT_LD];
     __shared__ float Vs[2][AT_KEYS][AT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int tq = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
     const long long qoff = ((long long)b * a.T + tq) * a.ld + h * 32;
     const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
@@ -198,16 +214,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
-    float4 rk = tile_load(Kb, a.ld, 0, a.S, tid), rv = tile_load(Vb, a.ld, 0, a.S, tid);
-    tile_store(Ks[0], rk, tid);
-    tile_store(Vs[0], rv, tid);
+    Tile<NW> rk, rv;
+    rk.load(Kb, a.ld, 0, a.S, tid);
+    rv.load(Vb, a.ld, 0, a.S, tid);
+    rk.store(Ks[0], tid);
+    rv.store(Vs[0], tid);
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk = tile_load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv = tile_load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
         }
         f32x16 s, dp;
 #pragma unroll
@@ -235,8 +253,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r)
             dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][krow(r, hi)][l31], ds[r], dq, 0, 0, 0);
         if (more) {
-            tile_store(Ks[cur ^ 1], rk, tid);
-            tile_store(Vs[cur ^ 1], rv, tid);
+            rk.store(Ks[cur ^ 1], tid);
+            rv.store(Vs[cur ^ 1], tid);
         }
         __syncthreads();
         cur ^= 1;
@@ -251,14 +269,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // backward 2/2: dK, dV (per key tile, streams the queries; needs LSE and delta)
 // here the natural orientation is S[query][key]: lane l holds key (l&31) and 16 queries.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ float Qs[2][AT_KEYS][AT_LD];
     __shared__ float Ds[2][AT_KEYS][AT_LD];
     __shared__ float Ls[2][AT_KEYS], Dl[2][AT_KEYS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int sk = blockIdx.x * AT_ROWS_WG + wave * 32 + l31;
+    const int sk = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool kok = sk < a.S;
     const long long koff = ((long long)b * a.S + sk) * a.ld + h * 32;
     const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
@@ -278,14 +297,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { dk[r] = 0.0f; dv[r] = 0.0f; }
 
     const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
-    float4 rq = tile_load(Qb, a.ld, 0, a.T, tid), rd = tile_load(Db, a.ld, 0, a.T, tid);
+    Tile<NW> rq, rd;
+    rq.load(Qb, a.ld, 0, a.T, tid);
+    rd.load(Db, a.ld, 0, a.T, tid);
     float rl = 0.f, rdl = 0.f;
     if (tid < AT_KEYS) {
         rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
         rdl = (tid < a.T) ? dlt[tid] : 0.0f;
     }
-    tile_store(Qs[0], rq, tid);
-    tile_store(Ds[0], rd, tid);
+    rq.store(Qs[0], tid);
+    rd.store(Ds[0], tid);
     if (tid < AT_KEYS) { Ls[0][tid] = rl; Dl[0][tid] = rdl; }
     __syncthreads();
     int cur = 0;
@@ -293,8 +314,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         const bool more = (it + 1) < ntiles;
         if (more) {
             const int t0 = (it + 1) * AT_KEYS;
-            rq = tile_load(Qb, a.ld, t0, a.T, tid);
-            rd = tile_load(Db, a.ld, t0, a.T, tid);
+            rq.load(Qb, a.ld, t0, a.T, tid);
+            rd.load(Db, a.ld, t0, a.T, tid);
             if (tid < AT_KEYS) {
                 rl = (t0 + tid < a.T) ? lse[t0 + tid] * AT_LOG2E : INFINITY;
                 rdl = (t0 + tid < a.T) ? dlt[t0 + tid] : 0.0f;
@@ -330,8 +351,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[cur][qr][l31], ds[r], dk, 0, 0, 0);
         }
         if (more) {
-            tile_store(Qs[cur ^ 1], rq, tid);
-            tile_store(Ds[cur ^ 1], rd, tid);
+            rq.store(Qs[cur ^ 1], tid);
+            rd.store(Ds[cur ^ 1], tid);
             if (tid < AT_KEYS) { Ls[cur ^ 1][tid] = rl; Dl[cur ^ 1][tid] = rdl; }
         }
         __syncthreads();
@@ -359,6 +380,14 @@ static int check_args(const float *q, const float *k, const float *v, int B, int
 
 using namespace detr;
 
+// waves per workgroup: 4 waves (128 rows) amortise the K/V tile loads best, but the grid must still balance over
+// 256 CUs -- below ~8 workgroups per CU the 2-wave kernels (twice the workgroups) win.  DETR_HIP_ATTN_WAVES forces.
+static int attn_waves(int rows, int bh) {
+    const int force = env_tile("DETR_HIP_ATTN_WAVES");
+    if (force == 2 || force == 4) return force;
+    return ((long long)cdiv(rows, 128) * bh < 2048) ? 2 : 4;
+}
+
 static int set_drop(AttnArgs &a, float p, uint32_t seed) {
     DETR_REQUIRE(p >= 0.0f && p < 1.0f, "attention: dropout p=%f out of range", p);
     a.drop_scale = p > 0.0f ? 1.0f / (1.0f - p) : 0.0f;
@@ -376,8 +405,9 @@ extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const 
     a.Q = q; a.K = k; a.V = v; a.O = o; a.LSE = lse;
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
     if (set_drop(a, dropout_p, dropout_seed)) return -1;
-    dim3 grid((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention fwd");
     return 0;
 }
@@ -395,9 +425,11 @@ extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const 
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
     if (set_drop(a, dropout_p, dropout_seed)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)cdiv(T, AT_ROWS_WG), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)cdiv(S, AT_ROWS_WG), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (attn_waves(S, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3((unsigned)cdiv(S, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((unsigned)cdiv(S, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dkv");
     return 0;
 }
