@@ -63,16 +63,32 @@ __host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, unsigned long 
 }
 static inline uint32_t drop_thresh16(float p) { return (uint32_t)(p * 65536.0f); }
 
-// wave64 reductions (all 64 lanes participate)
+// wave64 reductions (all 64 lanes participate; the result is wave-uniform).  DPP row-shift scan inside each row of
+// 16 lanes, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63 (the gfx9 wave64 reduction idiom):
+// 6 DPP-modified VALU ops + one v_readlane instead of 6 dependent ds_bpermute round trips through the LDS pipe.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float identity, float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, x),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov_f32<0x111, 0xf>(0.0f, v);   // row_shr:1
+    v += dpp_mov_f32<0x112, 0xf>(0.0f, v);   // row_shr:2
+    v += dpp_mov_f32<0x114, 0xf>(0.0f, v);   // row_shr:4
+    v += dpp_mov_f32<0x118, 0xf>(0.0f, v);   // row_shr:8
+    v += dpp_mov_f32<0x142, 0xa>(0.0f, v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f32<0x143, 0xc>(0.0f, v);   // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float ninf = -INFINITY;
+    v = fmaxf(v, dpp_mov_f32<0x111, 0xf>(ninf, v));
+    v = fmaxf(v, dpp_mov_f32<0x112, 0xf>(ninf, v));
+    v = fmaxf(v, dpp_mov_f32<0x114, 0xf>(ninf, v));
+    v = fmaxf(v, dpp_mov_f32<0x118, 0xf>(ninf, v));
+    v = fmaxf(v, dpp_mov_f32<0x142, 0xa>(ninf, v));
+    v = fmaxf(v, dpp_mov_f32<0x143, 0xc>(ninf, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace detr

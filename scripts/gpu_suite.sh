@@ -35,3 +35,4 @@ for w in $WHAT; do
 done
 cat $OUT/summary.txt
 for f in kernels model smoke bench bench_fwd; do [ -f $OUT/$f.log ] && { echo "=== $f"; tail -n 40 $OUT/$f.log; }; done
+exit 0
