@@ -31,7 +31,8 @@ void set_error(const char *fmt, ...);
 
 // out[r*ldc + c] += alpha * scale[c] * sum_s ws[s*part_stride + r*cols + c]   (gemm_f32.hip)
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
-                          float alpha, const float *scale, hipStream_t stream);
+                          float alpha, const float *scale, hipStream_t stream, const float *rs_ws = nullptr,
+                          float *rs_out = nullptr, float rs_alpha = 1.0f);
 
 // tuning hook: integer environment variable (0 when unset)
 static inline int env_tile(const char *name) {

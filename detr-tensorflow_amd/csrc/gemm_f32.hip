@@ -18,7 +18,42 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int a_vec, b_vec;
     EpiArgs e;
+    // optional fused bias gradient: row sums of the (MN-contiguous) A operand, i.e. rowsum[m] = sum_k A[m][k]
+    float *rowsum;               // split_k == 1: rowsum[m] += rowsum_alpha * sum;  else partial slab [split][M]
+    float rowsum_alpha;
+    int rowsum_partial;
 };
+
+// Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
+// one column group (4 consecutive rows m of A); the holders of a group are combined in a fixed order through LDS.
+template <int BM, int NSLOT>
+__device__ __forceinline__ void rowsum_finish(const float4 (&rs)[NSLOT], float *lds, const GemmArgs &g, int m0, int split,
+                                              int tid, bool bf16_map) {
+    float4 *part = reinterpret_cast<float4 *>(lds);            // [NSLOT][256]
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) part[i * 256 + tid] = rs[i];
+    __syncthreads();
+    if (tid < BM) {
+        const int cg = tid >> 2, comp = tid & 3;
+        float sum = 0.0f;
+        if (bf16_map) {          // LoaderMNb: group (t >> 4) + 16 i lives in threads (cg & 15) * 16 + kp, slot cg >> 4
+            const float *src = lds + ((cg >> 4) * 256 + (cg & 15) * 16) * 4 + comp;
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp) sum += src[kp * 4];
+        } else {                 // LoaderMN: group t % (BM/4) lives in threads cg + (BM/4) * j
+            constexpr int VPR = BM / 4;
+            const float *src = lds + cg * 4 + comp;
+#pragma unroll
+            for (int j = 0; j < 256 / VPR; ++j) sum += src[j * VPR * 4];
+        }
+        const int m = m0 + tid;
+        if (m < g.M) {
+            if (g.rowsum_partial) g.rowsum[(long long)split * g.M + m] = sum;
+            else g.rowsum[m] += g.rowsum_alpha * sum;
+        }
+    }
+    __syncthreads();
+}
 
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
@@ -64,9 +99,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
+    float4 rs[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto rs_add = [&](const float4 (&r)[LA::NV]) {
+#pragma unroll
+        for (int i = 0; i < LA::NV; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
+    };
     float4 ra[LA::NV], rb[LB::NV];
     la.load(kt0 * GEMM_BK, g.K, ra);
     lb.load(kt0 * GEMM_BK, g.K, rb);
+    if (do_rs) rs_add(ra);
     la.store(sm.A[0], ra);
     lb.store(sm.B[0], rb);
     __syncthreads();
@@ -80,12 +122,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
         }
         mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
+            if (do_rs) rs_add(ra);
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
         }
         __syncthreads();
         cur ^= 1;
     }
+    if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, false);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -128,9 +172,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
+    constexpr int NRS = AK ? 1 : LoaderMNb<BM>::NU;
+    float4 rs[NRS];
+#pragma unroll
+    for (int i = 0; i < NRS; ++i) rs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto rs_add = [&](const float4 (&r)[NRA]) {     // slot i = column group (tid >> 4) + 16 i, registers 2i (k) and 2i+1 (k+1)
+        if (!AK) {
+#pragma unroll
+            for (int i = 0; i < NRS; ++i) {
+                rs[i].x += r[2 * i].x + r[2 * i + 1].x; rs[i].y += r[2 * i].y + r[2 * i + 1].y;
+                rs[i].z += r[2 * i].z + r[2 * i + 1].z; rs[i].w += r[2 * i].w + r[2 * i + 1].w;
+            }
+        }
+    };
     float4 ra[NRA], rb[NRB];
     la.load(kt0 * BF_BK, g.K, ra);
     lb.load(kt0 * BF_BK, g.K, rb);
+    if (do_rs) rs_add(ra);
     la.store(sm.A[0], ra);
     lb.store(sm.B[0], rb);
     __syncthreads();
@@ -143,12 +202,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
         }
         mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
+            if (do_rs) rs_add(ra);
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
         }
         __syncthreads();
         cur ^= 1;
     }
+    if (do_rs) rowsum_finish<BM, NRS>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, true);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -156,8 +217,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
 // stride the split index, 4 independent loads in flight each), combined through LDS.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
                                                             int rows, int cols, float *__restrict__ C, long long ldc,
-                                                            float alpha, const float *__restrict__ scale, int vec) {
+                                                            float alpha, const float *__restrict__ scale, int vec,
+                                                            const float *__restrict__ rs_ws, float *__restrict__ rs_out,
+                                                            float rs_alpha) {
     __shared__ float4 red[4][64];
+    if (rs_ws) {     // fused bias gradient: partial row sums [splits][rows] -> rs_out[rows] (fixed summation order)
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < rows; m += gridDim.x * 256) {
+            float t = 0.0f;
+            for (int k = 0; k < splits; ++k) t += rs_ws[(long long)k * rows + m];
+            rs_out[m] += rs_alpha * t;
+        }
+    }
     const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
     if (vec) {
         const int c4n = cols >> 2;
@@ -204,7 +274,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 }
 
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
-                          float alpha, const float *scale, hipStream_t stream) {
+                          float alpha, const float *scale, hipStream_t stream, const float *rs_ws, float *rs_out,
+                          float rs_alpha) {
     const int vec = (cols % 4 == 0) && (ldc % 4 == 0) && (part_stride % 4 == 0) && aligned16(ws) && aligned16(C) &&
                     (!scale || aligned16(scale));
     const long long total = (long long)rows * (vec ? cols / 4 : cols);
@@ -212,7 +283,7 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols, C,
-                       ldc, alpha, scale, vec);
+                       ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -269,6 +340,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         const long long eb = d->b_kcontig ? (long long)(d->N - 1) * d->ldb + d->K : (long long)(d->K - 1) * d->ldb + d->N;
         DETR_REQUIRE(ea * 4 <= BUF_MAX_BYTES && eb * 4 <= BUF_MAX_BYTES, "gemm: an operand spans more than 4 GB");
     }
+    if (d->rowsum_a) DETR_REQUIRE(!d->a_kcontig && batch == 1, "gemm: rowsum_a needs an MN-contiguous A operand and batch == 1");
     DETR_REQUIRE((long long)batch * split <= 65535, "gemm: batch*split_k=%lld exceeds grid.z", (long long)batch * split);
 
     GemmArgs g;
@@ -309,7 +381,11 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long part = (long long)d->M * d->N;
     const bool partial = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace) &&
-                         d->workspace_bytes >= (long long)split * part * 4;
+                         d->workspace_bytes >= (long long)split * (part + (d->rowsum_a ? d->M : 0)) * 4;
+    DETR_REQUIRE(!(d->rowsum_a && split > 1 && !partial), "gemm: rowsum_a with split_k needs the workspace path");
+    g.rowsum = d->rowsum_a;
+    g.rowsum_alpha = d->rowsum_alpha;
+    g.rowsum_partial = 0;
     EpiArgs final_e = g.e;
     if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;
@@ -319,6 +395,10 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         g.e.scale = nullptr;
         g.e.atomic = 0;
         g.e.vec = (d->N % 4 == 0);
+        if (d->rowsum_a) {       // partial row sums go behind the tile slabs
+            g.rowsum = d->workspace + (long long)split * part;
+            g.rowsum_partial = 1;
+        }
     }
     // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
@@ -348,7 +428,8 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     }
     DETR_LAUNCH_CHECK("gemm");
     if (partial) {
-        launch_splitk_reduce(d->workspace, split, part, d->M, d->N, d->C, d->ldc, final_e.alpha, final_e.scale, s);
+        launch_splitk_reduce(d->workspace, split, part, d->M, d->N, d->C, d->ldc, final_e.alpha, final_e.scale, s,
+                             d->rowsum_a ? d->workspace + (long long)split * part : nullptr, d->rowsum_a, d->rowsum_alpha);
         DETR_LAUNCH_CHECK("gemm split-k reduce");
     }
     return 0;

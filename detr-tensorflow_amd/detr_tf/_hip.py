@@ -30,7 +30,8 @@ class GemmDesc(Structure):
                 ("mask", c_void_p), ("ldmask", c_int64),
                 ("act", c_int32), ("split_k", c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
-                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32)]
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
+                ("rowsum_a", c_void_p), ("rowsum_alpha", c_float)]
 
 
 class Conv3x3Desc(Structure):
@@ -191,7 +192,8 @@ def _f32(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
          residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0, compute=None):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0, compute=None,
+         rowsum_a=None, rowsum_alpha=1.0):
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -209,6 +211,7 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d.act, d.split_k = act, split_k
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    d.rowsum_a, d.rowsum_alpha = ptr(rowsum_a), rowsum_alpha
     ws = workspace if workspace is not None else WORKSPACE
     d.workspace, d.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
@@ -252,17 +255,18 @@ def linear_dgrad(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):
          mask=mask, ldmask=(mask.stride(0) if mask is not None else 0))
 
 
-def linear_wgrad(dy2d, x2d, dw_out_in, *, alpha=1.0):
-    """dW(out,in) += alpha * dy^T @ x  (atomic split-K; dW must hold zeros / the running sum)."""
+def linear_wgrad(dy2d, x2d, dw_out_in, *, alpha=1.0, bias_grad=None):
+    """dW(out,in) += alpha * dy^T @ x (deterministic split-K through the workspace; dW holds zeros / the running sum);
+    bias_grad (out,) += alpha * column sums of dy, fused into the same launch (row sums of the A operand)."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     sk = pick_split_k(N, K, M)
     if sk == 1:
         gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
-             residual=dw_out_in, ldr=dw_out_in.stride(0))
+             residual=dw_out_in, ldr=dw_out_in.stride(0), rowsum_a=bias_grad, rowsum_alpha=alpha)
     else:
         gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
-             split_k=sk)
+             split_k=sk, rowsum_a=bias_grad, rowsum_alpha=alpha)
 
 
 # ------------------------------------------------------------------------------------------

@@ -203,8 +203,7 @@ class DetrEngine:
                      (dbase + seed + 1) & 0xFFFFFFFF)
             d_out = d_drop
         # out projection
-        hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"])
-        self._colsum(d_out, G[f"{pfx}/out_proj_bias"])
+        hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"])
         dO = self.buf("scratch:dO", (B * T, D))
         hip.linear_dgrad(d_out, V[f"{pfx}/out_proj_kernel"], dO)
         # attention core
@@ -226,12 +225,9 @@ class DetrEngine:
             hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
         # in projection: Q = (q_in Wq^T + bq) * alpha
         alpha = float(HD) ** -0.5
-        hip.linear_wgrad(dQ, q_in, gW[0:D], alpha=alpha)
-        self._colsum(dQ, gb[0:D], alpha)
-        hip.linear_wgrad(dK, k_in, gW[D:2 * D])
-        self._colsum(dK, gb[D:2 * D])
-        hip.linear_wgrad(dV, v_in, gW[2 * D:])
-        self._colsum(dV, gb[2 * D:])
+        hip.linear_wgrad(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D])      # bias gradients fused (row sums of dy^T)
+        hip.linear_wgrad(dK, k_in, gW[D:2 * D], bias_grad=gb[D:2 * D])
+        hip.linear_wgrad(dV, v_in, gW[2 * D:], bias_grad=gb[2 * D:])
         hip.linear_dgrad(dQ, W[0:D], dq_in, alpha=alpha)
         hip.linear_dgrad(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None)
         hip.linear_dgrad(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)
@@ -255,13 +251,11 @@ class DetrEngine:
             d_y = self.buf("scratch:d_ffn_drop", d_f.shape)
             hip.call("detr_hip_dropout_f32", d_f.data_ptr(), d_y.data_ptr(), d_f.numel(), c_float(dp),
                      (dbase + seed + 1) & 0xFFFFFFFF)
-        hip.linear_wgrad(d_y, h, G[f"{pfx}/linear2/kernel"])
-        self._colsum(d_y, G[f"{pfx}/linear2/bias"])
+        hip.linear_wgrad(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"])
         dh = self.buf("scratch:dh", h.shape)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
         hip.linear_dgrad(d_y, V[f"{pfx}/linear2/kernel"], dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
-        hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"])
-        self._colsum(dh, G[f"{pfx}/linear1/bias"])
+        hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])
         hip.linear_dgrad(dh, V[f"{pfx}/linear1/kernel"], dx, residual=d_f)
 
     # ---- forward ----------------------------------------------------------------------------------
@@ -443,17 +437,13 @@ class DetrEngine:
         d_hs = self.buf("scratch:d_hs", (R, D))
         dt_b, dt_a = self.buf("scratch:dt_b", (R, D)), self.buf("scratch:dt_a", (R, D))
         if self.nb_class is None:
-            hip.linear_wgrad(dz3, t_b, G["bbox_embed_2/kernel"])
-            self._colsum(dz3, G["bbox_embed_2/bias"])
+            hip.linear_wgrad(dz3, t_b, G["bbox_embed_2/kernel"], bias_grad=G["bbox_embed_2/bias"])
             hip.linear_dgrad(dz3, V["bbox_embed_2/kernel"], dt_b, mask=t_b)
-            hip.linear_wgrad(dt_b, t_a, G["bbox_embed_1/kernel"])
-            self._colsum(dt_b, G["bbox_embed_1/bias"])
+            hip.linear_wgrad(dt_b, t_a, G["bbox_embed_1/kernel"], bias_grad=G["bbox_embed_1/bias"])
             hip.linear_dgrad(dt_b, V["bbox_embed_1/kernel"], dt_a, mask=t_a)
-            hip.linear_wgrad(dt_a, hs2, G["bbox_embed_0/kernel"])
-            self._colsum(dt_a, G["bbox_embed_0/bias"])
+            hip.linear_wgrad(dt_a, hs2, G["bbox_embed_0/kernel"], bias_grad=G["bbox_embed_0/bias"])
             hip.linear_dgrad(dt_a, V["bbox_embed_0/kernel"], d_hs)
-            hip.linear_wgrad(dl, hs2, G["class_embed/kernel"])
-            self._colsum(dl, G["class_embed/bias"])
+            hip.linear_wgrad(dl, hs2, G["class_embed/kernel"], bias_grad=G["class_embed/bias"])
             hip.linear_dgrad(dl, V["class_embed/kernel"], d_hs, residual=d_hs)
         else:
             def dense_bwd(dy, x, name, dx, mask=None, residual=None):

@@ -75,6 +75,11 @@ typedef struct {
     /* 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA with fp32 storage / accumulation (BASELINE config C3:
      * operands are rounded to bf16 on their way into LDS) */
     int32_t compute;
+    /* optional fused bias gradient of a weight-gradient GEMM (dW = dy^T x): rowsum_a[m] += rowsum_alpha * sum_k A[m][k]
+     * (A must be MN-contiguous, a_kcontig = 0; batch == 1; with split_k > 1 the deterministic workspace path is
+     * required and the workspace must hold split_k*(M*N + M) floats).  Replaces the reference's separate
+     * reduce_sum for every Linear bias gradient (tape gradient of custom_layers.py Linear bias). */
+    float *rowsum_a; float rowsum_alpha;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 

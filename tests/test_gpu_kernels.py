@@ -140,6 +140,29 @@ def test_split_k_deterministic_workspace_path(hip):
         hip.WORKSPACE = old
 
 
+@pytest.mark.parametrize("M,N,K,sk,compute", [(256, 256, 8400, 32, 0), (92, 256, 4800, 8, 0), (4, 256, 4800, 1, 0),
+                                               (2048, 256, 800, 3, 0), (256, 256, 8400, 32, 1), (768, 256, 801, 1, 1),
+                                               (128, 512, 20000, 24, 1), (92, 256, 4800, 8, 1)])
+def test_gemm_fused_rowsum_bias_gradient(hip, M, N, K, sk, compute):
+    """weight-gradient GEMM dW = dy^T x with the bias gradient (column sums of dy = row sums of the A operand) fused
+    into the same launch: exact fp32 sums in both compute modes, split and unsplit, ragged M, deterministic."""
+    torch.manual_seed(M + N + K + sk)
+    dy, x = torch.randn(K, M), torch.randn(K, N)
+    dyd, xd = g(dy), g(x)
+    ws = torch.empty(16 * 1024 * 1024, device=DEV)
+    b0 = torch.randn(M)
+    outs = []
+    for rep in range(2):
+        dw, db = torch.zeros(M, N, device=DEV), g(b0.clone())
+        kw = dict(split_k=sk) if sk > 1 else dict(residual=dw, ldr=N)
+        hip.gemm(M, N, K, dyd, M, 0, xd, N, 0, dw, N, alpha=0.5, workspace=ws, compute=compute, rowsum_a=db, rowsum_alpha=0.5, **kw)
+        outs.append((dw.clone(), db.clone()))
+    ref_w = 0.5 * ((_bf(dy) if compute else dy.double()).t() @ (_bf(x) if compute else x.double()))
+    close(outs[0][0], ref_w, rtol=5e-5, what="fused-rowsum gemm dW")
+    close(outs[0][1], b0.double() + 0.5 * dy.double().sum(0), rtol=2e-5, what="fused-rowsum bias gradient")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "must be deterministic"
+
+
 def test_gemm_batched_attention_layout(hip):
     """scores[b,h] = Q_h K_h^T and O = P V_h on the [B, L, heads*32] layout used by the transformer."""
     torch.manual_seed(4)
