@@ -9,9 +9,14 @@
 // consecutive k of one row = one ds_read_b128; 80 B = 5 sixteen-byte slots per row and gcd(5,16) = 1, so the 16
 // lanes of every ds_read_b128 service group (distinct rows mod 16) hit 16 distinct slots: conflict free.
 //   * K-contiguous fp32 operand ([mn][k]): float4 global load -> 4 bf16 -> one ds_write_b64.
-//   * MN-contiguous fp32 operand ([k][mn], e.g. HWIO kernels, weight-gradient operands): each lane loads the
-//     float4 of TWO consecutive k rows and writes four packed (k, k+1) words to four LDS rows; lanes are ordered
-//     k-pair fastest so that a half-wave writes 32 distinct banks.
+//   * MN-contiguous fp32 operand ([k][mn], weight-gradient operands, Linear dgrad weights) in the GEMM kernels
+//     (LoaderMNt): the tile keeps its natural orientation in LDS, cut into [4 k][16 mn] sub-blocks of 128 B, and
+//     the MFMA fragments are fetched with ds_read_b64_tr_b16 (gfx950 transpose read: the 16 lanes of a group hand
+//     in the sixteen 8-byte chunks of one sub-block and lane c receives column c = 4 consecutive k of one row).
+//     Global loads are float4 along mn (256 B contiguous per k row and wave), the LDS write is one linear
+//     ds_write_b64 per float4 -- the same cost as the K-contiguous path; fragment = 2 tr reads.
+//   * conv kernels (LoaderMNb, weights / gathered pixels): each lane loads the float4 of TWO consecutive k rows
+//     and writes four packed (k, k+1) words to four LDS rows of the [row][k] image.
 #pragma once
 #include "gemm_core.h"
 
@@ -136,9 +141,71 @@ struct LoaderMNb {
     }
 };
 
+// fp32 operand stored [k][mn] (mn contiguous), transpose-read image.  Unit u = t + 256*i, bit fields (low to high):
+// c = u & 3 (float4 inside a sub-block row), kr = (u >> 2) & 3 (k inside the sub-block), ib = mn sub-block, kb = k
+// sub-block; the LDS image is written LINEARLY in u (8 bytes per unit), sub-block (kb, ib) at ((kb * NB) + ib) * 128 B.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int BMN>
+struct LoaderMNt {
+    static constexpr int NB = BMN / 16;
+    static constexpr int NU = BMN / 32;              // float4 per thread and tile (32 k x BMN / 4 / 256)
+    BufSrc src;
+    unsigned ld4b;
+    int mn0, MN;
+    bool vec;
+    int tid;
+
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, int K, bool vec_, int tid_,
+                                         long long extent_elems = 0) {
+        src.init(p, extent_elems > 0 ? extent_elems : (long long)(K - 1) * ld_ + MN_);
+        ld4b = (unsigned)(ld_ * 4); mn0 = mn0_; MN = MN_; vec = vec_; tid = tid_;
+    }
+    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[NU], unsigned base = 0) const {
+        unsigned o[NU];
+        int nv[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+            const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+            o[i] = base + (unsigned)k * ld4b + 4u * (unsigned)col;
+            nv[i] = k < K ? MN - col : 0;
+        }
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) r[i] = src.ld4_vec(o[i], nv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) r[i] = src.ld4_scalar(o[i], nv[i]);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NU]) const {
+        unsigned short *flat = &S[0][0];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+            *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+    }
+};
+
+// MFMA fragment (8 consecutive k of row `row_base + (lane & 31)`) out of a transpose-read image
+template <int BMN>
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned short (*S)[BF_LD], int row_base, int ks, int lane) {
+    constexpr int NB = BMN / 16;
+    const int g = lane >> 4, t = lane & 15;
+    const int ib = (row_base >> 4) + (g & 1);
+    const int kb = (ks >> 2) + 2 * (g >> 1);
+    const unsigned short *p = &S[0][0] + ((kb * NB + ib) * 64 + t * 4);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + NB * 64));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // one 32-deep K tile: 2 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.
 // operand map: lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31].
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool ATR = false, bool BTR = false>
 __device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BF_LD], const unsigned short (*Bs)[BF_LD],
                                                f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
                                                int wm, int wn, int lane) {
@@ -149,11 +216,15 @@ __device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BF_LD]
     for (int ks = 0; ks < BF_BK; ks += 16) {
         bf16x8 a[T::TM], b[T::TN];
 #pragma unroll
-        for (int mi = 0; mi < T::TM; ++mi)
-            a[mi] = *reinterpret_cast<const bf16x8 *>(&As[wm * T::WTM + mi * 32 + l31][ks + kh]);
+        for (int mi = 0; mi < T::TM; ++mi) {
+            if (ATR) a[mi] = frag_tr<BM>(As, wm * T::WTM + mi * 32, ks, lane);
+            else a[mi] = *reinterpret_cast<const bf16x8 *>(&As[wm * T::WTM + mi * 32 + l31][ks + kh]);
+        }
 #pragma unroll
-        for (int ni = 0; ni < T::TN; ++ni)
-            b[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh]);
+        for (int ni = 0; ni < T::TN; ++ni) {
+            if (BTR) b[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
+            else b[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh]);
+        }
 #pragma unroll
         for (int mi = 0; mi < T::TM; ++mi)
 #pragma unroll

@@ -36,10 +36,13 @@ __device__ __forceinline__ void rowsum_finish(const float4 (&rs)[NSLOT], float *
     if (tid < BM) {
         const int cg = tid >> 2, comp = tid & 3;
         float sum = 0.0f;
-        if (bf16_map) {          // LoaderMNb: group (t >> 4) + 16 i lives in threads (cg & 15) * 16 + kp, slot cg >> 4
-            const float *src = lds + ((cg >> 4) * 256 + (cg & 15) * 16) * 4 + comp;
+        if (bf16_map) {          // LoaderMNt: group 4*ib + c lives in threads c + 4*kr + 16*ib + 16*NB*h (kr < 4, h < 16/NB)
+            constexpr int NB = BM / 16;
+            const float *src = lds + ((cg & 3) + 16 * (cg >> 2)) * 4 + comp;
 #pragma unroll
-            for (int kp = 0; kp < 16; ++kp) sum += src[kp * 4];
+            for (int h = 0; h < 16 / NB; ++h)
+#pragma unroll
+                for (int kr = 0; kr < 4; ++kr) sum += src[(4 * kr + 16 * NB * h) * 4];
         } else {                 // LoaderMN: group t % (BM/4) lives in threads cg + (BM/4) * j
             constexpr int VPR = BM / 4;
             const float *src = lds + cg * 4 + comp;
@@ -157,10 +160,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
 
-    using LA = typename std::conditional<AK, LoaderKb<BM>, LoaderMNb<BM>>::type;
-    using LB = typename std::conditional<BKC, LoaderKb<BN>, LoaderMNb<BN>>::type;
-    constexpr int NRA = AK ? LoaderKb<BM>::NV : 2 * LoaderMNb<BM>::NU;
-    constexpr int NRB = BKC ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
+    using LA = typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type;       // MN-contiguous: transpose-read image
+    using LB = typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type;
+    constexpr int NRA = AK ? LoaderKb<BM>::NV : LoaderMNt<BM>::NU;
+    constexpr int NRB = BKC ? LoaderKb<BN>::NV : LoaderMNt<BN>::NU;
     LA la;
     LB lb;
     la.init(A, g.lda, m0, g.M, g.K, g.a_vec != 0, tid);
@@ -173,17 +176,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
-    constexpr int NRS = AK ? 1 : LoaderMNb<BM>::NU;
-    float4 rs[NRS];
-#pragma unroll
-    for (int i = 0; i < NRS; ++i) rs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto rs_add = [&](const float4 (&r)[NRA]) {     // slot i = column group (tid >> 4) + 16 i, registers 2i (k) and 2i+1 (k+1)
+    float4 rs[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto rs_add = [&](const float4 (&r)[NRA]) {     // every float4 of a thread belongs to the column group 4*ib + c of its tid
         if (!AK) {
 #pragma unroll
-            for (int i = 0; i < NRS; ++i) {
-                rs[i].x += r[2 * i].x + r[2 * i + 1].x; rs[i].y += r[2 * i].y + r[2 * i + 1].y;
-                rs[i].z += r[2 * i].z + r[2 * i + 1].z; rs[i].w += r[2 * i].w + r[2 * i + 1].w;
-            }
+            for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
         }
     };
     float4 ra[NRA], rb[NRB];
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
             la.load((kt + 1) * BF_BK, g.K, ra);
             lb.load((kt + 1) * BF_BK, g.K, rb);
         }
-        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             if (do_rs) rs_add(ra);
             la.store(sm.A[cur ^ 1], ra);
@@ -209,7 +206,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
         __syncthreads();
         cur ^= 1;
     }
-    if (do_rs) rowsum_finish<BM, NRS>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, true);
+    if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, true);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -404,11 +401,10 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
     const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
     if (bf16c) {
-        // measured with the buffer-descriptor loaders (profiles/tune_bf16_r1b.txt): the 64x64 tile (8 waves/SIMD)
-        // wins every non-split shape of the step; 128x128 (2 waves/SIMD, 4x the operand reuse) only pays for split-K
-        // weight gradients with a >= 128x128 output and enough work per tile
-        const bool small = (split > 1) ? !(d->M >= 128 && d->N >= 128 && ((long long)d->M * d->N > 65536 || d->K >= 16384))
-                                       : true;
+        // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
+        // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (2 waves/SIMD, 4x the operand
+        // reuse) pays only for the long split-K weight gradients (K >= 16384) with N >= 128
+        const bool small = (split > 1) ? !(d->N >= 128 && d->K >= 16384) : true;
         if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
