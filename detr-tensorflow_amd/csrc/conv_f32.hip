@@ -374,8 +374,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     const long long tapstride = (long long)a.Ci * a.Co;
     LoaderConvAb<BM, DGRAD> la;
     la.init(a, m0, tid);
-    using LB = typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNb<BN>>::type;
-    constexpr int NRB = DGRAD ? LoaderKb<BN>::NV : 2 * LoaderMNb<BN>::NU;
+    using LB = typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNt<BN>>::type;   // fwd weights: transpose-read image
+    constexpr int NRB = DGRAD ? LoaderKb<BN>::NV : LoaderMNt<BN>::NU;
     LB lb;
     lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);   // one descriptor over the 9 taps
     f32x16 acc[T::TM][T::TN];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
             la.load(a, kt + 1, cpt, ra);
             load_b(kt + 1);
         }
-        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_bf16<BM, BN, WGM, WGN, false, !DGRAD>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
@@ -413,10 +413,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, wave, a.e);
 }
 
-// wgrad: A'[i = ci][k = m] gathered, MN-contiguous pairs of reduction rows
+// wgrad: A'[i = ci][k = m] gathered into a transpose-read image (gemm_bf16_core.h LoaderMNt): unit u = t + 256*i holds
+// the float4 of channels ci0 + 16*ib + 4*c of reduction row (output pixel) k = 4*kb + kr of the tile.
 template <int BM>
-struct LoaderWgradAb {
-    static constexpr int NU = BM / 64;
+struct LoaderWgradAt {
+    static constexpr int NB = BM / 16;
+    static constexpr int NU = BM / 32;
     BufSrc src;
     int n_[NU], h_[NU], w_[NU], m_[NU];
     int tid, ci0, kh, kw;
@@ -428,7 +430,7 @@ struct LoaderWgradAb {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + 256 * i;
-            const int m = m_begin + 2 * (u & 15);
+            const int m = m_begin + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
             m_[i] = m;
             w_[i] = m % a.Wo;
             const int t = m / a.Wo;
@@ -436,21 +438,15 @@ struct LoaderWgradAb {
             n_[i] = t / a.Ho;
         }
     }
-    __device__ __forceinline__ float4 fetch(const ConvWgradArgs &a, int n, int h, int w, int m, int m_end, int c) const {
-        const int hs = h * a.stride - a.pad + kh, ws = w * a.stride - a.pad + kw;
-        const bool v = m < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci;
-        const unsigned off = ((unsigned)((n * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)c) * 4u;
-        return src.ld4(v ? off : BUF_OOB);
-    }
-    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[2 * NU]) const {
+    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[NU]) const {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + 256 * i;
-            const int c = ci0 + (u >> 4) * 4;
-            r[2 * i] = fetch(a, n_[i], h_[i], w_[i], m_[i], m_end, c);
-            int w1 = w_[i] + 1, h1 = h_[i], n1 = n_[i];       // the next output pixel (row m + 1)
-            if (w1 >= a.Wo) { w1 = 0; h1 += 1; if (h1 >= a.Ho) { h1 = 0; n1 += 1; } }
-            r[2 * i + 1] = fetch(a, n1, h1, w1, m_[i] + 1, m_end, c);
+            const int c = ci0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+            const int hs = h_[i] * a.stride - a.pad + kh, ws = w_[i] * a.stride - a.pad + kw;
+            const bool v = m_[i] < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci;
+            const unsigned off = ((unsigned)((n_[i] * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)c) * 4u;
+            r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
     __device__ __forceinline__ void advance(const ConvWgradArgs &a) {
@@ -462,17 +458,11 @@ struct LoaderWgradAb {
             while (h_[i] >= a.Ho) { h_[i] -= a.Ho; n_[i] += 1; }
         }
     }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[2 * NU]) const {
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NU]) const {
+        unsigned short *flat = &S[0][0];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + 256 * i;
-            const int kp = u & 15, m4 = (u >> 4) * 4;
-            const float4 p = r[2 * i], q = r[2 * i + 1];
-            *reinterpret_cast<unsigned *>(&S[m4 + 0][2 * kp]) = pack_bf16(p.x, q.x);
-            *reinterpret_cast<unsigned *>(&S[m4 + 1][2 * kp]) = pack_bf16(p.y, q.y);
-            *reinterpret_cast<unsigned *>(&S[m4 + 2][2 * kp]) = pack_bf16(p.z, q.z);
-            *reinterpret_cast<unsigned *>(&S[m4 + 3][2 * kp]) = pack_bf16(p.w, q.w);
-        }
+        for (int i = 0; i < NU; ++i)
+            *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
     }
 };
 
@@ -490,9 +480,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvW
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     if (m_begin >= m_end) return;
     const int nkt = (m_end - m_begin + BF_BK - 1) / BF_BK;
-    LoaderWgradAb<BM> la;
+    LoaderWgradAt<BM> la;
     la.init(a, ci0, tap, m_begin, tid);
-    LoaderMNb<BN> lb;
+    LoaderMNt<BN> lb;
     lb.init(a.dy, a.Co, co0, a.Co, a.M, true, tid);
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -501,7 +491,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvW
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 ra[2 * LoaderWgradAb<BM>::NU], rb[2 * LoaderMNb<BN>::NU];
+    float4 ra[LoaderWgradAt<BM>::NU], rb[LoaderMNt<BN>::NU];
     la.load(a, m_end, ra);
     lb.load(m_begin, m_end, rb);
     la.store(sm.A[0], ra);
@@ -515,7 +505,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvW
             la.load(a, m_end, ra);
             lb.load(m_begin + (kt + 1) * BF_BK, m_end, rb);
         }
-        mma_ktile_bf16<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_bf16<BM, BN, WGM, WGN, true, true>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
@@ -799,7 +789,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
     if (d->compute == 1 && a.Cs % 32 == 0 && a.Cd % 32 == 0) {
-        if (force == 3 || (force == 0 && (a.Cd <= 64 || big < 128 || (dgrad && (a.Cd <= 128 || big < 512)))))
+        if (force == 3 || (force == 0 && (a.Cd <= 128 || big < 512)))   // measured: profiles/tune_bf16_r1d.txt
             launch_conv_bf16<64, 64, 2, 2>(a, dgrad, s);
         else launch_conv_bf16<128, 128, 2, 2>(a, dgrad, s);
     } else if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);

@@ -9,14 +9,12 @@
 // consecutive k of one row = one ds_read_b128; 80 B = 5 sixteen-byte slots per row and gcd(5,16) = 1, so the 16
 // lanes of every ds_read_b128 service group (distinct rows mod 16) hit 16 distinct slots: conflict free.
 //   * K-contiguous fp32 operand ([mn][k]): float4 global load -> 4 bf16 -> one ds_write_b64.
-//   * MN-contiguous fp32 operand ([k][mn], weight-gradient operands, Linear dgrad weights) in the GEMM kernels
-//     (LoaderMNt): the tile keeps its natural orientation in LDS, cut into [4 k][16 mn] sub-blocks of 128 B, and
+//   * MN-contiguous fp32 operand ([k][mn]: weight-gradient operands, Linear dgrad weights, HWIO conv kernels, the
+//     gathered pixels of the conv weight gradient) (LoaderMNt / LoaderWgradAt): the tile keeps its natural orientation in LDS, cut into [4 k][16 mn] sub-blocks of 128 B, and
 //     the MFMA fragments are fetched with ds_read_b64_tr_b16 (gfx950 transpose read: the 16 lanes of a group hand
 //     in the sixteen 8-byte chunks of one sub-block and lane c receives column c = 4 consecutive k of one row).
 //     Global loads are float4 along mn (256 B contiguous per k row and wave), the LDS write is one linear
 //     ds_write_b64 per float4 -- the same cost as the K-contiguous path; fragment = 2 tr reads.
-//   * conv kernels (LoaderMNb, weights / gathered pixels): each lane loads the float4 of TWO consecutive k rows
-//     and writes four packed (k, k+1) words to four LDS rows of the [row][k] image.
 #pragma once
 #include "gemm_core.h"
 
@@ -85,58 +83,6 @@ struct LoaderKb {
         for (int i = 0; i < NV; ++i) {
             const int row = (tid >> 3) + 32 * i;
             *reinterpret_cast<uint2 *>(&S[row][kq]) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
-        }
-    }
-};
-
-// fp32 operand stored [k][mn] (mn contiguous). Unit u = t + 256*i: k pair kp = u & 15, column group (u >> 4)*4.
-template <int BMN>
-struct LoaderMNb {
-    static constexpr int NU = BMN / 64;
-    BufSrc src;
-    unsigned ld4b;         // row stride in bytes
-    int mn0, MN;
-    bool vec;
-    int tid;
-
-    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, int K, bool vec_, int tid_,
-                                         long long extent_elems = 0) {
-        src.init(p, extent_elems > 0 ? extent_elems : (long long)(K - 1) * ld_ + MN_);
-        ld4b = (unsigned)(ld_ * 4); mn0 = mn0_; MN = MN_; vec = vec_; tid = tid_;
-    }
-    __device__ __forceinline__ void load(int k0, int K, float4 (&r)[2 * NU], unsigned base = 0) const {
-        unsigned o[2 * NU];
-        int nv[2 * NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + 256 * i;
-            const int k = k0 + 2 * (u & 15);
-            const int col = mn0 + (u >> 4) * 4;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                o[2 * i + h] = base + (unsigned)(k + h) * ld4b + 4u * (unsigned)col;
-                nv[2 * i + h] = k + h < K ? MN - col : 0;
-            }
-        }
-        if (vec) {
-#pragma unroll
-            for (int j = 0; j < 2 * NU; ++j) r[j] = src.ld4_vec(o[j], nv[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2 * NU; ++j) r[j] = src.ld4_scalar(o[j], nv[j]);
-        }
-    }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[2 * NU]) const {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + 256 * i;
-            const int kp = u & 15;
-            const int m4 = (u >> 4) * 4;
-            const float4 a = r[2 * i], b = r[2 * i + 1];
-            *reinterpret_cast<unsigned *>(&S[m4 + 0][2 * kp]) = pack_bf16(a.x, b.x);
-            *reinterpret_cast<unsigned *>(&S[m4 + 1][2 * kp]) = pack_bf16(a.y, b.y);
-            *reinterpret_cast<unsigned *>(&S[m4 + 2][2 * kp]) = pack_bf16(a.z, b.z);
-            *reinterpret_cast<unsigned *>(&S[m4 + 3][2 * kp]) = pack_bf16(a.w, b.w);
         }
     }
 };
