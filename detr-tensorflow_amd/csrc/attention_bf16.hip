@@ -1,34 +1,43 @@
-// attention_f32.hip -- fused multi-head attention core (head_dim 32, fp32) for gfx950:
-//     O = softmax(Q K^T) V        (Q is already scaled by 1/sqrt(32), transformer.py:307,317,340-343)
-// and its backward, flash-style: the [T, S] score / probability tensor (283 MB per encoder layer
-// at B=8, 800x1333) never touches HBM.  Layout: batch-first token matrices [B, T, heads*32]
-// (row stride ld floats); (batch, head) select a column block of 32.
-//
-// MFMA formulation (v_mfma_f32_32x32x2_f32, exact f32).  Everything is computed TRANSPOSED so that
-// the softmax row (one query) lives in ONE lane pair (l, l^32):
-//     S^T[key][query] = K_tile (A: rows = keys, LDS) x Q^T (B: per-lane registers)
-//   C/D map: lane l holds query (l&31) and the 16 keys  kr = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
-//   -> row max / row sum = 15 VALU ops + one cross-half shuffle (no LDS, no serial lanes).
-//     O^T[d][query]  += V^T (A: V[key][d] read row-wise from LDS) x P^T (B: the registers above;
-//   MFMA k-step r contracts the key pair {kr(hi=0), kr(hi=1)} which is exactly what the two lane
-//   halves hold in register r -- no data movement between QK^T and PV).
-// Softmax arithmetic: Q (or, in the dK/dV kernel, K) is pre-multiplied by log2(e) in registers so that every
-// exponential is one v_exp_f32 (exp2); LSE is stored in natural-log units.  The key-bound masks run only in the
-// last key tile (wave-uniform branch), and the dropout hash is evaluated once per PAIR of adjacent keys
-// (common.h drop_hash: 16 bits per element; element index = row * Sp + key, Sp = S rounded up to even).
-// K/V tiles: 32 keys x 32 dims row-major with row stride 33 dwords: conflict-free for both access
-// patterns (lanes over keys at fixed d, and lanes over d at fixed key).  Double-buffered
-// global->register->LDS pipeline, one barrier per key tile; 4 waves x 32 queries per workgroup.
+// attention_bf16.hip -- the fused attention core of attention_f32.hip with bf16 MFMA operands (precision="bf16",
+// BASELINE config C3): Q, K, V, P, dO and dS are rounded to bf16 (RNE) on their way into registers / LDS, the products
+// run on v_mfma_f32_32x32x16_bf16 (2 instructions per 32x32x32 product instead of 16 v_mfma_f32_32x32x2_f32), the
+// accumulation, the softmax statistics, LSE / delta and all outputs stay fp32.  Same transposed formulation:
+//     S^T[key][query] = K_tile (A: 8 consecutive d of a key row, ds_read_b128) x Q^T (B: per-lane registers)
+//   C/D map: lane l holds query (l&31) and the 16 keys krow(r, hi), hi = l>>5.
+//     O^T[d][query] += V^T (A) x P^T (B = the registers above, packed to bf16):  the k slot j (0..7) of k-step s2 of
+//   lane half hi is DEFINED as key 16*s2 + 4*hi + (j&3) + 8*(j>>2) -- exactly the keys the lane already holds in
+//   registers 8*s2 .. 8*s2+7 -- and the A operand follows: V stays [key][d] in LDS and ds_read_b64_tr_b16 (gfx950
+//   transpose read; the 16 lanes of a group hand in the 8-byte chunks of four arbitrary rows and lane c receives
+//   column c) gathers V[those four keys][d = lane's column].  No data movement between QK^T and PV, no V transpose.
+// The backward kernels reuse the same two fragment forms (row fragments for the score-type products, transpose-read
+// fragments for the gradient-type products).  Softmax arithmetic, masks and dropout as in attention_f32.hip.
 #include "attention_common.h"
 
 namespace detr {
 
-constexpr int AT_LD = 33;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// cooperative load of one 32 x 32 tile (rows row0.., zero filled past nrows) into registers / LDS by a workgroup of
-// NW waves: 256 float4 per tile, 4 / NW per thread
+constexpr int AB_LD = 40;        // bf16 per LDS tile row (80 B): 16-byte aligned rows, conflict-free ds_read_b128 fragments
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2 r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ bf16x8 pack8(const float *v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w;
+    w[0] = pk_bf16(v[0], v[1]); w[1] = pk_bf16(v[2], v[3]); w[2] = pk_bf16(v[4], v[5]); w[3] = pk_bf16(v[6], v[7]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// 32 x 32 fp32 tile -> bf16 LDS image [row][AB_LD], by a workgroup of NW waves (256 float4 per tile)
 template <int NW>
-struct Tile {
+struct TileB {
     static constexpr int LPT = 4 / NW;
     float4 v[LPT];
     __device__ __forceinline__ void load(const float *base, long long ld, int row0, int nrows, int tid) {
@@ -40,23 +49,42 @@ struct Tile {
             v[i] = (row < nrows) ? *reinterpret_cast<const float4 *>(base + (long long)row * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    __device__ __forceinline__ void store(float (*S)[AT_LD], int tid) const {
+    __device__ __forceinline__ void store(unsigned short (*S)[AB_LD], int tid, float scale = 1.0f) const {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int u = tid + 64 * NW * i;
             const int r = u >> 3, c = (u & 7) * 4;
-            S[r][c + 0] = v[i].x; S[r][c + 1] = v[i].y; S[r][c + 2] = v[i].z; S[r][c + 3] = v[i].w;
+            *reinterpret_cast<uint2 *>(&S[r][c]) =
+                make_uint2(pk_bf16(v[i].x * scale, v[i].y * scale), pk_bf16(v[i].z * scale, v[i].w * scale));
         }
     }
 };
+
+// row fragment: 8 consecutive columns (16*s + 8*hi ..) of tile row (lane & 31)
+__device__ __forceinline__ bf16x8 frag_row(const unsigned short (*S)[AB_LD], int s, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(&S[lane & 31][16 * s + 8 * (lane >> 5)]);
+}
+// transposed fragment for k-step s2: lane (column c = lane & 31 of the tile, half hi) receives the 8 tile rows
+// 16*s2 + 4*hi + {0,1,2,3, 8,9,10,11} of its column
+__device__ __forceinline__ bf16x8 frag_col(const unsigned short (*S)[AB_LD], int s2, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    const int row = 16 * s2 + 4 * (g >> 1) + (t >> 2);
+    const int col = 16 * (g & 1) + 4 * (t & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)&S[row][col]);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)&S[row + 8][col]);
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+#define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ float Ks[2][AT_KEYS][AT_LD];
-    __shared__ float Vs[2][AT_KEYS][AT_LD];
+__global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AT_KEYS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AT_KEYS][AB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -66,10 +94,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
     const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
 
-    float q[16];
+    bf16x8 qb[2];                 // B operand of QK^T: Q[tq][16 s + 8 hi ..], in log2 units
 #pragma unroll
-    for (int s = 0; s < 16; ++s) q[s] = qok ? Qb[(long long)tq * a.ld + 2 * s + hi] * AT_LOG2E : 0.0f;   // scores in log2 units
-
+    for (int s = 0; s < 2; ++s) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = qok ? Qb[(long long)tq * a.ld + 16 * s + 8 * hi + j] * AT_LOG2E : 0.0f;
+        qb[s] = pack8(t);
+    }
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
@@ -77,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
-    Tile<NW> rk, rv;
+    TileB<NW> rk, rv;
     rk.load(Kb, a.ld, 0, a.S, tid);
     rv.load(Vb, a.ld, 0, a.S, tid);
     rk.store(Ks[0], tid);
@@ -93,9 +125,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-        for (int st = 0; st < 16; ++st)
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][l31][2 * st + hi], q[st], s, 0, 0, 0);
+        s = MFMA_BF16(frag_row(Ks[cur], 0, lane), qb[0], s);
+        s = MFMA_BF16(frag_row(Ks[cur], 1, lane), qb[1], s);
         const int kbase = it * AT_KEYS;
         if (kbase + AT_KEYS > a.S) {                // ragged last tile only (wave-uniform)
 #pragma unroll
@@ -106,8 +137,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);              // finite: every tile holds at least one valid key
-        const float corr = fast_exp2(m - mn);       // exp2(-inf) = 0 on the first tile
+        const float mn = fmaxf(m, mx);
+        const float corr = fast_exp2(m - mn);
         float rs = 0.0f;
         float p[16];
 #pragma unroll
@@ -118,16 +149,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         rs += __shfl_xor(rs, 32, 64);
         lsum = lsum * corr + rs;
         m = mn;
-        if (a.drop_scale != 0.0f) {          // dropout on the attention probabilities (after normalisation == on p)
+        if (a.drop_scale != 0.0f) {
             const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][krow(r, hi)][l31], p[r], o, 0, 0, 0);
+        o = MFMA_BF16(frag_col(Vs[cur], 0, lane), pack8(p), o);
+        o = MFMA_BF16(frag_col(Vs[cur], 1, lane), pack8(p + 8), o);
         if (more) {
             rk.store(Ks[cur ^ 1], tid);
             rv.store(Vs[cur ^ 1], tid);
@@ -140,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         float *Ob = a.O + ((long long)b * a.T + tq) * a.ld + h * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
-        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);   // natural-log units
+        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);
     }
 }
 
@@ -148,9 +178,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 // backward 1/2: dQ (per query tile, streams the keys) and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ float Ks[2][AT_KEYS][AT_LD];
-    __shared__ float Vs[2][AT_KEYS][AT_LD];
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AT_KEYS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AT_KEYS][AB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -160,14 +190,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
     const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
 
-    float q[16], dout[16];
+    bf16x8 qb[2], dob[2];
     float dl = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        q[s] = qok ? a.Q[qoff + 2 * s + hi] * AT_LOG2E : 0.0f;      // scores in log2 units (q feeds only s)
-        dout[s] = qok ? a.dO[qoff + 2 * s + hi] : 0.0f;
-        const float ov = qok ? a.O[qoff + 2 * s + hi] : 0.0f;
-        dl += dout[s] * ov;
+    for (int s = 0; s < 2; ++s) {
+        float tqv[8], tdo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * s + 8 * hi + j;
+            tqv[j] = qok ? a.Q[qoff + d] * AT_LOG2E : 0.0f;
+            tdo[j] = qok ? a.dO[qoff + d] : 0.0f;
+            const float ov = qok ? a.O[qoff + d] : 0.0f;
+            dl += tdo[j] * ov;
+        }
+        qb[s] = pack8(tqv);
+        dob[s] = pack8(tdo);
     }
     dl += __shfl_xor(dl, 32, 64);
     const float lse = qok ? a.LSE[(long long)bh * a.T + tq] * AT_LOG2E : INFINITY;
@@ -179,7 +216,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
-    Tile<NW> rk, rv;
+    TileB<NW> rk, rv;
     rk.load(Kb, a.ld, 0, a.S, tid);
     rv.load(Vb, a.ld, 0, a.S, tid);
     rk.store(Ks[0], tid);
@@ -196,9 +233,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][l31][2 * st + hi], q[st], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][l31][2 * st + hi], dout[st], dp, 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+            s = MFMA_BF16(frag_row(Ks[cur], st, lane), qb[st], s);
+            dp = MFMA_BF16(frag_row(Vs[cur], st, lane), dob[st], dp);
         }
         const int kbase = it * AT_KEYS;
         float ds[16];
@@ -209,14 +246,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] - lse) * (dp[r] - dl);
-        if (kbase + AT_KEYS > a.S) {                // ragged last tile only: keys past S contribute nothing
+        if (kbase + AT_KEYS > a.S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kbase + krow(r, hi) >= a.S) ds[r] = 0.0f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][krow(r, hi)][l31], ds[r], dq, 0, 0, 0);
+        dq = MFMA_BF16(frag_col(Ks[cur], 0, lane), pack8(ds), dq);
+        dq = MFMA_BF16(frag_col(Ks[cur], 1, lane), pack8(ds + 8), dq);
         if (more) {
             rk.store(Ks[cur ^ 1], tid);
             rv.store(Vs[cur ^ 1], tid);
@@ -231,13 +267,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 2/2: dK, dV (per key tile, streams the queries; needs LSE and delta)
-// here the natural orientation is S[query][key]: lane l holds key (l&31) and 16 queries.
+// backward 2/2: dK, dV (per key tile, streams the queries): lane l holds key (l&31) and 16 queries krow(r, hi).
+// The Q tile is staged as bf16(Q * log2 e) -- the forward's rounded operand -- and K unscaled.
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ float Qs[2][AT_KEYS][AT_LD];
-    __shared__ float Ds[2][AT_KEYS][AT_LD];
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AT_KEYS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AT_KEYS][AB_LD];
     __shared__ float Ls[2][AT_KEYS], Dl[2][AT_KEYS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -251,27 +287,34 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const float *dlt = a.delta + (long long)bh * a.T;
     const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
-    float kk[16], vv[16];
+    bf16x8 kb[2], vb[2];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        kk[s] = kok ? a.K[koff + 2 * s + hi] * AT_LOG2E : 0.0f;     // scores in log2 units (kk feeds only s)
-        vv[s] = kok ? a.V[koff + 2 * s + hi] : 0.0f;
+    for (int s = 0; s < 2; ++s) {
+        float tk[8], tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * s + 8 * hi + j;
+            tk[j] = kok ? a.K[koff + d] : 0.0f;
+            tv[j] = kok ? a.V[koff + d] : 0.0f;
+        }
+        kb[s] = pack8(tk);
+        vb[s] = pack8(tv);
     }
     f32x16 dk, dv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.0f; dv[r] = 0.0f; }
 
     const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
-    Tile<NW> rq, rd;
+    TileB<NW> rq, rd;
     rq.load(Qb, a.ld, 0, a.T, tid);
     rd.load(Db, a.ld, 0, a.T, tid);
     float rl = 0.f, rdl = 0.f;
     if (tid < AT_KEYS) {
-        rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
+        rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;
         rdl = (tid < a.T) ? dlt[tid] : 0.0f;
     }
-    rq.store(Qs[0], tid);
-    rd.store(Ds[0], tid);
+    rq.store(Qs[0], tid, AT_LOG2E);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
+    rd.store(Ds[0], tid);                // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
     if (tid < AT_KEYS) { Ls[0][tid] = rl; Dl[0][tid] = rdl; }
     __syncthreads();
     int cur = 0;
@@ -290,9 +333,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[cur][l31][2 * st + hi], kk[st], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[cur][l31][2 * st + hi], vv[st], dp, 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+            s = MFMA_BF16(frag_row(Qs[cur], st, lane), kb[st], s);
+            dp = MFMA_BF16(frag_row(Ds[cur], st, lane), vb[st], dp);
         }
         float p[16], ds[16];
 #pragma unroll
@@ -310,13 +353,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = krow(r, hi);
-            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[cur][qr][l31], p[r], dv, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[cur][qr][l31], ds[r], dk, 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dv = MFMA_BF16(frag_col(Ds[cur], s2, lane), pack8(p + 8 * s2), dv);
+            dk = MFMA_BF16(frag_col(Qs[cur], s2, lane), pack8(ds + 8 * s2), dk);
         }
         if (more) {
-            rq.store(Qs[cur ^ 1], tid);
+            rq.store(Qs[cur ^ 1], tid, AT_LOG2E);
             rd.store(Ds[cur ^ 1], tid);
             if (tid < AT_KEYS) { Ls[cur ^ 1][tid] = rl; Dl[cur ^ 1][tid] = rdl; }
         }
@@ -326,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (kok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a.dK[koff + krow(r, hi)] = dk[r];
+            a.dK[koff + krow(r, hi)] = dk[r] * AT_LN2;
             a.dV[koff + krow(r, hi)] = dv[r];
         }
     }
@@ -336,9 +378,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 using namespace detr;
 
-extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                          uint32_t dropout_seed, void *stream) {
+extern "C" int detr_hip_attention_fwd_bf16c(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
+                                            int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
+                                            uint32_t dropout_seed, void *stream) {
     if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
     DETR_REQUIRE(o && lse, "attention fwd: null output");
     AttnArgs a = {};
@@ -346,16 +388,16 @@ extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const 
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
     if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
-    DETR_LAUNCH_CHECK("attention fwd");
+    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    DETR_LAUNCH_CHECK("attention fwd (bf16 MFMA)");
     return 0;
 }
 
-extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
-                                          const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                          uint32_t dropout_seed, void *stream) {
+extern "C" int detr_hip_attention_bwd_bf16c(const float *q, const float *k, const float *v, const float *o, const float *lse,
+                                            const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
+                                            int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
+                                            uint32_t dropout_seed, void *stream) {
     if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
     DETR_REQUIRE(o && lse && d_o && dq && dk && dv && delta, "attention bwd: null operand");
     DETR_REQUIRE(aligned16(d_o), "attention bwd: dO must be 16-byte aligned");
@@ -365,11 +407,11 @@ extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const 
     a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
     if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
-    DETR_LAUNCH_CHECK("attention bwd dq");
-    if (attn_waves(S, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3((unsigned)cdiv(S, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((unsigned)cdiv(S, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
-    DETR_LAUNCH_CHECK("attention bwd dkv");
+    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    DETR_LAUNCH_CHECK("attention bwd dq (bf16 MFMA)");
+    if (attn_waves(S, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, dim3((unsigned)cdiv(S, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, dim3((unsigned)cdiv(S, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    DETR_LAUNCH_CHECK("attention bwd dkv (bf16 MFMA)");
     return 0;
 }

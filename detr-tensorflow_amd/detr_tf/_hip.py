@@ -70,6 +70,9 @@ _SIGNATURES = {
     "detr_hip_attention_fwd_f32": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,
                                    ctypes.c_uint32, c_void_p],
     "detr_hip_attention_bwd_f32": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_float, ctypes.c_uint32, c_void_p],
+    "detr_hip_attention_fwd_bf16c": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,
+                                   ctypes.c_uint32, c_void_p],
+    "detr_hip_attention_bwd_bf16c": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_float, ctypes.c_uint32, c_void_p],
     "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],

@@ -174,7 +174,7 @@ class DetrEngine:
             # fused flash-style core: the [T,S] probabilities never reach HBM (csrc/attention_f32.hip)
             lse = self.buf(f"{tag}:lse", (BH, T))
             dp, dbase = self._drop
-            hip.call("detr_hip_attention_fwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(), lse.data_ptr(),
+            hip.call("detr_hip_attention_fwd_bf16c" if hip.COMPUTE_BF16 else "detr_hip_attention_fwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(), lse.data_ptr(),
                      B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)        # :317,:340,:341,:343
         else:
             Sp = (S + 3) // 4 * 4
@@ -210,7 +210,7 @@ class DetrEngine:
         dQ, dK, dV = self.buf("scratch:dQ", (B * T, D)), self.buf("scratch:dK", (B * S, D)), self.buf("scratch:dV", (B * S, D))
         if FUSED_ATTENTION:
             delta = self.buf("scratch:attn_delta", (BH, T))
-            hip.call("detr_hip_attention_bwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(),
+            hip.call("detr_hip_attention_bwd_bf16c" if hip.COMPUTE_BF16 else "detr_hip_attention_bwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(),
                      self._bufs[f"{tag}:lse"].data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
                      delta.data_ptr(), B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)
         else:

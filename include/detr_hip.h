@@ -187,7 +187,17 @@ int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, c
                                const float *d_o, float *dq, float *dk, float *dv, float *delta,
                                int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
                                float dropout_p, uint32_t dropout_seed, void *stream);
-/* attention-probability dropout (transformer.py:341): element index ((b*H + h)*T + t)*S + s of `dropout_seed` */
+/* attention-probability dropout (transformer.py:341): element index ((b*H + h)*T + t)*Sp + s of `dropout_seed`,
+ * Sp = S rounded up to even (one counter hash per pair of adjacent keys, common.h) */
+/* The same two entry points with bf16 MFMA operands (precision="bf16", BASELINE config C3): Q, K, V, P, dO and dS are
+ * rounded to bf16, accumulation / softmax statistics / LSE / delta / outputs stay fp32 (csrc/attention_bf16.hip). */
+int detr_hip_attention_fwd_bf16c(const float *q, const float *k, const float *v, float *o, float *lse,
+                                 int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
+                                 float dropout_p, uint32_t dropout_seed, void *stream);
+int detr_hip_attention_bwd_bf16c(const float *q, const float *k, const float *v, const float *o, const float *lse,
+                                 const float *d_o, float *dq, float *dk, float *dv, float *delta,
+                                 int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
+                                 float dropout_p, uint32_t dropout_seed, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,

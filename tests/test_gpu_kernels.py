@@ -220,6 +220,43 @@ def test_fused_attention_fwd_bwd(hip, B, T, S):
     close(dv, v.grad, rtol=5e-5, what="attention dv")
 
 
+@pytest.mark.parametrize("B,T,S,p", [(2, 1050, 1050, 0.0), (2, 100, 1050, 0.1), (3, 100, 100, 0.0), (1, 37, 5, 0.0),
+                                     (1, 300, 1344, 0.0), (2, 70, 333, 0.1)])
+def test_fused_attention_bf16_mfma(hip, B, T, S, p):
+    """bf16-MFMA attention core (precision="bf16"): Q, K, V, P, dO, dS rounded to bf16, everything else fp32.  Checked
+    against the fp64 reference (with the hash dropout masks of the oracle when p > 0) at bf16-level tolerances; the
+    transposed-fragment paths (ds_read_b64_tr_b16) would be off by O(1) if a row / column mapping were wrong."""
+    from oracle import dropout_ref as DR
+    torch.manual_seed(B * 77 + T + S)
+    H, hd, seed = 8, 32, 991
+    D = H * hd
+    q = (torch.randn(B, T, D, dtype=torch.float64) * 0.6).requires_grad_(True)
+    k = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    v = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2)
+    w = torch.softmax(sc, dim=-1)
+    if p > 0.0:
+        keep = torch.from_numpy(DR.keep_mask(seed, DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
+        w = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
+    o = (w @ vh).transpose(1, 2).reshape(B, T, D)
+    do = torch.randn(B, T, D, dtype=torch.float64)
+    o.backward(do)
+    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
+    od, lse = torch.full((B, T, D), 7.0, device=DEV), torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_fwd_bf16c", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
+             T, S, D, ctypes.c_float(p), seed)
+    close(od, o, rtol=1.5e-2, what="bf16 attention fwd")
+    close(lse.view(B, H, T), torch.logsumexp(sc, dim=-1), rtol=3e-3, what="bf16 attention lse")
+    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    delta = torch.zeros(B * H, T, device=DEV)
+    hip.call("detr_hip_attention_bwd_bf16c", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
+             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(p), seed)
+    close(dq, q.grad, rtol=2e-2, what="bf16 attention dq")
+    close(dk, k.grad, rtol=2e-2, what="bf16 attention dk")
+    close(dv, v.grad, rtol=2e-2, what="bf16 attention dv")
+
+
 def test_linear_helpers(hip):
     torch.manual_seed(5)
     M, K, N = 420, 256, 92
