@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, float *__restrict__ dx,
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                            int rows, int C) {
+                                                            int rows, int C, float *__restrict__ partial) {
     __shared__ float red[2][4][64 * LN_MAXV * 4 / 4];  // [gamma|beta][wave][C] ; C <= 1024 -> see below
     // (partial sums are kept per lane in registers and reduced through LDS at the end)
     const int lane = threadIdx.x & 63;
@@ -142,11 +142,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                     sg += rg[w * 256 + lane * 4 + e];
                     sb += rb[w * 256 + lane * 4 + e];
                 }
-                unsafeAtomicAdd(dgamma + j * 4 + e, sg);
-                unsafeAtomicAdd(dbeta + j * 4 + e, sb);
+                if (partial) {      // deterministic: per-block partials, summed in block order by the finish kernel
+                    partial[(long long)blockIdx.x * 2 * C + j * 4 + e] = sg;
+                    partial[(long long)blockIdx.x * 2 * C + C + j * 4 + e] = sb;
+                } else {
+                    unsafeAtomicAdd(dgamma + j * 4 + e, sg);
+                    unsafeAtomicAdd(dbeta + j * 4 + e, sb);
+                }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float *__restrict__ partial, int nblk, int C,
+                                                                   float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[(long long)(b + 0) * 2 * C + c];
+        s1 += partial[(long long)(b + 1) * 2 * C + c];
+        s2 += partial[(long long)(b + 2) * 2 * C + c];
+        s3 += partial[(long long)(b + 3) * 2 * C + c];
+    }
+    for (; b < nblk; ++b) s0 += partial[(long long)b * 2 * C + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (c < C) dgamma[c] += s;
+    else dbeta[c - C] += s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -363,14 +386,22 @@ extern "C" int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, co
 
 extern "C" int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
                                           const float *rstd, float *dx, float *dgamma, float *dbeta, int32_t rows,
-                                          int32_t C, void *stream) {
+                                          int32_t C, float *workspace, int64_t workspace_bytes, void *stream) {
     DETR_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm bwd: null operand");
     DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm bwd: C=%d rows=%d unsupported", C, rows);
     DETR_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma), "layernorm bwd: alignment");
-    const int grid = min(cdiv(rows, 16), 512);
+    const int grid = min(cdiv(rows, 8), 512);
+    // with a workspace of grid*2*C floats the gamma / beta gradients are reduced deterministically (per-block partials +
+    // a finish launch); without one they are accumulated with fp32 atomics
+    float *partial = (workspace && workspace_bytes >= (long long)grid * 2 * C * 4) ? workspace : nullptr;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C);
+                       dgamma, dbeta, rows, C, partial);
     DETR_LAUNCH_CHECK("layernorm bwd");
+    if (partial) {
+        hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, grid,
+                           C, dgamma, dbeta);
+        DETR_LAUNCH_CHECK("layernorm bwd finish");
+    }
     return 0;
 }
 

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "detr_hip_subsample2_fwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_subsample2_bwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_layernorm_fwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_float, c_void_p],
-    "detr_hip_layernorm_bwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_void_p],
+    "detr_hip_layernorm_bwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, f32p, c_int64, c_void_p],
     "detr_hip_softmax_rows_fwd_f32": [f32p, c_int64, c_int32, c_int64, c_void_p],
     "detr_hip_softmax_rows_bwd_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_void_p],
     "detr_hip_attention_fwd_f32": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,

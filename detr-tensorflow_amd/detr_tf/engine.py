@@ -112,18 +112,12 @@ class DetrEngine:
 
     def _conv1x1_fwd(self, x, M, cin, cout, conv_name, bn_name, out, residual=None, act=1):
         """1x1 conv + frozen BN (+ residual) (+ ReLU) as one GEMM (resnet_backbone.py:119-121,128-135).
-        fp32 mode: B = scaled kernel [cin][cout] (N contiguous).  bf16 mode: a transposed scaled copy
-        [cout][cin] keeps BOTH operands K-contiguous (128-byte row segments: measured 1.5x faster loads)."""
+        B = scaled kernel [cin][cout] (N contiguous; in bf16 mode it is staged as a transpose-read LDS image, which
+        made the former transposed weight copy unnecessary)."""
         ws = self._scaled_kernel(conv_name, bn_name)
         shift = self.bn_shift[bn_name]
         ldr = cout if residual is not None else 0
-        if self.compute == 1:
-            wst = self.buf(f"wst:{conv_name}", (cout, cin))
-            if self.weights_dirty:
-                hip.call("detr_hip_scale_cols_t_f32", ws.data_ptr(), None, wst.data_ptr(), cin, cout)
-            hip.gemm(M, cout, cin, x, cin, 1, wst, cin, 1, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
-        else:
-            hip.gemm(M, cout, cin, x, cin, 1, ws, cout, 0, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
+        hip.gemm(M, cout, cin, x, cin, 1, ws, cout, 0, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
 
     # ---- small helpers ----------------------------------------------------------------------------
     @staticmethod
@@ -151,7 +145,8 @@ class DetrEngine:
         rows = x.shape[0]
         hip.call("detr_hip_layernorm_bwd_f32", dy.data_ptr(), x.data_ptr(), self.P.views[f"{pfx}/gamma"].data_ptr(),
                  self._bufs[f"{tag}:mean"].data_ptr(), self._bufs[f"{tag}:rstd"].data_ptr(), dx.data_ptr(),
-                 self.P.gviews[f"{pfx}/gamma"].data_ptr(), self.P.gviews[f"{pfx}/beta"].data_ptr(), rows, D)
+                 self.P.gviews[f"{pfx}/gamma"].data_ptr(), self.P.gviews[f"{pfx}/beta"].data_ptr(), rows, D,
+                 hip.WORKSPACE.data_ptr(), hip.WORKSPACE.numel() * 4)        # deterministic gamma / beta reduction
 
     def _add(self, a, b, out):
         hip.call("detr_hip_add_f32", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())

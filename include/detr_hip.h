@@ -141,10 +141,11 @@ int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H
  * ------------------------------------------------------------------------------------------- */
 int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, float *y,
                                float *mean, float *rstd, int32_t rows, int32_t C, float eps, void *stream);
-/* dgamma/dbeta are ACCUMULATED (atomic) */
+/* dgamma/dbeta are ACCUMULATED: deterministically (per-block partials in `workspace` + a finish launch) when the
+ * workspace holds at least 512*2*C floats, with fp32 atomics otherwise (workspace may be NULL) */
 int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
                                const float *rstd, float *dx, float *dgamma, float *dbeta,
-                               int32_t rows, int32_t C, void *stream);
+                               int32_t rows, int32_t C, float *workspace, int64_t workspace_bytes, void *stream);
 int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream);
 /* ds = p * (dp - sum(dp*p)), written over dp */
 int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,

@@ -382,10 +382,20 @@ def test_layernorm_fwd_bwd(hip, rows, C):
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dyd = g(dy.float())
     hip.call("detr_hip_layernorm_bwd_f32", dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
-             rstd.data_ptr(), dxd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C)
+             rstd.data_ptr(), dxd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, None, 0)      # atomic fallback
     close(dxd, x.grad, rtol=2e-5, what="layernorm dx")
     close(dg, gam.grad, rtol=5e-5, what="layernorm dgamma")
     close(db, bet.grad, rtol=5e-5, what="layernorm dbeta")
+    ws = torch.empty(512 * 2 * C, device=DEV)                                     # deterministic workspace path
+    res = []
+    for rep in range(2):
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        hip.call("detr_hip_layernorm_bwd_f32", dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
+                 rstd.data_ptr(), dxd.data_ptr(), dg2.data_ptr(), db2.data_ptr(), rows, C, ws.data_ptr(), ws.numel() * 4)
+        res.append((dg2, db2))
+    close(res[0][0], gam.grad, rtol=5e-5, what="layernorm dgamma (workspace)")
+    close(res[0][1], bet.grad, rtol=5e-5, what="layernorm dbeta (workspace)")
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize("rows,cols,ld", [(640, 1050, 1052), (64, 100, 100), (10, 7, 8), (33, 1344, 1344)])
