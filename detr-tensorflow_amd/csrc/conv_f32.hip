@@ -23,7 +23,22 @@ struct ConvArgs {
     float *dst;
     int tiles_m, tiles_n;
     EpiArgs e;
+    // stride-2 dgrad, one launch per destination-pixel parity class (ph, pw): rows = (n, h2, w2) with h = 2*h2 + ph,
+    // w = 2*w2 + pw; only the taps with kh = kh0 (+2), kw = kw0 (+2) contribute (1, 2, 2 or 4 of the 9), so the classes
+    // together do 9/4 tap-GEMMs per pixel instead of 9 with 3/4 of the rows masked.
+    int par_on, Hp, Wp, ph, pw, kh0, kw0, nth, ntw;
 };
+
+// tap (kh, kw) of K-tile group t (t-th tap of the launch)
+__device__ __forceinline__ void conv_tap(const ConvArgs &a, int t, int &kh, int &kw) {
+    if (a.par_on) {
+        kh = a.kh0 + 2 * (t / a.ntw);
+        kw = a.kw0 + 2 * (t - (t / a.ntw) * a.ntw);
+    } else {
+        kh = t / 3;
+        kw = t - kh * 3;
+    }
+}
 
 template <int BM, bool DGRAD>
 struct LoaderConvA {
@@ -42,10 +57,18 @@ struct LoaderConvA {
             const int m = m0 + (tid >> 2) + 64 * i;
             ok[i] = m < a.M;
             const int mm = ok[i] ? m : 0;
-            const int wd = mm % a.Wd;
-            const int t = mm / a.Wd;
-            const int hd = t % a.Hd;
-            n_[i] = t / a.Hd;
+            int wd, hd;
+            if (DGRAD && a.par_on) {
+                const int t = mm / a.Wp;
+                wd = 2 * (mm - t * a.Wp) + a.pw;
+                hd = 2 * (t % a.Hp) + a.ph;
+                n_[i] = t / a.Hp;
+            } else {
+                wd = mm % a.Wd;
+                const int t = mm / a.Wd;
+                hd = t % a.Hd;
+                n_[i] = t / a.Hd;
+            }
             h_[i] = DGRAD ? hd + a.pad : hd * a.stride - a.pad;
             w_[i] = DGRAD ? wd + a.pad : wd * a.stride - a.pad;
         }
@@ -54,7 +77,8 @@ struct LoaderConvA {
     __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * GEMM_BK + kq;
-        const int kh = tap / 3, kw = tap - kh * 3;
+        int kh, kw;
+        conv_tap(a, tap, kh, kw);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int hs, ws;
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int cpt = a.Cs / GEMM_BK;  // K tiles per tap
-    const int nkt = 9 * cpt;
+    const int nkt = (a.par_on ? a.nth * a.ntw : 9) * cpt;
     const long long tapstride = (long long)a.Ci * a.Co;
 
     LoaderConvA<BM, DGRAD> la;
@@ -127,7 +151,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     float4 ra[LoaderConvA<BM, DGRAD>::NV], rb[LB::NV];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
-        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb, (unsigned)(tap * tapstride * 4));
+        int kh, kw;
+        conv_tap(a, tap, kh, kw);
+        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * 4));
     };
     la.load(a, 0, cpt, ra);
     load_b(0);
@@ -312,10 +338,18 @@ struct LoaderConvAb {
             const int m = m0 + (tid >> 3) + 32 * i;
             ok[i] = m < a.M;
             const int mm = ok[i] ? m : 0;
-            const int wd = mm % a.Wd;
-            const int t = mm / a.Wd;
-            const int hd = t % a.Hd;
-            n_[i] = t / a.Hd;
+            int wd, hd;
+            if (DGRAD && a.par_on) {
+                const int t = mm / a.Wp;
+                wd = 2 * (mm - t * a.Wp) + a.pw;
+                hd = 2 * (t % a.Hp) + a.ph;
+                n_[i] = t / a.Hp;
+            } else {
+                wd = mm % a.Wd;
+                const int t = mm / a.Wd;
+                hd = t % a.Hd;
+                n_[i] = t / a.Hd;
+            }
             h_[i] = DGRAD ? hd + a.pad : hd * a.stride - a.pad;
             w_[i] = DGRAD ? wd + a.pad : wd * a.stride - a.pad;
         }
@@ -324,7 +358,8 @@ struct LoaderConvAb {
     __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BF_BK + kq;
-        const int kh = tap / 3, kw = tap - kh * 3;
+        int kh, kw;
+        conv_tap(a, tap, kh, kw);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int hs, ws;
@@ -370,7 +405,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     const int tn = id % a.tiles_n, tm = id / a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int cpt = a.Cs / BF_BK;
-    const int nkt = 9 * cpt;
+    const int nkt = (a.par_on ? a.nth * a.ntw : 9) * cpt;
     const long long tapstride = (long long)a.Ci * a.Co;
     LoaderConvAb<BM, DGRAD> la;
     la.init(a, m0, tid);
@@ -388,7 +423,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a)
     float4 ra[LoaderConvAb<BM, DGRAD>::NV], rb[NRB];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
-        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)(tap * tapstride * 4));
+        int kh, kw;
+        conv_tap(a, tap, kh, kw);
+        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * 4));
     };
     la.load(a, 0, cpt, ra);
     load_b(0);
@@ -785,19 +822,37 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.ldr = a.Cd;
     e.ldmask = a.Cd;
     a.e = e;
+    a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
     const bool dgrad = mode == 1;
-    const long long big = (long long)cdiv(a.M, 128) * cdiv(a.Cd, 128);
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
-    if (d->compute == 1 && a.Cs % 32 == 0 && a.Cd % 32 == 0) {
-        if (force == 3 || (force == 0 && (a.Cd <= 128 || big < 512)))   // measured: profiles/tune_bf16_r1d.txt
-            launch_conv_bf16<64, 64, 2, 2>(a, dgrad, s);
-        else launch_conv_bf16<128, 128, 2, 2>(a, dgrad, s);
-    } else if (force == 1) launch_conv<128, 128, 2, 2>(a, dgrad, s);
-    else if (force == 2) launch_conv<128, 64, 2, 2>(a, dgrad, s);
-    else if (force == 3) launch_conv<64, 64, 2, 2>(a, dgrad, s);
-    else {
-        (void)big;   // 64x64 measured best on every backbone shape (profiles/tune_r1.txt)
-        launch_conv<64, 64, 2, 2>(a, dgrad, s);
+    auto launch = [&](const ConvArgs &c) {
+        const long long big = (long long)cdiv(c.M, 128) * cdiv(c.Cd, 128);
+        if (d->compute == 1 && c.Cs % 32 == 0 && c.Cd % 32 == 0) {
+            if (force == 3 || (force == 0 && (c.Cd <= 128 || big < 512)))   // measured: profiles/tune_bf16_r1d.txt
+                launch_conv_bf16<64, 64, 2, 2>(c, dgrad, s);
+            else launch_conv_bf16<128, 128, 2, 2>(c, dgrad, s);
+        } else if (force == 1) launch_conv<128, 128, 2, 2>(c, dgrad, s);
+        else if (force == 2) launch_conv<128, 64, 2, 2>(c, dgrad, s);
+        else launch_conv<64, 64, 2, 2>(c, dgrad, s);   // 64x64 measured best on every backbone shape (profiles/tune_r1.txt)
+    };
+    if (dgrad && d->stride == 2 && env_tile("DETR_HIP_DGRAD_S2_CLASSES") != 2) {
+        // one launch per destination-pixel parity class: 1 + 2 + 2 + 4 tap-GEMMs instead of 9 with 3/4 of the rows masked
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                ConvArgs c = a;
+                c.par_on = 1; c.ph = ph; c.pw = pw;
+                c.Hp = (a.Hd + 1 - ph) / 2;
+                c.Wp = (a.Wd + 1 - pw) / 2;
+                c.M = d->N * c.Hp * c.Wp;
+                if (c.M <= 0) continue;
+                c.kh0 = (ph + d->pad) & 1; c.kw0 = (pw + d->pad) & 1;
+                c.nth = c.kh0 ? 1 : 2; c.ntw = c.kw0 ? 1 : 2;
+                c.e.remap_w2 = c.Wp; c.e.remap_h2 = c.Hp; c.e.remap_W = a.Wd; c.e.remap_H = a.Hd;
+                c.e.remap_ph = ph; c.e.remap_pw = pw;
+                launch(c);
+            }
+    } else {
+        launch(a);
     }
     DETR_LAUNCH_CHECK("conv3x3");
     return 0;

@@ -40,6 +40,10 @@ struct EpiArgs {
     float drop_scale;        // 1/(1-p), 0 = no dropout; element index = row * N + col
     uint32_t drop_thresh;    // p * 2^24
     uint32_t drop_seed;
+    // optional output-row remap (stride-2 conv dgrad, one launch per pixel-parity class): GEMM row r of the class
+    // (n, h2, w2) addresses pixel (n, 2*h2 + remap_ph, 2*w2 + remap_pw) of the [.., remap_H, remap_W, N] tensors
+    // C / residual / mask.  remap_w2 == 0: identity.
+    int remap_w2 = 0, remap_h2 = 0, remap_W = 0, remap_H = 0, remap_ph = 0, remap_pw = 0;
 };
 
 template <int BM, int BN, int WGN>
@@ -319,16 +323,22 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
             const int col = colbase + c4;
             if (row >= M || col >= N) continue;
             const float4 a = *reinterpret_cast<const float4 *>(stage + rl * S::LD + c4);
-            float *dst = C + (long long)row * ldc + col;
+            long long prow = row;
+            if (e.remap_w2 > 0) {
+                const int w2 = row % e.remap_w2, t2 = row / e.remap_w2;
+                const int h2 = t2 % e.remap_h2, n2 = t2 / e.remap_h2;
+                prow = ((long long)n2 * e.remap_H + 2 * h2 + e.remap_ph) * e.remap_W + 2 * w2 + e.remap_pw;
+            }
+            float *dst = C + prow * ldc + col;
             if (e.vec && col + 3 < N) {
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (e.scale) sc = *reinterpret_cast<const float4 *>(e.scale + col);
                 if (e.bias) bi = *reinterpret_cast<const float4 *>(e.bias + col);
-                if (e.residual) rs = *reinterpret_cast<const float4 *>(e.residual + (long long)row * e.ldr + col);
-                if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + (long long)row * e.ldmask + col);
+                if (e.residual) rs = *reinterpret_cast<const float4 *>(e.residual + prow * e.ldr + col);
+                if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + prow * e.ldmask + col);
                 float4 o;
-                const unsigned long long di = (unsigned long long)row * N + col;
+                const unsigned long long di = (unsigned long long)prow * N + col;
                 o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x, di);
                 o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y, di + 1);
                 o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z, di + 2);
@@ -348,9 +358,9 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                     if (col + j < N) {
                         const float sc = e.scale ? e.scale[col + j] : 1.0f;
                         const float bi = e.bias ? e.bias[col + j] : 0.0f;
-                        const float rs = e.residual ? e.residual[(long long)row * e.ldr + col + j] : 0.0f;
-                        const float mk = e.mask ? e.mask[(long long)row * e.ldmask + col + j] : 1.0f;
-                        const float o = epi_one(av[j], sc, bi, e, rs, mk, (unsigned long long)row * N + col + j);
+                        const float rs = e.residual ? e.residual[prow * e.ldr + col + j] : 0.0f;
+                        const float mk = e.mask ? e.mask[prow * e.ldmask + col + j] : 1.0f;
+                        const float o = epi_one(av[j], sc, bi, e, rs, mk, (unsigned long long)prow * N + col + j);
                         if (e.atomic) unsafeAtomicAdd(dst + j, o);
                         else dst[j] = o;
                     }

@@ -154,22 +154,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float *__restrict__ partial, int nblk, int C,
-                                                                   float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * C) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += partial[(long long)(b + 0) * 2 * C + c];
-        s1 += partial[(long long)(b + 1) * 2 * C + c];
-        s2 += partial[(long long)(b + 2) * 2 * C + c];
-        s3 += partial[(long long)(b + 3) * 2 * C + c];
+// 64 columns x 16 row-partitions per block: every thread sums nblk/16 partials (independent loads), the partitions are
+// combined through LDS in a fixed order
+__global__ __launch_bounds__(1024) void layernorm_bwd_finish_kernel(const float *__restrict__ partial, int nblk, int C,
+                                                                    float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < 2 * C)
+        for (int b = part; b < nblk; b += 16) s += partial[(long long)b * 2 * C + c];
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && c < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        if (c < C) dgamma[c] += t;
+        else dbeta[c - C] += t;
     }
-    for (; b < nblk; ++b) s0 += partial[(long long)b * 2 * C + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (c < C) dgamma[c] += s;
-    else dbeta[c - C] += s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,7 +401,7 @@ extern "C" int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const
                        dgamma, dbeta, rows, C, partial);
     DETR_LAUNCH_CHECK("layernorm bwd");
     if (partial) {
-        hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, grid,
+        hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, grid,
                            C, dgamma, dbeta);
         DETR_LAUNCH_CHECK("layernorm bwd finish");
     }
