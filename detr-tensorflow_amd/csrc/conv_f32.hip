@@ -395,7 +395,7 @@ struct LoaderConvAb {
 };
 
 template <int BM, int BN, int WGM, int WGN, bool DGRAD>
-__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_bf16c_kernel(ConvArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_bf16c_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
     BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
@@ -504,7 +504,7 @@ struct LoaderWgradAt {
 };
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_bf16c_kernel(ConvWgradArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_wgrad_bf16c_kernel(ConvWgradArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
     BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);

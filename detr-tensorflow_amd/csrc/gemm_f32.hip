@@ -138,7 +138,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
 
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
     BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
