@@ -34,6 +34,14 @@ class GemmDesc(Structure):
                 ("rowsum_a", c_void_p), ("rowsum_alpha", c_float)]
 
 
+class StemDesc(Structure):
+    _fields_ = [("N", c_int32), ("H", c_int32), ("W", c_int32), ("Ho", c_int32), ("Wo", c_int32),
+                ("img", c_void_p), ("w", c_void_p), ("y", c_void_p),
+                ("alpha", c_float), ("scale", c_void_p), ("bias", c_void_p),
+                ("act", c_int32), ("split", c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32)]
+
+
 class Conv3x3Desc(Structure):
     _fields_ = [("N", c_int32), ("Hi", c_int32), ("Wi", c_int32), ("Ci", c_int32),
                 ("Ho", c_int32), ("Wo", c_int32), ("Co", c_int32), ("stride", c_int32), ("pad", c_int32),
@@ -58,6 +66,7 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
+    "detr_hip_stem_conv7x7_f32": [POINTER(StemDesc), c_int32, c_void_p],
     "detr_hip_stem_im2col_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_f32": [f32p, f32p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_f32": [f32p, c_void_p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
@@ -292,6 +301,24 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
         PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0,
                      f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}",
                      4.0 * (N * Hi * Wi * Ci + N * Ho * Wo * Co + 9 * Ci * Co + (rows * (Ci if mode == 1 else Co) if mask is not None else 0)))
+
+
+def stem_conv(mode, img, w, y, N, H, W, Ho, Wo, *, alpha=1.0, scale=None, bias=None, act=0, split=0, compute=None):
+    """Implicit-GEMM stem convolution (include/detr_hip.h detr_stem_desc): mode 0 forward, mode 2 weight gradient
+    (w = dy, y = dw accumulated)."""
+    d = StemDesc()
+    d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+    d.img, d.w, d.y = img.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.alpha = alpha
+    d.scale, d.bias = ptr(scale), ptr(bias)
+    d.act, d.split = act, split
+    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
+    d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    _check(load().detr_hip_stem_conv7x7_f32(byref(d), mode, _stream()), "detr_hip_stem_conv7x7_f32")
+    if ev0 is not None:
+        M = N * Ho * Wo
+        PROFILER.end("gemm_f32", 2.0 * M * 64 * 147, ev0, f"stem7x7 mode{mode} M{M}", 4.0 * (N * H * W * 3 + M * 64 + 147 * 64))
 
 
 def call(name, *args):

@@ -30,6 +30,8 @@ HD = 32
 FF = 2048
 BN_EPS = 1e-5
 LN_EPS = 1e-5
+# implicit-GEMM stem convolution (default) vs the im2col buffer + GEMM path (DETR_HIP_IMPLICIT_STEM=0)
+IMPLICIT_STEM = os.environ.get("DETR_HIP_IMPLICIT_STEM", "1") != "0"
 # fused flash-style attention (default) vs the materialised GEMM + softmax + GEMM path (DETR_HIP_FUSED_ATTN=0)
 FUSED_ATTENTION = os.environ.get("DETR_HIP_FUSED_ATTN", "1") != "0"
 
@@ -288,11 +290,14 @@ class DetrEngine:
         # ---------------- stem (resnet_backbone.py:11-26) ----------------
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         M1 = B * H1 * W1
-        col = self.buf("stem:col", (M1, 160))
-        hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
         ws = self._scaled_kernel("backbone/conv1/kernel", "backbone/bn1")
         stem = self.buf("stem:out", (B, H1, W1, 64))
-        hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift["backbone/bn1"], act=1)
+        if IMPLICIT_STEM:       # implicit GEMM: the 7x7x3 patches are gathered from the image by the A loader (stem_conv.hip)
+            hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift["backbone/bn1"], act=1)
+        else:                   # im2col buffer + GEMM (DETR_HIP_IMPLICIT_STEM=0)
+            col = self.buf("stem:col", (M1, 160))
+            hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
+            hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift["backbone/bn1"], act=1)
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         pool = self.buf("stem:pool", (B, H2, W2, 64))
         amax = self.buf("stem:amax", (B, H2, W2, 64), torch.uint8)
@@ -579,13 +584,18 @@ class DetrEngine:
                 elif p == "backbone/layer3/0":
                     on_bucket(2)
         # ---------------- stem ----------------
-        stem, pool, amax, col = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax", "col"))
+        stem, pool, amax = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax"))
         H1, W1 = stem.shape[1], stem.shape[2]
         H2, W2 = pool.shape[1], pool.shape[2]
         d_stem = self.buf("scratch:d_stem", stem.shape)
         hip.call("detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(), amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1,
                  W1, 64, H2, W2)
-        self._wgrad(147, 64, B * H1 * W1, col, 160, d_stem, 64, G["backbone/conv1/kernel"], 64,
-                    scale=self.bn_scale["backbone/bn1"])
+        if IMPLICIT_STEM:
+            M1 = B * H1 * W1
+            hip.stem_conv(2, self.images, d_stem, G["backbone/conv1/kernel"], B, self._shape[1], self._shape[2], H1, W1,
+                          scale=self.bn_scale["backbone/bn1"], split=max(1, min(512, M1 // 4096)))
+        else:
+            self._wgrad(147, 64, B * H1 * W1, self._bufs["stem:col"], 160, d_stem, 64, G["backbone/conv1/kernel"], 64,
+                        scale=self.bn_scale["backbone/bn1"])
         if on_bucket:
             on_bucket(3)

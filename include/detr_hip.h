@@ -120,6 +120,26 @@ int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream)
  * ------------------------------------------------------------------------------------------- */
 int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W,
                              int32_t Ho, int32_t Wo, int32_t ldcol, void *stream);
+
+/* The stem convolution as an IMPLICIT GEMM (no im2col buffer): ZeroPadding2D(3) + 7x7 stride-2 VALID conv 3 -> 64
+ * (+ folded frozen BN + ReLU), resnet_backbone.py:11-26.   mode 0: y[M,64] = act((gather(img) @ w[147][64]) * scale + bias) * ...
+ * with the GEMM epilogue order of detr_gemm_desc; mode 2 (weight gradient): w = dy [M,64], y = dw [147][64],
+ * dw += alpha * scale[co] * sum_m gather(img)[m][k] * dy[m][co], reduction split over `split` workgroups through
+ * `workspace` (split*147*64 floats, deterministic).  M = N*Ho*Wo, k = (kh*7 + kw)*3 + c. */
+typedef struct {
+    int32_t N, H, W, Ho, Wo;
+    const float *img;       /* [N, H, W, 3] */
+    const float *w;         /* mode 0: kernel [147][64]; mode 2: dy [M][64] */
+    float *y;               /* mode 0: output [M][64]; mode 2: dw [147][64] */
+    float alpha;
+    const float *scale;
+    const float *bias;
+    int32_t act;
+    int32_t split;
+    float *workspace; int64_t workspace_bytes;
+    int32_t compute;        /* 0 = exact fp32 MFMA, 1 = bf16 MFMA */
+} detr_stem_desc;
+int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, void *stream);
 int detr_hip_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H,
                                   int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
 /* dx[n,h,w,c] = (x[n,h,w,c] > 0) * sum over windows whose argmax is (h,w) of dy */

@@ -257,6 +257,39 @@ def test_fused_attention_bf16_mfma(hip, B, T, S, p):
     close(dv, v.grad, rtol=2e-2, what="bf16 attention dv")
 
 
+@pytest.mark.parametrize("N,H,W,compute", [(2, 37, 53, 0), (1, 128, 160, 0), (2, 37, 53, 1), (3, 64, 96, 1)])
+def test_stem_conv_implicit_gemm(hip, N, H, W, compute):
+    """7x7/s2 stem convolution as an implicit GEMM (no im2col buffer): forward with folded BN + ReLU and the weight
+    gradient (split over the output pixels, deterministic) vs torch conv2d on the zero-padded image."""
+    torch.manual_seed(N + H + W + compute)
+    hip.ensure_workspace(DEV)                        # the split reduction goes through the shared workspace
+    rnd = (lambda *sh: _bf(torch.randn(*sh))) if compute else (lambda *sh: torch.randn(*sh, dtype=torch.float64))
+    img = rnd(N, H, W, 3)
+    w = (rnd(7, 7, 3, 64) / 12.0).requires_grad_(True)
+    scale, shift = torch.rand(64, dtype=torch.float64) + 0.5, torch.randn(64, dtype=torch.float64)
+    z = F.conv2d(F.pad(img.permute(0, 3, 1, 2), (3, 3, 3, 3)), w.permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
+    Ho, Wo = z.shape[1], z.shape[2]
+    y = torch.relu(z * scale + shift)
+    imgd, sd = g(img.float()), g(scale.float())
+    ws = g((w.detach() * scale).float().reshape(147, 64))          # BN scale folded into the kernel, as the engine does
+    yd = torch.zeros(N, Ho, Wo, 64, device=DEV)
+    hip.stem_conv(0, imgd, ws, yd, N, H, W, Ho, Wo, bias=g(shift.float()), act=1, compute=compute)
+    close(yd, y, rtol=(3e-3 if compute else 2e-5), what="stem conv fwd")     # bf16: w*scale is re-rounded by the kernel
+    dz = rnd(N, Ho, Wo, 64)
+    (z * dz).sum().backward()
+    dzd = g(dz.float())
+    res = []
+    for rep in range(2):
+        dw = torch.zeros(147, 64, device=DEV)
+        hip.stem_conv(2, imgd, dzd, dw, N, H, W, Ho, Wo, scale=sd, split=7, compute=compute)
+        res.append(dw)
+    close(res[0].view(7, 7, 3, 64), w.grad * scale, rtol=5e-5, what="stem conv wgrad")
+    assert torch.equal(res[0], res[1])
+    dw1 = torch.zeros(147, 64, device=DEV)
+    hip.stem_conv(2, imgd, dzd, dw1, N, H, W, Ho, Wo, scale=sd, split=1, compute=compute)
+    close(dw1.view(7, 7, 3, 64), w.grad * scale, rtol=5e-5, what="stem conv wgrad (unsplit)")
+
+
 def test_linear_helpers(hip):
     torch.manual_seed(5)
     M, K, N = 420, 256, 92
