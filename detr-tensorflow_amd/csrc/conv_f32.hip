@@ -555,6 +555,145 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 weight gradient with the NINE TAPS FUSED (stride 1, pad 1, Ci % 64 == 0, Co % 64 == 0):
+//   dw[tap][ci][co] += sum over output pixels of x[pix + tap][ci] * dy[pix][co]
+// One workgroup owns a 64(ci) x 64(co) tile of all nine taps (9 accumulators of 16 registers per wave).  The reduction
+// runs over UNITS of 32 consecutive output pixels of one output row: per unit the workgroup stages the dy tile
+// [32 px][64 co] and the haloed input patch [3 rows][34 px][64 ci] ONCE (bf16, natural [pixel][channel] orientation
+// cut into [4 px][16 ch] sub-blocks of 128 B) and every tap reads its MFMA fragments with ds_read_b64_tr_b16 at a
+// shifted pixel row -- the per-tap kernel above re-loads x and dy for every tap (4.2x the LDS fill per MFMA).
+// ------------------------------------------------------------------------------------------------
+constexpr int WF_ROW = 9 * 4 * 64;        // shorts per patch row: 9 pixel groups x 4 ci blocks x [4][16]
+
+struct WgradFusedSmem {
+    unsigned short X[2][3 * WF_ROW];      // haloed input patch
+    unsigned short D[2][32 * 64];         // dy tile (transpose-read image, BMN = 64)
+};
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kernel(ConvWgradArgs a, int units_per_split,
+                                                                                 int chunks) {
+    constexpr int SMEM = (int)sizeof(WgradFusedSmem) > SmemBytes<64, 64, 2>::VALUE ? (int)sizeof(WgradFusedSmem)
+                                                                                    : SmemBytes<64, 64, 2>::VALUE;
+    __shared__ __attribute__((aligned(16))) char smem_raw[SMEM];
+    WgradFusedSmem &sm = *reinterpret_cast<WgradFusedSmem *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = blockIdx.x % a.tiles_n, tm = blockIdx.x / a.tiles_n;
+    const int ci0 = tm * 64, co0 = tn * 64;
+    const int total_units = a.N * a.Ho * chunks;
+    const int u_begin = blockIdx.z * units_per_split;
+    const int u_end = min(total_units, u_begin + units_per_split);
+    if (u_begin >= u_end) return;
+    BufSrc xs, ds;
+    xs.init(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci);
+    ds.init(a.dy, (long long)a.N * a.Ho * a.Wo * a.Co);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    float4 rx[7], rd[2];
+    auto load_unit = [&](int u) {
+        const int chunk = u % chunks;
+        const int t = u / chunks;
+        const int ho = t % a.Ho, n = t / a.Ho;
+        const int wo0 = chunk * 32;
+        // dy tile: LoaderMNt<64> map (row = pixel j, col = co)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            const int j = 4 * (v >> 6) + ((v >> 2) & 3);
+            const int col = 16 * ((v >> 4) & 3) + 4 * (v & 3);
+            const bool ok = wo0 + j < a.Wo;
+            const unsigned off = ((unsigned)((n * a.Ho + ho) * a.Wo + wo0 + j) * (unsigned)a.Co + (unsigned)(co0 + col)) * 4u;
+            rd[i] = ds.ld4(ok ? off : BUF_OOB);
+        }
+        // input patch: slot v -> (patch pixel pp = v / 16 in [0, 102), float4 c4 = v % 16 of the 64 channels)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int v = tid + 256 * i;
+            const int pp = v >> 4, c4 = v & 15;
+            const int kh = pp / 34, c = pp - kh * 34;
+            const int hi = ho - 1 + kh, wi = wo0 - 1 + c;
+            const bool ok = pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+            const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * 4u;
+            rx[i] = xs.ld4(ok ? off : BUF_OOB);
+        }
+    };
+    auto store_unit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = make_uint2(pack_bf16(rd[i].x, rd[i].y), pack_bf16(rd[i].z, rd[i].w));
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int v = tid + 256 * i;
+            const int pp = v >> 4, c4 = v & 15;
+            if (pp < 102) {
+                const int kh = pp / 34, c = pp - kh * 34;
+                const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (c & 3) * 16 + (c4 & 3) * 4;
+                *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
+            }
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int g = lane >> 4, t16 = lane & 15;
+    // fragment offsets (shorts) inside one buffer: they do not depend on the unit, the tap row kh is an immediate offset
+    int xo[2][3][2], dofs[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int cib = 2 * wm + (g & 1);                        // 16-channel block of this lane group
+        const int jbase = 16 * s2 + 8 * (g >> 1) + (t16 >> 2);   // output pixel handed in by this lane (read 1)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = jbase + kw + 4 * h;
+                xo[s2][kw][h] = ((c >> 2) * 4 + cib) * 64 + (c & 3) * 16 + (t16 & 3) * 4;
+            }
+        dofs[s2] = ((4 * s2 + 2 * (g >> 1)) * 4 + 2 * wn + (g & 1)) * 64 + t16 * 4;
+    }
+    load_unit(u_begin);
+    store_unit(0);
+    __syncthreads();
+    int cur = 0;
+    for (int u = u_begin; u < u_end; ++u) {
+        const bool more = (u + 1) < u_end;
+        if (more) load_unit(u + 1);
+        const unsigned short *X = sm.X[cur];
+        const unsigned short *D = sm.D[cur];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            // B fragment: dy[pixels 16 s2 + 8 hi ..][co = wn*32 + (lane & 31)]  (image of LoaderMNt<64>)
+            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2]));
+            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2] + 4 * 64));
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][0] + kh * WF_ROW));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][1] + kh * WF_ROW));
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+        if (more) store_unit(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        f32x16 one[1][1];
+        one[0][0] = acc[t];
+        float *dw = a.dw + (long long)t * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
+        epilogue<64, 64, 2, 2>(one, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem / pooling / subsample elementwise kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void stem_im2col_kernel(const float *__restrict__ img, float *__restrict__ col, int N, int H, int W,
@@ -755,6 +894,43 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
 }
 
+// fused-tap bf16 weight gradient (stride 1, pad 1, channel counts % 64 == 0)
+static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s) {
+    ConvWgradArgs a = a0;
+    a.tiles_m = a.Ci / 64;
+    a.tiles_n = a.Co / 64;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int chunks = cdiv(a.Wo, 32);
+    const int units = a.N * a.Ho * chunks;
+    if (split <= 0) {
+        int wgs = env_tile("DETR_HIP_WGRAD_FUSED_WGS");      // tuning hook: target workgroup count (default 1024)
+        if (wgs <= 2) wgs = 1024;
+        split = cdiv(wgs, tiles);
+    }
+    if (split > units) split = units;
+    if (split < 1) split = 1;
+    const int ups = cdiv(units, split);
+    split = cdiv(units, ups);
+    const long long part = 9LL * a.Ci * a.Co;
+    const bool partial = split > 1 && ws && aligned16(ws) && ws_bytes >= (long long)split * part * 4;
+    float *dw_final = a.dw;
+    const EpiArgs final_e = a.e;
+    a.part_stride = 0;
+    if (partial) {
+        a.dw = ws;
+        a.part_stride = part;
+        a.e.alpha = 1.0f;
+        a.e.scale = nullptr;
+        a.e.atomic = 0;
+        a.e.vec = 1;
+    } else {
+        a.e.atomic = 1;   // accumulate onto dw (split == 1, or the atomic fallback without a workspace)
+    }
+    dim3 grid((unsigned)tiles, 1, (unsigned)split), block(GEMM_THREADS);
+    hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel, grid, block, 0, s, a, ups, chunks);
+    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
+}
+
 }  // namespace detr
 
 using namespace detr;
@@ -794,6 +970,11 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
         const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
+        if (bf && d->stride == 1 && d->pad == 1 && d->Ci % 64 == 0 && d->Co % 64 == 0 && env_tile("DETR_HIP_WGRAD_FUSED") != 2) {
+            launch_wgrad_fused(a, d->split, d->workspace, d->workspace_bytes, s);
+            DETR_LAUNCH_CHECK("conv3x3 wgrad bf16 (fused taps)");
+            return 0;
+        }
         if (bf) {
             if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, true);
             else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, true);
