@@ -903,8 +903,8 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
     const int chunks = cdiv(a.Wo, 32);
     const int units = a.N * a.Ho * chunks;
     if (split <= 0) {
-        int wgs = env_tile("DETR_HIP_WGRAD_FUSED_WGS");      // tuning hook: target workgroup count (default 1024)
-        if (wgs <= 2) wgs = 1024;
+        int wgs = env_tile("DETR_HIP_WGRAD_FUSED_WGS");      // tuning hook: target workgroup count (512 measured best: 2 per CU)
+        if (wgs <= 2) wgs = 512;
         split = cdiv(wgs, tiles);
     }
     if (split > units) split = units;
