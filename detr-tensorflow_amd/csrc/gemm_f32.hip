@@ -403,9 +403,13 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     if (bf16c) {
         // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
         // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (2 waves/SIMD, 4x the operand
-        // reuse) pays only for the long split-K weight gradients (K >= 16384) with N >= 128
-        const bool small = (split > 1) ? !(d->N >= 128 && d->K >= 16384) : true;
-        if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
+        // reuse) pays only for the long split-K weight gradients (K >= 16384, N >= 128) and for unsplit K >= 1024 GEMMs
+        // that still fill the chip with 128x128 tiles (M33600 N256 K1024: 54 vs 60 us)
+        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
+        const bool small = (split > 1) ? !(d->N >= 128 && d->K >= 16384) : !(d->K >= 1024 && t128 >= 512);
+        if (force == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
+        else if (force == 5) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
+        else if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
     } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (force == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);

@@ -14,7 +14,7 @@ from detr_tf import _hip as hip
 hip.load()
 dev = "cuda"
 ws = hip.ensure_workspace(dev)
-TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x256", 6: "256x64"}
+TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x256|64x128(bf16)", 6: "256x64"}
 
 
 def timeit(fn, reps=8, warm=2):
@@ -90,7 +90,7 @@ if __name__ == "__main__":
                                        (133600, 512, 128, 1, 0, True), (133600, 128, 512, 1, 0, False), (534400, 256, 64, 1, 0, True),
                                        (534400, 64, 256, 1, 0, False), (8400, 256, 256, 1, 1, False), (8400, 2048, 256, 1, 1, False),
                                        (8400, 256, 2048, 1, 1, True), (800, 256, 2048, 1, 1, True)]:
-            gemm_case(M, N, K, ak, bk, res=res, tiles=(1, 3))
+            gemm_case(M, N, K, ak, bk, res=res, tiles=(1, 2, 3, 5))
         for (M, N, K, sks) in [(256, 256, 800, (1, 3, 6, 12)), (256, 256, 8400, (8, 16, 32, 64)), (256, 1024, 33600, (8, 16, 32)), (64, 256, 534400, (64, 128, 256)),
                                (128, 512, 133600, (32, 64, 128)), (147, 64, 2134400, (128, 341, 682)), (2048, 256, 8400, (4, 8, 16))]:
             gemm_case(M, N, K, 0, 0, splits=sks, tiles=(1, 3))
