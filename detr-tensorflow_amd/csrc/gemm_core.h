@@ -276,16 +276,15 @@ struct StageCfg {
 
 // dropout position (transformer.py:169,174-176): with a residual, the GEMM result is dropped BEFORE the
 // residual is added (x + drop(f(x))); without one, after the activation (drop(relu(.))).
-__device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiArgs &e, float res, float msk,
-                                         unsigned long long idx) {
+__device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiArgs &e, float res, float msk, bool keep) {
     v = v * sc + bi;
     v *= e.alpha;
     const bool drop = e.drop_scale != 0.0f;
-    if (drop && e.residual) v = drop_keep(e.drop_seed, idx, e.drop_thresh) ? v * e.drop_scale : 0.0f;
+    if (drop && e.residual) v = keep ? v * e.drop_scale : 0.0f;
     v += res;
     if (e.act == 1) v = fmaxf(v, 0.0f);
     else if (e.act == 2) v = 1.0f / (1.0f + expf(-v));
-    if (drop && !e.residual) v = drop_keep(e.drop_seed, idx, e.drop_thresh) ? v * e.drop_scale : 0.0f;
+    if (drop && !e.residual) v = keep ? v * e.drop_scale : 0.0f;
     if (e.mask) v = (msk > 0.0f) ? v : 0.0f;
     return v;
 }
@@ -339,10 +338,21 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                 if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + prow * e.ldmask + col);
                 float4 o;
                 const unsigned long long di = (unsigned long long)prow * N + col;
-                o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x, di);
-                o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y, di + 1);
-                o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z, di + 2);
-                o.w = epi_one(a.w, sc.w, bi.w, e, rs.w, mk.w, di + 3);
+                bool k0 = true, k1 = true, k2 = true, k3 = true;
+                if (e.drop_scale != 0.0f) {
+                    if ((di & 1ull) == 0) {      // two hashes serve the four elements (common.h: 16 bits per element)
+                        const uint32_t h0 = drop_hash(e.drop_seed, di >> 1), h1 = drop_hash(e.drop_seed, (di >> 1) + 1);
+                        k0 = (h0 & 0xFFFFu) >= e.drop_thresh; k1 = (h0 >> 16) >= e.drop_thresh;
+                        k2 = (h1 & 0xFFFFu) >= e.drop_thresh; k3 = (h1 >> 16) >= e.drop_thresh;
+                    } else {
+                        k0 = drop_keep(e.drop_seed, di, e.drop_thresh); k1 = drop_keep(e.drop_seed, di + 1, e.drop_thresh);
+                        k2 = drop_keep(e.drop_seed, di + 2, e.drop_thresh); k3 = drop_keep(e.drop_seed, di + 3, e.drop_thresh);
+                    }
+                }
+                o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x, k0);
+                o.y = epi_one(a.y, sc.y, bi.y, e, rs.y, mk.y, k1);
+                o.z = epi_one(a.z, sc.z, bi.z, e, rs.z, mk.z, k2);
+                o.w = epi_one(a.w, sc.w, bi.w, e, rs.w, mk.w, k3);
                 if (e.atomic) {
                     unsafeAtomicAdd(dst + 0, o.x);
                     unsafeAtomicAdd(dst + 1, o.y);
@@ -360,7 +370,8 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                         const float bi = e.bias ? e.bias[col + j] : 0.0f;
                         const float rs = e.residual ? e.residual[prow * e.ldr + col + j] : 0.0f;
                         const float mk = e.mask ? e.mask[prow * e.ldmask + col + j] : 1.0f;
-                        const float o = epi_one(av[j], sc, bi, e, rs, mk, (unsigned long long)prow * N + col + j);
+                        const bool kp = e.drop_scale == 0.0f || drop_keep(e.drop_seed, (unsigned long long)prow * N + col + j, e.drop_thresh);
+                        const float o = epi_one(av[j], sc, bi, e, rs, mk, kp);
                         if (e.atomic) unsafeAtomicAdd(dst + j, o);
                         else dst[j] = o;
                     }
