@@ -27,6 +27,7 @@ struct ConvArgs {
     // w = 2*w2 + pw; only the taps with kh = kh0 (+2), kw = kw0 (+2) contribute (1, 2, 2 or 4 of the 9), so the classes
     // together do 9/4 tap-GEMMs per pixel instead of 9 with 3/4 of the rows masked.
     int par_on, Hp, Wp, ph, pw, kh0, kw0, nth, ntw;
+    int w16;                     // the kernel tensor is bf16 in memory (bf16 compute only)
 };
 
 // tap (kh, kw) of K-tile group t (t-th tap of the launch)
@@ -394,7 +395,7 @@ struct LoaderConvAb {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool W16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_bf16c_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
@@ -409,8 +410,10 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     const long long tapstride = (long long)a.Ci * a.Co;
     LoaderConvAb<BM, DGRAD> la;
     la.init(a, m0, tid);
-    using LB = typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNt<BN>>::type;   // fwd weights: transpose-read image
-    constexpr int NRB = DGRAD ? LoaderKb<BN>::NV : LoaderMNt<BN>::NU;
+    // fwd weights: transpose-read image; W16: the kernel is already bf16 in memory (per-step weight shadow)
+    using LB = typename std::conditional<W16, typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN>>::type,
+                                         typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
+    constexpr int NRB = LB::NREG;
     LB lb;
     lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);   // one descriptor over the 9 taps
     f32x16 acc[T::TM][T::TN];
@@ -420,12 +423,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 ra[LoaderConvAb<BM, DGRAD>::NV], rb[NRB];
+    float4 ra[LoaderConvAb<BM, DGRAD>::NV];
+    typename LB::Reg rb[NRB];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
         int kh, kw;
         conv_tap(a, tap, kh, kw);
-        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * 4));
+        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * (W16 ? 2 : 4)));
     };
     la.load(a, 0, cpt, ra);
     load_b(0);
@@ -843,8 +847,11 @@ static void launch_conv_bf16(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cd, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
-    if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
+    if (a.w16) {
+        if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
+    } else if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -1003,6 +1010,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.ldr = a.Cd;
     e.ldmask = a.Cd;
     a.e = e;
+    a.w16 = (d->w_dtype == 1);
+    DETR_REQUIRE(d->w_dtype == 0 || (d->w_dtype == 1 && d->compute == 1 && mode != 2 && d->Ci % 32 == 0 && d->Co % 32 == 0),
+                 "conv3x3: a bf16 kernel tensor needs compute = bf16, mode 0/1 and channel counts %% 32 == 0");
     a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
     const bool dgrad = mode == 1;
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic

@@ -50,6 +50,8 @@ struct BfSmemBytes {
 template <int BMN>
 struct LoaderKb {
     static constexpr int NV = BMN / 32;
+    typedef float4 Reg;
+    static constexpr int NREG = NV;
     BufSrc src;
     unsigned off[NV];      // byte offset of the row, BUF_OOB for rows outside the operand
     bool vec;
@@ -95,6 +97,8 @@ template <int BMN>
 struct LoaderMNt {
     static constexpr int NB = BMN / 16;
     static constexpr int NU = BMN / 32;              // float4 per thread and tile (32 k x BMN / 4 / 256)
+    typedef float4 Reg;
+    static constexpr int NREG = NU;
     BufSrc src;
     unsigned ld4b;
     int mn0, MN;
@@ -130,6 +134,70 @@ struct LoaderMNt {
 #pragma unroll
         for (int i = 0; i < NU; ++i)
             *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+    }
+};
+
+// ---- operands that are ALREADY bf16 in memory (the per-step bf16 shadow of the weights, engine.py): no conversion,
+// half the bytes; same LDS images as LoaderKb / LoaderMNt.  K (k-contiguous) must be a multiple of 8, MN of 4.
+// [mn][k], k contiguous: 16-byte chunks of 8 k; thread t: rows (t >> 2) + 64*i, k offset (t & 3) * 8
+template <int BMN>
+struct LoaderKh {
+    static constexpr int NV = BMN / 64;
+    typedef uint4 Reg;
+    static constexpr int NREG = NV;
+    BufSrc src;
+    unsigned off[NV];
+    int k8, tid;
+    __device__ __forceinline__ void init(const float *p, long long ld, int mn0, int MN, int K, bool, int tid_,
+                                         long long extent_elems = 0) {
+        src.init_bytes(p, (extent_elems > 0 ? extent_elems : (long long)(MN - 1) * ld + K) * 2);
+        tid = tid_;
+        k8 = (tid & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int g = mn0 + (tid >> 2) + 64 * i;
+            off[i] = g < MN ? (unsigned)((long long)g * ld * 2) : BUF_OOB;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int K, uint4 (&r)[NV], unsigned base = 0) const {
+        const int k = k0 + k8;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = src.ld16((off[i] != BUF_OOB && k + 8 <= K) ? off[i] + base + 2u * (unsigned)k : BUF_OOB);
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const uint4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<uint4 *>(&S[(tid >> 2) + 64 * i][k8]) = r[i];
+    }
+};
+
+// [k][mn], mn contiguous: transpose-read image, 8-byte units of 4 mn (same unit map as LoaderMNt)
+template <int BMN>
+struct LoaderMNth {
+    static constexpr int NB = BMN / 16;
+    static constexpr int NU = BMN / 32;
+    typedef uint2 Reg;
+    static constexpr int NREG = NU;
+    BufSrc src;
+    unsigned ld2b;
+    int mn0, MN, tid;
+    __device__ __forceinline__ void init(const float *p, long long ld_, int mn0_, int MN_, int K, bool, int tid_,
+                                         long long extent_elems = 0) {
+        src.init_bytes(p, (extent_elems > 0 ? extent_elems : (long long)(K - 1) * ld_ + MN_) * 2);
+        ld2b = (unsigned)(ld_ * 2); mn0 = mn0_; MN = MN_; tid = tid_;
+    }
+    __device__ __forceinline__ void load(int k0, int K, uint2 (&r)[NU], unsigned base = 0) const {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+            const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+            r[i] = src.ld8((k < K && col + 4 <= MN) ? base + (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const uint2 (&r)[NU]) const {
+        unsigned short *flat = &S[0][0];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = r[i];
     }
 };
 

@@ -89,8 +89,17 @@ struct BufSrc {
     __device__ __forceinline__ void init(const float *base, long long elems) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(unsigned)(elems * 4), 0x00020000);
     }
+    __device__ __forceinline__ void init_bytes(const void *base, long long bytes) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)bytes, 0x00020000);
+    }
     __device__ __forceinline__ float4 ld4(unsigned voff) const {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+    __device__ __forceinline__ uint4 ld16(unsigned voff) const {      // 16 raw bytes (8 bf16)
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+    }
+    __device__ __forceinline__ uint2 ld8(unsigned voff) const {       // 8 raw bytes (4 bf16)
+        return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
     }
     __device__ __forceinline__ float ld1(unsigned voff) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));

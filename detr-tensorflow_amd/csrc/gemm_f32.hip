@@ -22,6 +22,7 @@ struct GemmArgs {
     float *rowsum;               // split_k == 1: rowsum[m] += rowsum_alpha * sum;  else partial slab [split][M]
     float rowsum_alpha;
     int rowsum_partial;
+    int b16;                     // B operand is bf16 in memory (bf16 compute only)
 };
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
 }
 
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool B16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
@@ -161,9 +162,11 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     if (kt0 >= kt1) return;
 
     using LA = typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type;       // MN-contiguous: transpose-read image
-    using LB = typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type;
+    // B16: the B operand is already bf16 in memory (per-step weight shadow): half the bytes, no conversion
+    using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN>, LoaderMNth<BN>>::type,
+                                         typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
     constexpr int NRA = AK ? LoaderKb<BM>::NV : LoaderMNt<BM>::NU;
-    constexpr int NRB = BKC ? LoaderKb<BN>::NV : LoaderMNt<BN>::NU;
+    constexpr int NRB = LB::NREG;
     LA la;
     LB lb;
     la.init(A, g.lda, m0, g.M, g.K, g.a_vec != 0, tid);
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
             for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
         }
     };
-    float4 ra[NRA], rb[NRB];
+    float4 ra[NRA];
+    typename LB::Reg rb[NRB];
     la.load(kt0 * BF_BK, g.K, ra);
     lb.load(kt0 * BF_BK, g.K, rb);
     if (do_rs) rs_add(ra);
@@ -304,10 +308,15 @@ static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak,
     a.tiles_n = cdiv(g.N, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
     dim3 block(GEMM_THREADS);
-    if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
-    else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
-    else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+    if (g.b16) {
+        if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a);
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false, true>), grid, block, 0, s, a);
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, true>), grid, block, 0, s, a);
+    } else if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, false>), grid, block, 0, s, a);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false, false>), grid, block, 0, s, a);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, false>), grid, block, 0, s, a);
     return 0;
 }
 
@@ -335,6 +344,9 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     {   // operands are addressed through 32-bit buffer offsets (gemm_core.h BufSrc)
         const long long ea = d->a_kcontig ? (long long)(d->M - 1) * d->lda + d->K : (long long)(d->K - 1) * d->lda + d->M;
         const long long eb = d->b_kcontig ? (long long)(d->N - 1) * d->ldb + d->K : (long long)(d->K - 1) * d->ldb + d->N;
+        DETR_REQUIRE(d->b_dtype == 0 || (d->b_dtype == 1 && bf16c && batch == 1 && aligned16(d->B) && d->ldb % 8 == 0 &&
+                                         (d->b_kcontig ? d->K % 8 == 0 : d->N % 4 == 0)),
+                     "gemm: a bf16 B operand needs compute = bf16, batch 1, 16-byte alignment, ldb %% 8 == 0 and K %% 8 (N %% 4) == 0");
         DETR_REQUIRE(ea * 4 <= BUF_MAX_BYTES && eb * 4 <= BUF_MAX_BYTES, "gemm: an operand spans more than 4 GB");
     }
     if (d->rowsum_a) DETR_REQUIRE(!d->a_kcontig && batch == 1, "gemm: rowsum_a needs an MN-contiguous A operand and batch == 1");
@@ -383,6 +395,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     g.rowsum = d->rowsum_a;
     g.rowsum_alpha = d->rowsum_alpha;
     g.rowsum_partial = 0;
+    g.b16 = d->b_dtype == 1;
     EpiArgs final_e = g.e;
     if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;

@@ -433,6 +433,52 @@ extern "C" int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t 
     return 0;
 }
 
+namespace detr {
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk2_bf16(float a, float b) {
+    bf16x2_t r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+__global__ void cvt_bf16_kernel(const float4 *__restrict__ x, uint2 *__restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        out[i] = make_uint2(pk2_bf16(v.x, v.y), pk2_bf16(v.z, v.w));
+    }
+}
+__global__ void scale_cols_bf16_kernel(const float4 *__restrict__ w, const float4 *__restrict__ scale, uint2 *__restrict__ out,
+                                       long long n4, int c4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = w[i], sc = scale[i % c4];
+        out[i] = make_uint2(pk2_bf16(v.x * sc.x, v.y * sc.y), pk2_bf16(v.z * sc.z, v.w * sc.w));
+    }
+}
+}  // namespace detr
+
+extern "C" int detr_hip_cvt_bf16(const float *x, uint16_t *out, int64_t n, void *stream) {
+    DETR_REQUIRE(x && out && n > 0 && n % 4 == 0 && aligned16(x) && ((uintptr_t)out % 8 == 0), "cvt_bf16: bad args");
+    const long long n4 = n / 4;
+    long long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, (uint2 *)out, n4);
+    DETR_LAUNCH_CHECK("cvt_bf16");
+    return 0;
+}
+
+extern "C" int detr_hip_scale_cols_bf16(const float *w, const float *scale, uint16_t *out, int64_t rows, int32_t cols,
+                                        void *stream) {
+    DETR_REQUIRE(w && scale && out && rows > 0 && cols > 0 && cols % 4 == 0, "scale_cols_bf16: bad args");
+    DETR_REQUIRE(aligned16(w) && aligned16(scale) && ((uintptr_t)out % 8 == 0), "scale_cols_bf16: alignment");
+    const long long n4 = rows * (long long)(cols / 4);
+    long long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(scale_cols_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)w,
+                       (const float4 *)scale, (uint2 *)out, n4, cols / 4);
+    DETR_LAUNCH_CHECK("scale_cols_bf16");
+    return 0;
+}
+
 extern "C" int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha,
                                    void *stream) {
     DETR_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad args");

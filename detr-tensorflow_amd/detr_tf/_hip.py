@@ -31,7 +31,7 @@ class GemmDesc(Structure):
                 ("act", c_int32), ("split_k", c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
-                ("rowsum_a", c_void_p), ("rowsum_alpha", c_float)]
+                ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32)]
 
 
 class StemDesc(Structure):
@@ -49,7 +49,7 @@ class Conv3x3Desc(Structure):
                 ("alpha", c_float),
                 ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
                 ("act", c_int32), ("split", c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32), ("w_dtype", c_int32)]
 
 
 class SetLossDesc(Structure):
@@ -66,6 +66,8 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
+    "detr_hip_cvt_bf16": [f32p, c_void_p, c_int64, c_void_p],
+    "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
     "detr_hip_stem_conv7x7_f32": [POINTER(StemDesc), c_int32, c_void_p],
     "detr_hip_stem_im2col_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_f32": [f32p, f32p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
@@ -210,7 +212,8 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.A, d.lda, d.a_kcontig = A.data_ptr() + 4 * a_off, lda, int(a_kcontig)
-    d.B, d.ldb, d.b_kcontig = B.data_ptr() + 4 * b_off, ldb, int(b_kcontig)
+    d.B, d.ldb, d.b_kcontig = B.data_ptr() + B.element_size() * b_off, ldb, int(b_kcontig)
+    d.b_dtype = 1 if B.dtype == torch.bfloat16 else 0          # bf16 weight shadow (bf16 compute only)
     d.C, d.ldc = C.data_ptr() + 4 * c_off, ldc
     d.batch, d.batch_inner = batch, batch_inner
     d.sA0, d.sA1 = sA
@@ -289,6 +292,7 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     d = Conv3x3Desc()
     d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.stride, d.pad = N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.w_dtype = 1 if (mode != 2 and w.dtype == torch.bfloat16) else 0
     d.alpha = alpha
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split

@@ -102,12 +102,30 @@ class DetrEngine:
         self.fold_bn()
         return missing
 
+    def _w(self, name):
+        """Weight OPERAND of a GEMM: the fp32 tensor, or -- while the bf16-compute kernels are active -- its bf16 shadow
+        (half the bytes, no conversion in the kernel).  Biases, LayerNorm vectors and gradients stay fp32."""
+        if hip.COMPUTE_BF16 and self.P.views16 is not None:
+            return self.P.views16[name]
+        return self.P.views[name]
+
+    def _refresh_shadow(self):
+        """bf16 compute mode: one flat fp32 -> bf16 conversion of all parameters per optimiser step (~60 us)."""
+        flat16 = self.P.shadow16()
+        hip.call("detr_hip_cvt_bf16", self.P.flat.data_ptr(), flat16.data_ptr(), self.P.flat.numel())
+
     def _scaled_kernel(self, conv_name, bn_name):
-        """kernel * bn scale per output channel (the frozen-BN fold into the conv)."""
+        """kernel * bn scale per output channel (the frozen-BN fold into the conv); bf16 compute mode: the bf16 copy."""
         w = self.P.views[conv_name]
+        co = w.shape[-1]
+        if self.compute == 1 and conv_name != "backbone/conv1/kernel":      # (the stem kernel takes the fp32 copy)
+            ws16 = self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)
+            if self.weights_dirty:
+                hip.call("detr_hip_scale_cols_bf16", w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws16.data_ptr(),
+                         w.numel() // co, co)
+            return ws16
         ws = self.buf(f"ws:{conv_name}", w.shape)
         if self.weights_dirty:
-            co = w.shape[-1]
             hip.call("detr_hip_scale_cols_f32", w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws.data_ptr(),
                      w.numel() // co, co)
         return ws
@@ -160,7 +178,7 @@ class DetrEngine:
     def _mha_fwd(self, tag, pfx, q_in, k_in, v_in, B, T, S, out, residual, seed=0):
         """MultiHeadAttention.call transformer.py:285-356 + the residual add of the caller.
         q_in [B*T,256], k_in/v_in [B*S,256]; out = attn(q,k,v) @ Wo^T + bo + residual."""
-        W, bias = self.P.views[f"{pfx}/in_proj_kernel"], self.P.views[f"{pfx}/in_proj_bias"]
+        W, bias = self._w(f"{pfx}/in_proj_kernel"), self.P.views[f"{pfx}/in_proj_bias"]
         Qb, Kb, Vb = self.buf(f"{tag}:Q", (B * T, D)), self.buf(f"{tag}:K", (B * S, D)), self.buf(f"{tag}:V", (B * S, D))
         hip.linear_fwd(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5)          # :297,:307
         hip.linear_fwd(k_in, W[D:2 * D], bias[D:2 * D], Kb)
@@ -181,7 +199,7 @@ class DetrEngine:
             hip.call("detr_hip_softmax_rows_fwd_f32", Pm.data_ptr(), BH * T, S, Sp)     # :340
             hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
                      sB=(S * D, HD), sC=(T * D, HD))                                   # :343-345
-        hip.linear_fwd(O, self.P.views[f"{pfx}/out_proj_kernel"], self.P.views[f"{pfx}/out_proj_bias"], out,
+        hip.linear_fwd(O, self._w(f"{pfx}/out_proj_kernel"), self.P.views[f"{pfx}/out_proj_bias"], out,
                        residual=residual, dropout_p=self._drop[0], dropout_seed=self._drop[1] + seed + 1)   # :346-347 + :169
 
 
@@ -190,7 +208,7 @@ class DetrEngine:
         """Backward of _mha_fwd w.r.t. q_in, k_in, v_in and the MHA parameters.
         d_out: gradient of the out-projection output.  dk_in/dv_in may be accumulated onto."""
         V, G = self.P.views, self.P.gviews
-        W, gW, gb = V[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
+        W, gW, gb = self._w(f"{pfx}/in_proj_kernel"), G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
         Qb, Kb, Vb, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "O"))
         BH = B * HEADS
         dp, dbase = self._drop
@@ -202,7 +220,7 @@ class DetrEngine:
         # out projection
         hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"])
         dO = self.buf("scratch:dO", (B * T, D))
-        hip.linear_dgrad(d_out, V[f"{pfx}/out_proj_kernel"], dO)
+        hip.linear_dgrad(d_out, self._w(f"{pfx}/out_proj_kernel"), dO)
         # attention core
         dQ, dK, dV = self.buf("scratch:dQ", (B * T, D)), self.buf("scratch:dK", (B * S, D)), self.buf("scratch:dV", (B * S, D))
         if FUSED_ATTENTION:
@@ -233,9 +251,9 @@ class DetrEngine:
         V = self.P.views
         dp, dbase = self._drop
         h = self.buf(f"{tag}:h", (x.shape[0], FF))
-        hip.linear_fwd(x, V[f"{pfx}/linear1/kernel"], V[f"{pfx}/linear1/bias"], h, act=1, dropout_p=dp,
+        hip.linear_fwd(x, self._w(f"{pfx}/linear1/kernel"), V[f"{pfx}/linear1/bias"], h, act=1, dropout_p=dp,
                        dropout_seed=dbase + seed)                                      # :172-174
-        hip.linear_fwd(h, V[f"{pfx}/linear2/kernel"], V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
+        hip.linear_fwd(h, self._w(f"{pfx}/linear2/kernel"), V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
                        dropout_seed=dbase + seed + 1)                                  # :175-176
 
     def _ffn_bwd(self, tag, pfx, d_f, x, dx, seed=0):
@@ -251,14 +269,16 @@ class DetrEngine:
         hip.linear_wgrad(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"])
         dh = self.buf("scratch:dh", h.shape)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
-        hip.linear_dgrad(d_y, V[f"{pfx}/linear2/kernel"], dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
+        hip.linear_dgrad(d_y, self._w(f"{pfx}/linear2/kernel"), dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
         hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])
-        hip.linear_dgrad(dh, V[f"{pfx}/linear1/kernel"], dx, residual=d_f)
+        hip.linear_dgrad(dh, self._w(f"{pfx}/linear1/kernel"), dx, residual=d_f)
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, images, training=False):
         """See _forward_impl.  GEMM / conv compute mode: self.compute (0 = exact fp32, 1 = bf16 MFMA)."""
         hip.COMPUTE_BF16 = self.compute
+        if self.compute == 1 and (self.weights_dirty or self.P.views16 is None):
+            self._refresh_shadow()
         try:
             return self._forward_impl(images, training)
         finally:
@@ -338,7 +358,7 @@ class DetrEngine:
         self._feat_meta = (feat, Hf, Wf, L)
         # ---------------- input_proj + positional encoding (detr.py:172-175) ----------------
         src = self.buf("enc:src0", (B * L, D))
-        hip.gemm(B * L, D, 2048, feat, 2048, 1, V["input_proj/kernel"], D, 0, src, D, bias=V["input_proj/bias"])
+        hip.gemm(B * L, D, 2048, feat, 2048, 1, self._w("input_proj/kernel"), D, 0, src, D, bias=V["input_proj/bias"])
         key = (Hf, Wf)
         if key not in self._pos_cache:
             self._pos_cache[key] = torch.from_numpy(position_embedding_sine_host(Hf, Wf)).to(self.device)
@@ -536,7 +556,7 @@ class DetrEngine:
                     on_bucket(i)
             return
         g = self.buf("scratch:g_feat", feat.shape)
-        hip.gemm(B * L, 2048, D, d_x, D, 1, V["input_proj/kernel"], D, 1, g, 2048, mask=feat, ldmask=2048)
+        hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
         # ---------------- residual stages ----------------
         n_blocks = len(self._block_meta)
         for bi in reversed(range(n_blocks)):
@@ -544,9 +564,10 @@ class DetrEngine:
             p, x, y1, y2 = m["p"], m["x"], m["y1"], m["y2"]
             h, w, ho, wo, cin, d1, d2, stride = m["h"], m["w"], m["ho"], m["wo"], m["cin"], m["d1"], m["d2"], m["stride"]
             M_in, M_out = B * h * w, B * ho * wo
-            ws1 = self._bufs[f"ws:{p}/conv1/kernel"]
-            ws2 = self._bufs[f"ws:{p}/conv2/kernel"]
-            ws3 = self._bufs[f"ws:{p}/conv3/kernel"]
+            wk = "ws16" if self.compute == 1 else "ws"       # scaled kernels of the forward (bf16 shadow in bf16 mode)
+            ws1 = self._bufs[f"{wk}:{p}/conv1/kernel"]
+            ws2 = self._bufs[f"{wk}:{p}/conv2/kernel"]
+            ws3 = self._bufs[f"{wk}:{p}/conv3/kernel"]
             # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
             self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{p}/conv3/kernel"], d2, scale=self.bn_scale[f"{p}/bn3"])
             dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1))
@@ -562,7 +583,7 @@ class DetrEngine:
             mask = None if is_first_block else x           # x = ReLU output of the previous block
             if m["first"]:
                 xs = m["xs"]
-                wsd = self._bufs[f"ws:{p}/downsample_0/kernel"]
+                wsd = self._bufs[f"{wk}:{p}/downsample_0/kernel"]
                 self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{p}/downsample_0/kernel"], d2,
                             scale=self.bn_scale[f"{p}/downsample_1"])
                 if stride == 2:

@@ -130,17 +130,25 @@ class ParamStore:
         for k, shp in self.shapes.items():
             n = int(np.prod(shp))
             self.offsets[k] = (off, n)
-            off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            off += (n + 7) // 8 * 8          # every tensor 16-byte aligned in the fp32 buffer AND in its bf16 shadow
         self.total = off
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.views = {k: self.flat[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
         self.gviews = {k: self.grad[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
+        self.flat16, self.views16 = None, None      # bf16 shadow of `flat` (bf16 compute mode; refreshed by the engine)
         # frozen BN raw vectors [4, C] per layer: weight, bias, running_mean, running_var
         self.bn_raw = {p: torch.zeros(4, c, dtype=torch.float32, device=device) for p, c in self.bn.items()}
         for p in self.bn_raw:
             self.bn_raw[p][3].fill_(1.0)
         self.init_random(seed)
+
+    def shadow16(self):
+        """bf16 twin of the flat parameter buffer (same offsets): the weight operand of the bf16-compute kernels."""
+        if self.flat16 is None:
+            self.flat16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            self.views16 = {k: self.flat16[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
+        return self.flat16
 
     # ---- initialisation / IO --------------------------------------------------------------
     def init_random(self, seed):

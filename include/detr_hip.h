@@ -80,6 +80,10 @@ typedef struct {
      * required and the workspace must hold split_k*(M*N + M) floats).  Replaces the reference's separate
      * reduce_sum for every Linear bias gradient (tape gradient of custom_layers.py Linear bias). */
     float *rowsum_a; float rowsum_alpha;
+    /* 0: B is fp32.  1: B points to bf16 data (uint16, RNE-rounded weights; ldb in elements) -- bf16 compute only: the
+     * engine keeps a per-step bf16 shadow of the weights so that the weight operand is read at half the bytes and
+     * without conversion (K %% 8 == 0 for a k-contiguous B, N %% 4 == 0 otherwise). */
+    int32_t b_dtype;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 
@@ -107,6 +111,7 @@ typedef struct {
     int32_t split;       /* wgrad: number of row splits (0 = auto) */
     float *workspace; int64_t workspace_bytes;   /* wgrad: scratch for deterministic split reduction (see detr_gemm_desc) */
     int32_t compute;     /* 0 = exact fp32 MFMA, 1 = bf16 MFMA (see detr_gemm_desc) */
+    int32_t w_dtype;     /* modes 0/1 with compute = 1: 1 = `w` points to bf16 data (weight shadow, see detr_gemm_desc.b_dtype) */
 } detr_conv3x3_desc;
 int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
 
@@ -118,6 +123,10 @@ int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream)
  *   ZeroPadding2D + MaxPool2D('valid') does) with argmax for the backward;
  *   maxpool backward fused with the stem ReLU mask.
  * ------------------------------------------------------------------------------------------- */
+/* fp32 -> bf16 (RNE) copies that feed the bf16 weight operands: a flat conversion (n %% 4 == 0) and the frozen-BN fold
+ * out[r][c] = bf16(w[r][c] * scale[c]) (custom_layers.py:21-24 folded into the conv kernel). */
+int detr_hip_cvt_bf16(const float *x, uint16_t *out, int64_t n, void *stream);
+int detr_hip_scale_cols_bf16(const float *w, const float *scale, uint16_t *out, int64_t rows, int32_t cols, void *stream);
 int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W,
                              int32_t Ho, int32_t Wo, int32_t ldcol, void *stream);
 

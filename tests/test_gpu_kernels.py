@@ -758,6 +758,46 @@ def test_gemm_bf16_compute_layouts(hip, M, N, K, ak, bk):
     assert float((C[:, N:] - 7.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,bk", [(8400, 256, 256, 1), (8400, 2048, 256, 0), (300, 92, 256, 1), (1000, 256, 1024, 0),
+                                       (33600, 256, 1024, 1), (77, 64, 64, 0)])
+def test_gemm_bf16_weight_shadow_operand(hip, M, N, K, bk):
+    """B operand already bf16 in memory (detr_gemm_desc.b_dtype = 1, the per-step weight shadow): bit-identical to the
+    fp32-B path on the same (bf16-representable) values, fused epilogue included."""
+    torch.manual_seed(M + N + K + bk)
+    A = torch.randn(M, K)
+    Bm = _bf(torch.randn(N, K) if bk else torch.randn(K, N)).float()
+    bias, res = torch.randn(N), torch.randn(M, N)
+    Ad, Bd, B16 = g(A), g(Bm), g(Bm).to(torch.bfloat16)
+    outs = []
+    for Bop in (Bd, B16):
+        C = torch.zeros(M, N, device=DEV)
+        hip.gemm(M, N, K, Ad, K, 1, Bop, K if bk else N, bk, C, N, bias=g(bias), residual=g(res), ldr=N, act=1, compute=1)
+        outs.append(C)
+    ref = torch.relu(_bf(A) @ (Bm.double().t() if bk else Bm.double()) + bias.double() + res.double())
+    close(outs[0], ref, rtol=5e-5, what="bf16c gemm (fp32 B)")
+    assert torch.equal(outs[0], outs[1]), "bf16-B path must match the fp32-B path bit for bit"
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 25, 42, 256, 256, 1)])
+def test_conv3x3_bf16_weight_shadow_operand(hip, N, H, W, Ci, Co, stride):
+    """conv3x3 forward / dgrad with the kernel tensor already bf16 in memory (w_dtype = 1): bit-identical to the fp32-w path."""
+    torch.manual_seed(N + H + W + Ci + stride)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x, dy = g(torch.randn(N, H, W, Ci)), g(torch.randn(N, Ho, Wo, Co))
+    w = _bf(torch.randn(3, 3, Ci, Co) / (3 * Ci ** 0.5)).float()
+    wd, w16 = g(w), g(w).to(torch.bfloat16)
+    shift = g(torch.randn(Co))
+    ys, dxs = [], []
+    for wop in (wd, w16):
+        y = torch.zeros(N, Ho, Wo, Co, device=DEV)
+        hip.conv3x3(0, x, wop, y, N, H, W, Ci, Ho, Wo, Co, stride, bias=shift, act=1, compute=1)
+        dx = torch.zeros(N, H, W, Ci, device=DEV)
+        hip.conv3x3(1, dy, wop, dx, N, H, W, Ci, Ho, Wo, Co, stride, compute=1)
+        ys.append(y); dxs.append(dx)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(dxs[0], dxs[1])
+    assert float(ys[0].abs().max()) > 0 and float(dxs[0].abs().max()) > 0
+
+
 def test_gemm_bf16_compute_split_k(hip):
     torch.manual_seed(31)
     M, N, K = 256, 512, 20000
