@@ -44,7 +44,27 @@ struct EpiArgs {
     // (n, h2, w2) addresses pixel (n, 2*h2 + remap_ph, 2*w2 + remap_pw) of the [.., remap_H, remap_W, N] tensors
     // C / residual / mask.  remap_w2 == 0: identity.
     int remap_w2 = 0, remap_h2 = 0, remap_W = 0, remap_H = 0, remap_ph = 0, remap_pw = 0;
+    // bf16 STORAGE of the activation tensors (backbone, DETR_HIP_ACT16): C / residual / mask are bf16 in memory (uint16,
+    // leading dimensions in elements); the arithmetic of the epilogue stays fp32, the result is rounded once (RNE)
+    int c16 = 0, r16 = 0, m16 = 0;
 };
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ float4 ld_bf16x4(const void *base, long long elem) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(base) + elem);
+    return make_float4(bf16_bits_to_f32(v.x & 0xFFFFu), bf16_bits_to_f32(v.x >> 16), bf16_bits_to_f32(v.y & 0xFFFFu),
+                       bf16_bits_to_f32(v.y >> 16));
+}
+__device__ __forceinline__ float ld_bf16x1(const void *base, long long elem) {
+    return bf16_bits_to_f32(reinterpret_cast<const unsigned short *>(base)[elem]);
+}
+__device__ __forceinline__ unsigned f32_to_bf16_pair(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
 
 template <int BM, int BN, int WGN>
 struct SmemBytes;
@@ -337,14 +357,15 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                 const int h2 = t2 % e.remap_h2, n2 = t2 / e.remap_h2;
                 prow = ((long long)n2 * e.remap_H + 2 * h2 + e.remap_ph) * e.remap_W + 2 * w2 + e.remap_pw;
             }
-            float *dst = C + prow * ldc + col;
+            float *dst = C + prow * ldc + col;                      // (fp32 output; the bf16 form is addressed below)
+            unsigned short *dst16 = reinterpret_cast<unsigned short *>(C) + prow * ldc + col;
             if (e.vec && col + 3 < N) {
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (e.scale) sc = *reinterpret_cast<const float4 *>(e.scale + col);
                 if (e.bias) bi = *reinterpret_cast<const float4 *>(e.bias + col);
-                if (e.residual) rs = *reinterpret_cast<const float4 *>(e.residual + prow * e.ldr + col);
-                if (e.mask) mk = *reinterpret_cast<const float4 *>(e.mask + prow * e.ldmask + col);
+                if (e.residual) rs = e.r16 ? ld_bf16x4(e.residual, prow * e.ldr + col) : *reinterpret_cast<const float4 *>(e.residual + prow * e.ldr + col);
+                if (e.mask) mk = e.m16 ? ld_bf16x4(e.mask, prow * e.ldmask + col) : *reinterpret_cast<const float4 *>(e.mask + prow * e.ldmask + col);
                 float4 o;
                 const unsigned long long di = (unsigned long long)prow * N + col;
                 bool k0 = true, k1 = true, k2 = true, k3 = true;
@@ -367,6 +388,8 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                     unsafeAtomicAdd(dst + 1, o.y);
                     unsafeAtomicAdd(dst + 2, o.z);
                     unsafeAtomicAdd(dst + 3, o.w);
+                } else if (e.c16) {
+                    *reinterpret_cast<uint2 *>(dst16) = make_uint2(f32_to_bf16_pair(o.x, o.y), f32_to_bf16_pair(o.z, o.w));
                 } else {
                     *reinterpret_cast<float4 *>(dst) = o;
                 }
@@ -377,11 +400,12 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                     if (col + j < N) {
                         const float sc = e.scale ? e.scale[col + j] : 1.0f;
                         const float bi = e.bias ? e.bias[col + j] : 0.0f;
-                        const float rs = e.residual ? e.residual[prow * e.ldr + col + j] : 0.0f;
-                        const float mk = e.mask ? e.mask[prow * e.ldmask + col + j] : 1.0f;
+                        const float rs = !e.residual ? 0.0f : (e.r16 ? ld_bf16x1(e.residual, prow * e.ldr + col + j) : e.residual[prow * e.ldr + col + j]);
+                        const float mk = !e.mask ? 1.0f : (e.m16 ? ld_bf16x1(e.mask, prow * e.ldmask + col + j) : e.mask[prow * e.ldmask + col + j]);
                         const bool kp = e.drop_scale == 0.0f || drop_keep(e.drop_seed, (unsigned long long)prow * N + col + j, e.drop_thresh);
                         const float o = epi_one(av[j], sc, bi, e, rs, mk, kp);
                         if (e.atomic) unsafeAtomicAdd(dst + j, o);
+                        else if (e.c16) dst16[j] = (unsigned short)(f32_to_bf16_pair(o, 0.0f) & 0xFFFFu);
                         else dst[j] = o;
                     }
                 }

@@ -23,6 +23,7 @@ struct GemmArgs {
     float rowsum_alpha;
     int rowsum_partial;
     int b16;                     // B operand is bf16 in memory (bf16 compute only)
+    int a16;                     // A operand is bf16 in memory (bf16 activation storage)
 };
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
 }
 
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool B16>
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
@@ -161,11 +162,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
 
-    using LA = typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type;       // MN-contiguous: transpose-read image
+    // MN-contiguous: transpose-read image.  A16: the A operand is bf16 in memory (bf16 activation storage)
+    using LA = typename std::conditional<A16, typename std::conditional<AK, LoaderKh<BM>, LoaderMNth<BM>>::type,
+                                         typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type>::type;
     // B16: the B operand is already bf16 in memory (per-step weight shadow): half the bytes, no conversion
     using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN>, LoaderMNth<BN>>::type,
                                          typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
-    constexpr int NRA = AK ? LoaderKb<BM>::NV : LoaderMNt<BM>::NU;
+    constexpr int NRA = LA::NREG;
     constexpr int NRB = LB::NREG;
     LA la;
     LB lb;
@@ -178,15 +181,15 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
+    const bool do_rs = !AK && !A16 && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
     float4 rs[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
-    auto rs_add = [&](const float4 (&r)[NRA]) {     // every float4 of a thread belongs to the column group 4*ib + c of its tid
-        if (!AK) {
+    auto rs_add = [&](const typename LA::Reg (&r)[NRA]) {     // every float4 of a thread belongs to the column group 4*ib + c of its tid
+        if constexpr (!AK && !A16) {
 #pragma unroll
             for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
         }
     };
-    float4 ra[NRA];
+    typename LA::Reg ra[NRA];
     typename LB::Reg rb[NRB];
     la.load(kt0 * BF_BK, g.K, ra);
     lb.load(kt0 * BF_BK, g.K, rb);
@@ -308,15 +311,18 @@ static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak,
     a.tiles_n = cdiv(g.N, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
     dim3 block(GEMM_THREADS);
-    if (g.b16) {
-        if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a);
-        else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false, true>), grid, block, 0, s, a);
-        else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, true>), grid, block, 0, s, a);
-    } else if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, false>), grid, block, 0, s, a);
-    else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false, false>), grid, block, 0, s, a);
-    else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, false>), grid, block, 0, s, a);
+#define DETR_BF16_LAUNCH(A16_, B16_)                                                                                          \
+    do {                                                                                                                          \
+        if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, A16_, B16_>), grid, block, 0, s, a);        \
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, false, A16_, B16_>), grid, block, 0, s, a); \
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, A16_, B16_>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, A16_, B16_>), grid, block, 0, s, a);               \
+    } while (0)
+    if (g.a16 && g.b16) DETR_BF16_LAUNCH(true, true);
+    else if (g.a16) DETR_BF16_LAUNCH(true, false);
+    else if (g.b16) DETR_BF16_LAUNCH(false, true);
+    else DETR_BF16_LAUNCH(false, false);
+#undef DETR_BF16_LAUNCH
     return 0;
 }
 
@@ -348,6 +354,11 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
                                          (d->b_kcontig ? d->K % 8 == 0 : d->N % 4 == 0)),
                      "gemm: a bf16 B operand needs compute = bf16, batch 1, 16-byte alignment, ldb %% 8 == 0 and K %% 8 (N %% 4) == 0");
         DETR_REQUIRE(ea * 4 <= BUF_MAX_BYTES && eb * 4 <= BUF_MAX_BYTES, "gemm: an operand spans more than 4 GB");
+        DETR_REQUIRE(d->a_dtype == 0 || (d->a_dtype == 1 && bf16c && batch == 1 && !d->rowsum_a && ((uintptr_t)d->A % 16 == 0) &&
+                                         (d->a_kcontig ? (d->lda % 8 == 0 && d->K % 8 == 0) : (d->lda % 4 == 0 && d->M % 4 == 0))),
+                     "gemm: a bf16 A operand needs compute = bf16, batch 1, no rowsum_a, 16-byte alignment and K %% 8 (M %% 4) == 0");
+        DETR_REQUIRE((d->c_dtype == 0 && d->r_dtype == 0 && d->m_dtype == 0) || (batch == 1 && split == 1),
+                     "gemm: bf16 C / residual / mask need batch 1 and no split-K");
     }
     if (d->rowsum_a) DETR_REQUIRE(!d->a_kcontig && batch == 1, "gemm: rowsum_a needs an MN-contiguous A operand and batch == 1");
     DETR_REQUIRE((long long)batch * split <= 65535, "gemm: batch*split_k=%lld exceeds grid.z", (long long)batch * split);
@@ -381,6 +392,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
         g.e.drop_thresh = drop_thresh16(d->dropout_p);
         g.e.drop_seed = d->dropout_seed;
     }
+    g.e.c16 = d->c_dtype == 1; g.e.r16 = d->r_dtype == 1; g.e.m16 = d->m_dtype == 1;
     g.e.vec = aligned16(d->C) && (d->ldc % 4 == 0) && (d->sC0 % 4 == 0) && (d->sC1 % 4 == 0) &&
               (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
               (!d->residual || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
@@ -396,6 +408,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     g.rowsum_alpha = d->rowsum_alpha;
     g.rowsum_partial = 0;
     g.b16 = d->b_dtype == 1;
+    g.a16 = d->a_dtype == 1;
     EpiArgs final_e = g.e;
     if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;

@@ -31,7 +31,8 @@ class GemmDesc(Structure):
                 ("act", c_int32), ("split_k", c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
-                ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32)]
+                ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32),
+                ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
 
 
 class StemDesc(Structure):
@@ -211,10 +212,12 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
-    d.A, d.lda, d.a_kcontig = A.data_ptr() + 4 * a_off, lda, int(a_kcontig)
+    d.A, d.lda, d.a_kcontig = A.data_ptr() + A.element_size() * a_off, lda, int(a_kcontig)
+    is16 = lambda t: 1 if (t is not None and t.dtype == torch.bfloat16) else 0      # bf16 activation storage
+    d.a_dtype, d.c_dtype, d.r_dtype, d.m_dtype = is16(A), is16(C), is16(residual), is16(mask)
     d.B, d.ldb, d.b_kcontig = B.data_ptr() + B.element_size() * b_off, ldb, int(b_kcontig)
     d.b_dtype = 1 if B.dtype == torch.bfloat16 else 0          # bf16 weight shadow (bf16 compute only)
-    d.C, d.ldc = C.data_ptr() + 4 * c_off, ldc
+    d.C, d.ldc = C.data_ptr() + C.element_size() * c_off, ldc
     d.batch, d.batch_inner = batch, batch_inner
     d.sA0, d.sA1 = sA
     d.sB0, d.sB1 = sB

@@ -84,6 +84,10 @@ typedef struct {
      * engine keeps a per-step bf16 shadow of the weights so that the weight operand is read at half the bytes and
      * without conversion (K %% 8 == 0 for a k-contiguous B, N %% 4 == 0 otherwise). */
     int32_t b_dtype;
+    /* bf16 STORAGE of activation tensors (bf16 compute only; the engine's backbone tensors when DETR_HIP_ACT16=1): 1 = the
+     * tensor is bf16 in memory (uint16, RNE; leading dimensions in elements), 0 = fp32.  The epilogue arithmetic stays
+     * fp32 and the result is rounded once.  Not with split_k / batch (partial slabs and gradients of parameters stay fp32). */
+    int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask */
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 

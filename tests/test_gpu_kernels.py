@@ -798,6 +798,34 @@ def test_conv3x3_bf16_weight_shadow_operand(hip, N, H, W, Ci, Co, stride):
     assert float(ys[0].abs().max()) > 0 and float(dxs[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize("M,N,K,bk", [(8400, 256, 256, 1), (33600, 1024, 256, 0), (1000, 64, 256, 1), (531, 256, 64, 0)])
+def test_gemm_bf16_activation_storage(hip, M, N, K, bk):
+    """bf16 STORAGE of A / C / residual / mask (a_dtype .. m_dtype = 1): same accumulators as the fp32-storage call on
+    the same values, the result rounded once to bf16 -- compared bit for bit with bf16(fp32-storage result)."""
+    torch.manual_seed(M + N + K + bk + 5)
+    A = _bf(torch.randn(M, K)).float()
+    Bm = _bf(torch.randn(N, K) if bk else torch.randn(K, N)).float()
+    res, msk, bias = _bf(torch.randn(M, N)).float(), _bf(torch.randn(M, N)).float(), torch.randn(N)
+    Ad, Bd, rd, md, bd = g(A), g(Bm).to(torch.bfloat16), g(res), g(msk), g(bias)
+    C32 = torch.zeros(M, N, device=DEV)
+    hip.gemm(M, N, K, Ad, K, 1, Bd, K if bk else N, bk, C32, N, bias=bd, residual=rd, ldr=N, mask=md, ldmask=N, act=1, compute=1)
+    C16 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm(M, N, K, Ad.to(torch.bfloat16), K, 1, Bd, K if bk else N, bk, C16, N, bias=bd, residual=rd.to(torch.bfloat16), ldr=N,
+             mask=md.to(torch.bfloat16), ldmask=N, act=1, compute=1)
+    assert torch.equal(C16, C32.to(torch.bfloat16)), "bf16-storage GEMM differs from bf16(fp32-storage GEMM)"
+    assert float(C32.abs().max()) > 0
+    # weight-gradient form: both operands MN-contiguous bf16 activations, fp32 split-K output
+    dy, x = _bf(torch.randn(M, 64)).float(), A[:, :64].contiguous()
+    ws = torch.empty(8 * 1024 * 1024, device=DEV)
+    outs = []
+    for cast in (lambda t: t, lambda t: t.to(torch.bfloat16)):
+        dw = torch.zeros(64, 64, device=DEV)
+        hip.gemm(64, 64, M, cast(g(dy)), 64, 0, cast(g(x)), 64, 0, dw, 64, split_k=16, workspace=ws, compute=1)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]), "bf16-storage wgrad differs from the fp32-storage wgrad"
+    close(outs[0], dy.double().t() @ x.double(), rtol=5e-5, what="bf16-storage wgrad")
+
+
 def test_gemm_bf16_compute_split_k(hip):
     torch.manual_seed(31)
     M, N, K = 256, 512, 20000
