@@ -28,6 +28,7 @@ struct ConvArgs {
     // together do 9/4 tap-GEMMs per pixel instead of 9 with 3/4 of the rows masked.
     int par_on, Hp, Wp, ph, pw, kh0, kw0, nth, ntw;
     int w16;                     // the kernel tensor is bf16 in memory (bf16 compute only)
+    int x16;                     // the source tensor (x for fwd, dy for dgrad) is bf16 in memory
 };
 
 // tap (kh, kw) of K-tile group t (t-th tap of the launch)
@@ -192,6 +193,7 @@ struct ConvWgradArgs {
     long long part_stride;   // 9*Ci*Co when the splits write partial slabs, 0 for the atomic fallback
     int tiles_m, tiles_n;
     EpiArgs e;
+    int s16;                 // x and dy are bf16 in memory (bf16 activation storage; bf16 compute only)
 };
 
 template <int BM>
@@ -322,21 +324,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
 // ------------------------------------------------------------------------------------------------
 // bf16-compute variants (fp32 storage, bf16 MFMA; see gemm_bf16_core.h).  Channel counts must be % 32.
 // ------------------------------------------------------------------------------------------------
-template <int BM, bool DGRAD>
+// X16: the source tensor is bf16 in memory (bf16 activation storage): 16-byte chunks of 8 channels, no conversion
+template <int BM, bool DGRAD, bool X16>
 struct LoaderConvAb {
-    static constexpr int NV = BM / 32;
+    static constexpr int NV = X16 ? BM / 64 : BM / 32;
+    typedef typename std::conditional<X16, uint4, float4>::type Reg;
     BufSrc src;
     int n_[NV], h_[NV], w_[NV];
     bool ok[NV];
     int kq, tid;
 
     __device__ __forceinline__ void init(const ConvArgs &a, int m0, int tid_) {
-        src.init(a.src, (long long)a.N * a.Hs * a.Ws * a.Cs);
+        src.init_bytes(a.src, (long long)a.N * a.Hs * a.Ws * a.Cs * (X16 ? 2 : 4));
         tid = tid_;
-        kq = (tid & 7) * 4;
+        kq = X16 ? (tid & 3) * 8 : (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int m = m0 + (tid >> 3) + 32 * i;
+            const int m = m0 + (X16 ? (tid >> 2) + 64 * i : (tid >> 3) + 32 * i);
             ok[i] = m < a.M;
             const int mm = ok[i] ? m : 0;
             int wd, hd;
@@ -356,7 +360,7 @@ struct LoaderConvAb {
         }
     }
     // halo / stride-parity / tile-edge lanes take the out-of-range offset: the descriptor returns zeros, no branch
-    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
+    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, Reg (&r)[NV]) const {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BF_BK + kq;
         int kh, kw;
@@ -382,20 +386,25 @@ struct LoaderConvAb {
                 ws = w_[i] + kw;
                 v = v && hs >= 0 && ws >= 0 && hs < a.Hs && ws < a.Ws;
             }
-            const unsigned off = ((unsigned)((n_[i] * a.Hs + hs) * a.Ws + ws) * (unsigned)a.Cs + (unsigned)c0) * 4u;
-            r[i] = src.ld4(v ? off : BUF_OOB);
+            const unsigned off = ((unsigned)((n_[i] * a.Hs + hs) * a.Ws + ws) * (unsigned)a.Cs + (unsigned)c0) * (X16 ? 2u : 4u);
+            if constexpr (X16) r[i] = src.ld16(v ? off : BUF_OOB);
+            else r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NV]) const {
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const Reg (&r)[NV]) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint2 *>(&S[row][kq]) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+            if constexpr (X16) {
+                *reinterpret_cast<uint4 *>(&S[(tid >> 2) + 64 * i][kq]) = r[i];
+            } else {
+                const int row = (tid >> 3) + 32 * i;
+                *reinterpret_cast<uint2 *>(&S[row][kq]) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+            }
         }
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool W16>
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool W16, bool X16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_bf16c_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     const int cpt = a.Cs / BF_BK;
     const int nkt = (a.par_on ? a.nth * a.ntw : 9) * cpt;
     const long long tapstride = (long long)a.Ci * a.Co;
-    LoaderConvAb<BM, DGRAD> la;
+    LoaderConvAb<BM, DGRAD, X16> la;
     la.init(a, m0, tid);
     // fwd weights: transpose-read image; W16: the kernel is already bf16 in memory (per-step weight shadow)
     using LB = typename std::conditional<W16, typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN>>::type,
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 ra[LoaderConvAb<BM, DGRAD>::NV];
+    typename LoaderConvAb<BM, DGRAD, X16>::Reg ra[LoaderConvAb<BM, DGRAD, X16>::NV];
     typename LB::Reg rb[NRB];
     auto load_b = [&](int kt) {
         const int tap = kt / cpt;
@@ -456,16 +465,17 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
 
 // wgrad: A'[i = ci][k = m] gathered into a transpose-read image (gemm_bf16_core.h LoaderMNt): unit u = t + 256*i holds
 // the float4 of channels ci0 + 16*ib + 4*c of reduction row (output pixel) k = 4*kb + kr of the tile.
-template <int BM>
+template <int BM, bool S16>
 struct LoaderWgradAt {
     static constexpr int NB = BM / 16;
     static constexpr int NU = BM / 32;
+    typedef typename std::conditional<S16, uint2, float4>::type Reg;
     BufSrc src;
     int n_[NU], h_[NU], w_[NU], m_[NU];
     int tid, ci0, kh, kw;
 
     __device__ __forceinline__ void init(const ConvWgradArgs &a, int ci0_, int tap, int m_begin, int tid_) {
-        src.init(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci);
+        src.init_bytes(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci * (S16 ? 2 : 4));
         tid = tid_; ci0 = ci0_;
         kh = tap / 3; kw = tap - kh * 3;
 #pragma unroll
@@ -479,15 +489,16 @@ struct LoaderWgradAt {
             n_[i] = t / a.Ho;
         }
     }
-    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, float4 (&r)[NU]) const {
+    __device__ __forceinline__ void load(const ConvWgradArgs &a, int m_end, Reg (&r)[NU]) const {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + 256 * i;
             const int c = ci0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
             const int hs = h_[i] * a.stride - a.pad + kh, ws = w_[i] * a.stride - a.pad + kw;
             const bool v = m_[i] < m_end && hs >= 0 && ws >= 0 && hs < a.Hi && ws < a.Wi && c < a.Ci;
-            const unsigned off = ((unsigned)((n_[i] * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)c) * 4u;
-            r[i] = src.ld4(v ? off : BUF_OOB);
+            const unsigned off = ((unsigned)((n_[i] * a.Hi + hs) * a.Wi + ws) * (unsigned)a.Ci + (unsigned)c) * (S16 ? 2u : 4u);
+            if constexpr (S16) r[i] = src.ld8(v ? off : BUF_OOB);
+            else r[i] = src.ld4(v ? off : BUF_OOB);
         }
     }
     __device__ __forceinline__ void advance(const ConvWgradArgs &a) {
@@ -499,15 +510,17 @@ struct LoaderWgradAt {
             while (h_[i] >= a.Ho) { h_[i] -= a.Ho; n_[i] += 1; }
         }
     }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const float4 (&r)[NU]) const {
+    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const Reg (&r)[NU]) const {
         unsigned short *flat = &S[0][0];
 #pragma unroll
-        for (int i = 0; i < NU; ++i)
-            *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+        for (int i = 0; i < NU; ++i) {
+            if constexpr (S16) *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = r[i];
+            else *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+        }
     }
 };
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool S16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_wgrad_bf16c_kernel(ConvWgradArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
@@ -521,9 +534,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     if (m_begin >= m_end) return;
     const int nkt = (m_end - m_begin + BF_BK - 1) / BF_BK;
-    LoaderWgradAt<BM> la;
+    LoaderWgradAt<BM, S16> la;
     la.init(a, ci0, tap, m_begin, tid);
-    LoaderMNt<BN> lb;
+    typename std::conditional<S16, LoaderMNth<BN>, LoaderMNt<BN>>::type lb;      // dy: same storage type as x
     lb.init(a.dy, a.Co, co0, a.Co, a.M, true, tid);
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -532,7 +545,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 ra[LoaderWgradAt<BM>::NU], rb[LoaderMNt<BN>::NU];
+    typename LoaderWgradAt<BM, S16>::Reg ra[LoaderWgradAt<BM, S16>::NU];
+    typename std::conditional<S16, uint2, float4>::type rb[LoaderMNt<BN>::NU];
     la.load(a, m_end, ra);
     lb.load(m_begin, m_end, rb);
     la.store(sm.A[0], ra);
@@ -574,6 +588,7 @@ struct WgradFusedSmem {
     unsigned short D[2][32 * 64];         // dy tile (transpose-read image, BMN = 64)
 };
 
+template <bool S16>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kernel(ConvWgradArgs a, int units_per_split,
                                                                                  int chunks) {
     constexpr int SMEM = (int)sizeof(WgradFusedSmem) > SmemBytes<64, 64, 2>::VALUE ? (int)sizeof(WgradFusedSmem)
@@ -589,8 +604,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
     const int u_end = min(total_units, u_begin + units_per_split);
     if (u_begin >= u_end) return;
     BufSrc xs, ds;
-    xs.init(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci);
-    ds.init(a.dy, (long long)a.N * a.Ho * a.Wo * a.Co);
+    xs.init_bytes(a.x, (long long)a.N * a.Hi * a.Wi * a.Ci * (S16 ? 2 : 4));
+    ds.init_bytes(a.dy, (long long)a.N * a.Ho * a.Wo * a.Co * (S16 ? 2 : 4));
 
     f32x16 acc[9];
 #pragma unroll
@@ -598,7 +613,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    float4 rx[7], rd[2];
+    typedef typename std::conditional<S16, uint2, float4>::type Reg;     // 4 channels of one pixel
+    Reg rx[7], rd[2];
     auto load_unit = [&](int u) {
         const int chunk = u % chunks;
         const int t = u / chunks;
@@ -611,8 +627,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             const int j = 4 * (v >> 6) + ((v >> 2) & 3);
             const int col = 16 * ((v >> 4) & 3) + 4 * (v & 3);
             const bool ok = wo0 + j < a.Wo;
-            const unsigned off = ((unsigned)((n * a.Ho + ho) * a.Wo + wo0 + j) * (unsigned)a.Co + (unsigned)(co0 + col)) * 4u;
-            rd[i] = ds.ld4(ok ? off : BUF_OOB);
+            const unsigned off = ((unsigned)((n * a.Ho + ho) * a.Wo + wo0 + j) * (unsigned)a.Co + (unsigned)(co0 + col)) * (S16 ? 2u : 4u);
+            if constexpr (S16) rd[i] = ds.ld8(ok ? off : BUF_OOB);
+            else rd[i] = ds.ld4(ok ? off : BUF_OOB);
         }
         // input patch: slot v -> (patch pixel pp = v / 16 in [0, 102), float4 c4 = v % 16 of the 64 channels)
 #pragma unroll
@@ -622,14 +639,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             const int kh = pp / 34, c = pp - kh * 34;
             const int hi = ho - 1 + kh, wi = wo0 - 1 + c;
             const bool ok = pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-            const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * 4u;
-            rx[i] = xs.ld4(ok ? off : BUF_OOB);
+            const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * (S16 ? 2u : 4u);
+            if constexpr (S16) rx[i] = xs.ld8(ok ? off : BUF_OOB);
+            else rx[i] = xs.ld4(ok ? off : BUF_OOB);
         }
     };
     auto store_unit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = make_uint2(pack_bf16(rd[i].x, rd[i].y), pack_bf16(rd[i].z, rd[i].w));
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (S16) *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = rd[i];
+            else *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = make_uint2(pack_bf16(rd[i].x, rd[i].y), pack_bf16(rd[i].z, rd[i].w));
+        }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int v = tid + 256 * i;
@@ -637,7 +657,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             if (pp < 102) {
                 const int kh = pp / 34, c = pp - kh * 34;
                 const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (c & 3) * 16 + (c4 & 3) * 4;
-                *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
+                if constexpr (S16) *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = rx[i];
+                else *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
             }
         }
     };
@@ -805,6 +826,85 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
     }
 }
 
+// bf16-storage twins of the two pooling kernels (4 channels = 8 bytes per thread)
+__device__ __forceinline__ float4 bf4_to_f4(uint2 v) {
+    return make_float4(bf16_bits_to_f32(v.x & 0xFFFFu), bf16_bits_to_f32(v.x >> 16), bf16_bits_to_f32(v.y & 0xFFFFu), bf16_bits_to_f32(v.y >> 16));
+}
+__global__ __launch_bounds__(256) void maxpool_fwd_bf16_kernel(const uint2 *__restrict__ x, uint2 *__restrict__ y,
+                                                               uint32_t *__restrict__ amax, int N, int H, int W, int C4,
+                                                               int Ho, int Wo, long long total4) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total4;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const unsigned pix = (unsigned)(idx / C4);
+        const int wo = (int)(pix % (unsigned)Wo);
+        const unsigned t = pix / (unsigned)Wo;
+        const int ho = (int)(t % (unsigned)Ho);
+        const int n = (int)(t / (unsigned)Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        uint32_t bi[4] = {0, 0, 0, 0};
+        uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+        (void)braw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // the explicit ZeroPadding2D(1) takes part in the max
+                if (hi >= 0 && wi >= 0 && hi < H && wi < W) v = bf4_to_f4(x[((long long)(n * H + hi) * W + wi) * C4 + c4]);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = (uint32_t)(kh * 3 + kw); }
+            }
+        y[idx] = make_uint2(f32_to_bf16_pair(best[0], best[1]), f32_to_bf16_pair(best[2], best[3]));   // exact: inputs are bf16
+        amax[idx] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const uint2 *__restrict__ dy, const uint32_t *__restrict__ amax,
+                                                               const uint2 *__restrict__ x, uint2 *__restrict__ dx, int N, int H,
+                                                               int W, int C4, int Ho, int Wo, long long total4) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total4;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const unsigned pix = (unsigned)(idx / C4);
+        const int w = (int)(pix % (unsigned)W);
+        const unsigned t = pix / (unsigned)W;
+        const int h = (int)(t % (unsigned)H);
+        const int n = (int)(t / (unsigned)H);
+        const float4 xv = bf4_to_f4(x[idx]);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = h + 1 - kh;
+            if (th < 0 || (th & 1)) continue;
+            const int ho = th >> 1;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = w + 1 - kw;
+                if (tw < 0 || (tw & 1)) continue;
+                const int wo = tw >> 1;
+                if (wo >= Wo) continue;
+                const long long o4 = ((long long)(n * Ho + ho) * Wo + wo) * C4 + c4;
+                const uint32_t am = amax[o4];
+                const float4 d = bf4_to_f4(dy[o4]);
+                const uint32_t tap = (uint32_t)(kh * 3 + kw);
+                if ((am & 0xFFu) == tap) g.x += d.x;
+                if (((am >> 8) & 0xFFu) == tap) g.y += d.y;
+                if (((am >> 16) & 0xFFu) == tap) g.z += d.z;
+                if ((am >> 24) == tap) g.w += d.w;
+            }
+        }
+        g.x = xv.x > 0.0f ? g.x : 0.0f;
+        g.y = xv.y > 0.0f ? g.y : 0.0f;
+        g.z = xv.z > 0.0f ? g.z : 0.0f;
+        g.w = xv.w > 0.0f ? g.w : 0.0f;
+        dx[idx] = make_uint2(f32_to_bf16_pair(g.x, g.y), f32_to_bf16_pair(g.z, g.w));
+    }
+}
+
 __global__ void subsample2_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4,
                                       int Ho, int Wo, long long total) {
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -847,11 +947,16 @@ static void launch_conv_bf16(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cd, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
-    if (a.w16) {
-        if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
-    } else if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+#define DETR_CONV_LAUNCH(W16_, X16_)                                                                                        \
+    do {                                                                                                                        \
+        if (dgrad) hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, true, W16_, X16_>), grid, block, 0, s, a);          \
+        else hipLaunchKernelGGL((conv3x3_bf16c_kernel<BM, BN, WGM, WGN, false, W16_, X16_>), grid, block, 0, s, a);                \
+    } while (0)
+    if (a.w16 && a.x16) DETR_CONV_LAUNCH(true, true);
+    else if (a.w16) DETR_CONV_LAUNCH(true, false);
+    else if (a.x16) DETR_CONV_LAUNCH(false, true);
+    else DETR_CONV_LAUNCH(false, false);
+#undef DETR_CONV_LAUNCH
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -896,7 +1001,8 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
         a.e.atomic = 1;   // accumulate onto dw
     }
     dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
-    if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
+    if (bf16c && a.s16) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
+    else if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
 }
@@ -934,7 +1040,8 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
         a.e.atomic = 1;   // accumulate onto dw (split == 1, or the atomic fallback without a workspace)
     }
     dim3 grid((unsigned)tiles, 1, (unsigned)split), block(GEMM_THREADS);
-    hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel, grid, block, 0, s, a, ups, chunks);
+    if (a.s16) hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<true>, grid, block, 0, s, a, ups, chunks);
+    else hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<false>, grid, block, 0, s, a, ups, chunks);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
 }
 
@@ -967,6 +1074,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.drop_scale = 0.0f; e.drop_thresh = 0; e.drop_seed = 0;
     e.vec = (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
             (!d->residual || aligned16(d->residual)) && (!d->mask || aligned16(d->mask));   // channel counts are % 16
+    e.c16 = (mode != 2 && d->y_dtype == 1); e.r16 = d->r_dtype == 1; e.m16 = d->m_dtype == 1;
     if (mode == 2) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0, "conv3x3 wgrad: only scale/alpha epilogue");
         ConvWgradArgs a;
@@ -974,6 +1082,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         a.stride = d->stride; a.pad = d->pad;
         a.x = d->x; a.dy = d->w; a.dw = d->y;
         a.M = d->N * d->Ho * d->Wo;
+        a.s16 = (d->x_dtype == 1);
+        DETR_REQUIRE(d->x_dtype == d->w_dtype && d->y_dtype == 0, "conv3x3 wgrad: x and dy must share their storage type, dw is fp32");
+        DETR_REQUIRE(!a.s16 || (d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0), "conv3x3 wgrad: bf16 tensors need compute = bf16");
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
         const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
@@ -1011,6 +1122,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.ldmask = a.Cd;
     a.e = e;
     a.w16 = (d->w_dtype == 1);
+    a.x16 = (d->x_dtype == 1);
+    DETR_REQUIRE((d->x_dtype == 0 && d->y_dtype == 0 && d->r_dtype == 0 && d->m_dtype == 0) || (d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0),
+                 "conv3x3: bf16 tensors need compute = bf16 and channel counts %% 32 == 0");
     DETR_REQUIRE(d->w_dtype == 0 || (d->w_dtype == 1 && d->compute == 1 && mode != 2 && d->Ci % 32 == 0 && d->Co % 32 == 0),
                  "conv3x3: a bf16 kernel tensor needs compute = bf16, mode 0/1 and channel counts %% 32 == 0");
     a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
@@ -1103,5 +1217,29 @@ extern "C" int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N
     hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)dy, (float4 *)dx, H, W, C / 4, Ho, Wo, total);
     DETR_LAUNCH_CHECK("subsample2 bwd");
+    return 0;
+}
+
+extern "C" int detr_hip_maxpool3x3s2_fwd_bf16(const uint16_t *x, uint16_t *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W,
+                                              int32_t C, int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(x && y && argmax && C % 4 == 0, "maxpool fwd bf16: bad operands");
+    DETR_REQUIRE(((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 8 == 0) && ((uintptr_t)argmax % 4 == 0), "maxpool fwd bf16: alignment");
+    DETR_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool fwd: bad output size");
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint2 *)x,
+                       (uint2 *)y, (uint32_t *)argmax, N, H, W, C / 4, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("maxpool fwd bf16");
+    return 0;
+}
+
+extern "C" int detr_hip_maxpool3x3s2_bwd_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *x, uint16_t *dx, int32_t N,
+                                              int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream) {
+    DETR_REQUIRE(dy && argmax && x && dx && C % 4 == 0, "maxpool bwd bf16: bad operands");
+    DETR_REQUIRE(((uintptr_t)dy % 8 == 0) && ((uintptr_t)x % 8 == 0) && ((uintptr_t)dx % 8 == 0) && ((uintptr_t)argmax % 4 == 0),
+                 "maxpool bwd bf16: alignment");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint2 *)dy,
+                       (const uint32_t *)argmax, (const uint2 *)x, (uint2 *)dx, N, H, W, C / 4, Ho, Wo, total);
+    DETR_LAUNCH_CHECK("maxpool bwd bf16");
     return 0;
 }

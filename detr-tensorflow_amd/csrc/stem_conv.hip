@@ -156,7 +156,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_fwd_kernel(StemArgs a) {
 // weight gradient: dw[k][co] (+)= sum_m gather(img)[m][k] * dy[m][co]
 // grid = (3 tiles of 64 k, 1, row splits); reduction over the output pixels of the split
 // ------------------------------------------------------------------------------------------------
-template <bool BF>
+template <bool BF, bool D16>
 __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
     constexpr int BM = 64, BN = 64, BK = BF ? BF_BK : GEMM_BK;
     constexpr int SMEM = BF ? BfSmemBytes<BM, BN, 2>::VALUE : SmemBytes<BM, BN, 2>::VALUE;
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
     };
     if constexpr (BF) {
         BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
-        LoaderMNt<BN> lb;
+        typename std::conditional<D16, LoaderMNth<BN>, LoaderMNt<BN>>::type lb;     // D16: dy is bf16 in memory
         lb.init(a.dy, 64, 0, 64, a.M, true, tid);
-        float4 rb[LoaderMNt<BN>::NU];
+        typename std::conditional<D16, uint2, float4>::type rb[LoaderMNt<BN>::NU];
         auto store_a = [&](unsigned short (*S)[BF_LD]) {
             unsigned short *flat = &S[0][0];
 #pragma unroll
@@ -283,6 +283,8 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
     e.vec = (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias));
     const bool bf = d->compute == 1;
     if (mode == 0) {
+        DETR_REQUIRE(d->y_dtype == 0 || bf, "stem conv: a bf16 output needs compute = bf16");
+        e.c16 = d->y_dtype == 1;
         a.w = d->w; a.y = d->y; a.e = e;
         dim3 grid((unsigned)cdiv(a.M, 64));
         if (bf) hipLaunchKernelGGL(stem_fwd_kernel<true>, grid, dim3(GEMM_THREADS), 0, s, a);
@@ -311,8 +313,10 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
     }
     a.e = e;
     dim3 grid(3, 1, (unsigned)split);
-    if (bf) hipLaunchKernelGGL(stem_wgrad_kernel<true>, grid, dim3(GEMM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<false>, grid, dim3(GEMM_THREADS), 0, s, a);
+    DETR_REQUIRE(d->w_dtype == 0 || bf, "stem conv wgrad: a bf16 dy needs compute = bf16");
+    if (bf && d->w_dtype == 1) hipLaunchKernelGGL((stem_wgrad_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else if (bf) hipLaunchKernelGGL((stem_wgrad_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, s, a);
     DETR_LAUNCH_CHECK("stem conv wgrad");
     if (partial) {
         launch_splitk_reduce(d->workspace, split, part, STEM_K, 64, d->y, 64, fin.alpha, fin.scale, s);

@@ -40,7 +40,8 @@ class StemDesc(Structure):
                 ("img", c_void_p), ("w", c_void_p), ("y", c_void_p),
                 ("alpha", c_float), ("scale", c_void_p), ("bias", c_void_p),
                 ("act", c_int32), ("split", c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32),
+                ("w_dtype", c_int32), ("y_dtype", c_int32)]
 
 
 class Conv3x3Desc(Structure):
@@ -50,7 +51,8 @@ class Conv3x3Desc(Structure):
                 ("alpha", c_float),
                 ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
                 ("act", c_int32), ("split", c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32), ("w_dtype", c_int32)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32), ("w_dtype", c_int32),
+                ("x_dtype", c_int32), ("y_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
 
 
 class SetLossDesc(Structure):
@@ -67,6 +69,9 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
+    "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "detr_hip_maxpool3x3s2_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p],
     "detr_hip_cvt_bf16": [f32p, c_void_p, c_int64, c_void_p],
     "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
     "detr_hip_stem_conv7x7_f32": [POINTER(StemDesc), c_int32, c_void_p],
@@ -295,7 +300,8 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     d = Conv3x3Desc()
     d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.stride, d.pad = N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
-    d.w_dtype = 1 if (mode != 2 and w.dtype == torch.bfloat16) else 0
+    is16 = lambda t: 1 if (t is not None and t.dtype == torch.bfloat16) else 0      # bf16 weight shadow / activation storage
+    d.w_dtype, d.x_dtype, d.y_dtype, d.r_dtype, d.m_dtype = is16(w), is16(x), is16(y), is16(residual), is16(mask)
     d.alpha = alpha
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split
@@ -319,6 +325,8 @@ def stem_conv(mode, img, w, y, N, H, W, Ho, Wo, *, alpha=1.0, scale=None, bias=N
     d.alpha = alpha
     d.scale, d.bias = ptr(scale), ptr(bias)
     d.act, d.split = act, split
+    d.w_dtype = 1 if (mode == 2 and w.dtype == torch.bfloat16) else 0       # bf16 activation storage: dy / the output
+    d.y_dtype = 1 if (mode == 0 and y.dtype == torch.bfloat16) else 0
     d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
     ev0 = PROFILER.begin() if PROFILER is not None else None

@@ -32,6 +32,9 @@ BN_EPS = 1e-5
 LN_EPS = 1e-5
 # implicit-GEMM stem convolution (default) vs the im2col buffer + GEMM path (DETR_HIP_IMPLICIT_STEM=0)
 IMPLICIT_STEM = os.environ.get("DETR_HIP_IMPLICIT_STEM", "1") != "0"
+# bf16 STORAGE of the backbone activations and their gradients in precision="bf16" (default on; DETR_HIP_ACT16=0 keeps
+# fp32 storage with bf16 MFMA operands only)
+ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
 # fused flash-style attention (default) vs the materialised GEMM + softmax + GEMM path (DETR_HIP_FUSED_ATTN=0)
 FUSED_ATTENTION = os.environ.get("DETR_HIP_FUSED_ATTN", "1") != "0"
 
@@ -311,7 +314,9 @@ class DetrEngine:
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         M1 = B * H1 * W1
         ws = self._scaled_kernel("backbone/conv1/kernel", "backbone/bn1")
-        stem = self.buf("stem:out", (B, H1, W1, 64))
+        adt = torch.bfloat16 if (self.compute == 1 and ACT16) else torch.float32      # storage type of backbone activations
+        self._adt = adt
+        stem = self.buf("stem:out", (B, H1, W1, 64), adt)
         if IMPLICIT_STEM:       # implicit GEMM: the 7x7x3 patches are gathered from the image by the A loader (stem_conv.hip)
             hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift["backbone/bn1"], act=1)
         else:                   # im2col buffer + GEMM (DETR_HIP_IMPLICIT_STEM=0)
@@ -319,9 +324,10 @@ class DetrEngine:
             hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
             hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift["backbone/bn1"], act=1)
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        pool = self.buf("stem:pool", (B, H2, W2, 64))
+        pool = self.buf("stem:pool", (B, H2, W2, 64), adt)
         amax = self.buf("stem:amax", (B, H2, W2, 64), torch.uint8)
-        hip.call("detr_hip_maxpool3x3s2_fwd_f32", stem.data_ptr(), pool.data_ptr(), amax.data_ptr(), B, H1, W1, 64, H2, W2)
+        hip.call("detr_hip_maxpool3x3s2_fwd_bf16" if adt == torch.bfloat16 else "detr_hip_maxpool3x3s2_fwd_f32", stem.data_ptr(),
+                 pool.data_ptr(), amax.data_ptr(), B, H1, W1, 64, H2, W2)
         # ---------------- residual stages (resnet_backbone.py:116-137) ----------------
         x, h, w, cin = pool, H2, W2, 64
         self._block_meta = []
@@ -332,22 +338,24 @@ class DetrEngine:
                 stride = 2 if (b == 0 and li > 0) else 1
                 ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
                 M_in, M_out = B * h * w, B * ho * wo
-                y1 = self.buf(f"{p}:y1", (B, h, w, d1))
+                y1 = self.buf(f"{p}:y1", (B, h, w, d1), adt)
                 self._conv1x1_fwd(x, M_in, cin, d1, f"{p}/conv1/kernel", f"{p}/bn1", y1)
-                y2 = self.buf(f"{p}:y2", (B, ho, wo, d1))
+                y2 = self.buf(f"{p}:y2", (B, ho, wo, d1), adt)
                 hip.conv3x3(0, y1, self._scaled_kernel(f"{p}/conv2/kernel", f"{p}/bn2"), y2, B, h, w, d1, ho, wo, d1,
                             stride, bias=self.bn_shift[f"{p}/bn2"], act=1)
                 if b == 0:
                     if stride == 2:
-                        xs = self.buf(f"{p}:xs", (B, ho, wo, cin))
-                        hip.call("detr_hip_subsample2_fwd_f32", x.data_ptr(), xs.data_ptr(), B, h, w, cin, ho, wo)
+                        xs = self.buf(f"{p}:xs", (B, ho, wo, cin), adt)
+                        # a plain 16-byte-chunk gather: bf16 tensors pass as cin/2 "float" channels
+                        hip.call("detr_hip_subsample2_fwd_f32", x.data_ptr(), xs.data_ptr(), B, h, w,
+                                 cin // 2 if adt == torch.bfloat16 else cin, ho, wo)
                     else:
                         xs = x
-                    idn = self.buf(f"{p}:idn", (B, ho, wo, d2))
+                    idn = self.buf(f"{p}:idn", (B, ho, wo, d2), adt)
                     self._conv1x1_fwd(xs, M_out, cin, d2, f"{p}/downsample_0/kernel", f"{p}/downsample_1", idn, act=0)
                 else:
                     xs, idn = None, x
-                out = self.buf(f"{p}:out", (B, ho, wo, d2))
+                out = self.buf(f"{p}:out", (B, ho, wo, d2), adt)
                 self._conv1x1_fwd(y2, M_out, d1, d2, f"{p}/conv3/kernel", f"{p}/bn3", out, residual=idn)
                 self._block_meta.append(dict(p=p, x=x, xs=xs, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, cin=cin,
                                              d1=d1, d2=d2, stride=stride, first=(b == 0)))
@@ -555,7 +563,8 @@ class DetrEngine:
                 for i in (1, 2, 3):
                     on_bucket(i)
             return
-        g = self.buf("scratch:g_feat", feat.shape)
+        adt = self._adt
+        g = self.buf("scratch:g_feat", feat.shape, adt)
         hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
         # ---------------- residual stages ----------------
         n_blocks = len(self._block_meta)
@@ -570,16 +579,16 @@ class DetrEngine:
             ws3 = self._bufs[f"{wk}:{p}/conv3/kernel"]
             # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
             self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{p}/conv3/kernel"], d2, scale=self.bn_scale[f"{p}/bn3"])
-            dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1))
+            dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1), adt)
             hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
             # conv2 (3x3)
             hip.conv3x3(2, y1, dz2, G[f"{p}/conv2/kernel"], B, h, w, d1, ho, wo, d1, stride, scale=self.bn_scale[f"{p}/bn2"])
-            dz1 = self.buf(f"scratch:dz1:{d1}:{h}", (B, h, w, d1))
+            dz1 = self.buf(f"scratch:dz1:{d1}:{h}", (B, h, w, d1), adt)
             hip.conv3x3(1, dz2, ws2, dz1, B, h, w, d1, ho, wo, d1, stride, mask=y1)
             # conv1
             self._wgrad(cin, d1, M_in, x, cin, dz1, d1, G[f"{p}/conv1/kernel"], d1, scale=self.bn_scale[f"{p}/bn1"])
             is_first_block = bi == 0
-            gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin))
+            gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin), adt)
             mask = None if is_first_block else x           # x = ReLU output of the previous block
             if m["first"]:
                 xs = m["xs"]
@@ -587,12 +596,13 @@ class DetrEngine:
                 self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{p}/downsample_0/kernel"], d2,
                             scale=self.bn_scale[f"{p}/downsample_1"])
                 if stride == 2:
-                    dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin))
+                    dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
                     hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
-                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin))
-                    hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin, ho, wo)
+                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
+                    hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w,
+                             cin // 2 if adt == torch.bfloat16 else cin, ho, wo)
                 else:
-                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin))
+                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
                     hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
             else:
                 idg = g
@@ -608,9 +618,9 @@ class DetrEngine:
         stem, pool, amax = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax"))
         H1, W1 = stem.shape[1], stem.shape[2]
         H2, W2 = pool.shape[1], pool.shape[2]
-        d_stem = self.buf("scratch:d_stem", stem.shape)
-        hip.call("detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(), amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1,
-                 W1, 64, H2, W2)
+        d_stem = self.buf("scratch:d_stem", stem.shape, adt)
+        hip.call("detr_hip_maxpool3x3s2_bwd_bf16" if adt == torch.bfloat16 else "detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(),
+                 amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
         if IMPLICIT_STEM:
             M1 = B * H1 * W1
             hip.stem_conv(2, self.images, d_stem, G["backbone/conv1/kernel"], B, self._shape[1], self._shape[2], H1, W1,

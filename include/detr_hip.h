@@ -116,6 +116,9 @@ typedef struct {
     float *workspace; int64_t workspace_bytes;   /* wgrad: scratch for deterministic split reduction (see detr_gemm_desc) */
     int32_t compute;     /* 0 = exact fp32 MFMA, 1 = bf16 MFMA (see detr_gemm_desc) */
     int32_t w_dtype;     /* modes 0/1 with compute = 1: 1 = `w` points to bf16 data (weight shadow, see detr_gemm_desc.b_dtype) */
+    /* bf16 storage of the activation tensors (see detr_gemm_desc.a_dtype): x = the tensor passed as `x`, y = the one passed as `y`
+     * (mode 2: x = input activations, `w` = dy whose dtype is w_dtype, y = dw always fp32), r = residual, m = mask */
+    int32_t x_dtype, y_dtype, r_dtype, m_dtype;
 } detr_conv3x3_desc;
 int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
 
@@ -151,6 +154,8 @@ typedef struct {
     int32_t split;
     float *workspace; int64_t workspace_bytes;
     int32_t compute;        /* 0 = exact fp32 MFMA, 1 = bf16 MFMA */
+    int32_t w_dtype;        /* mode 2: 1 = dy is bf16 in memory (bf16 activation storage) */
+    int32_t y_dtype;        /* mode 0: 1 = the output is stored as bf16 */
 } detr_stem_desc;
 int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, void *stream);
 int detr_hip_maxpool3x3s2_fwd_f32(const float *x, float *y, uint8_t *argmax, int32_t N, int32_t H,
@@ -160,6 +165,12 @@ int detr_hip_maxpool3x3s2_bwd_f32(const float *dy, const uint8_t *argmax, const 
                                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                   void *stream);
 /* stride-2 1x1 downsample helpers (resnet_backbone.py:111-113): gather / zero-filled scatter */
+/* bf16-storage twins of the stem max pooling (see detr_gemm_desc.a_dtype); the subsample kernels are plain 16-byte copies and
+ * serve bf16 tensors with C/2 "float" channels. */
+int detr_hip_maxpool3x3s2_fwd_bf16(const uint16_t *x, uint16_t *y, uint8_t *argmax, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, int32_t Ho, int32_t Wo, void *stream);
+int detr_hip_maxpool3x3s2_bwd_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *x, uint16_t *dx, int32_t N,
+                                   int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_fwd_f32(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C,
                                 int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,

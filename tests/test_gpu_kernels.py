@@ -826,6 +826,47 @@ def test_gemm_bf16_activation_storage(hip, M, N, K, bk):
     close(outs[0], dy.double().t() @ x.double(), rtol=5e-5, what="bf16-storage wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 25, 42, 256, 256, 1)])
+def test_conv3x3_bf16_activation_storage(hip, N, H, W, Ci, Co, stride):
+    """conv3x3 forward / dgrad / wgrad and the stem max pooling on bf16-STORED tensors: bit-identical to bf16(result of the
+    fp32-storage kernels) on the same (bf16-representable) values; weight gradients (fp32) identical."""
+    torch.manual_seed(N + H + W + Ci + stride + 9)
+    hip.ensure_workspace(DEV)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    b16 = lambda t: t.to(torch.bfloat16)
+    x, dy = g(_bf(torch.randn(N, H, W, Ci)).float()), g(_bf(torch.randn(N, Ho, Wo, Co)).float())
+    w16 = g(_bf(torch.randn(3, 3, Ci, Co) / (3 * Ci ** 0.5)).float()).to(torch.bfloat16)
+    shift, res, msk = g(torch.randn(Co)), g(_bf(torch.randn(N, Ho, Wo, Co)).float()), g(_bf(torch.randn(N, H, W, Ci)).float())
+    y32, y16 = torch.zeros(N, Ho, Wo, Co, device=DEV), torch.zeros(N, Ho, Wo, Co, device=DEV, dtype=torch.bfloat16)
+    hip.conv3x3(0, x, w16, y32, N, H, W, Ci, Ho, Wo, Co, stride, bias=shift, residual=res, act=1, compute=1)
+    hip.conv3x3(0, b16(x), w16, y16, N, H, W, Ci, Ho, Wo, Co, stride, bias=shift, residual=b16(res), act=1, compute=1)
+    assert torch.equal(y16, b16(y32)) and float(y32.abs().max()) > 0
+    dx32, dx16 = torch.zeros(N, H, W, Ci, device=DEV), torch.zeros(N, H, W, Ci, device=DEV, dtype=torch.bfloat16)
+    hip.conv3x3(1, dy, w16, dx32, N, H, W, Ci, Ho, Wo, Co, stride, mask=msk, compute=1)
+    hip.conv3x3(1, b16(dy), w16, dx16, N, H, W, Ci, Ho, Wo, Co, stride, mask=b16(msk), compute=1)
+    assert torch.equal(dx16, b16(dx32)) and float(dx32.abs().max()) > 0
+    dws = []
+    for cast in (lambda t: t, b16):
+        dw = torch.zeros(3, 3, Ci, Co, device=DEV)
+        hip.conv3x3(2, cast(x), cast(dy), dw, N, H, W, Ci, Ho, Wo, Co, stride, split=5, compute=1)
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1]) and float(dws[0].abs().max()) > 0
+    if stride == 1 and Ci == 64:          # the stem pooling pair on the same tensors
+        C = Ci
+        H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p32, p16 = torch.zeros(N, H2, W2, C, device=DEV), torch.zeros(N, H2, W2, C, device=DEV, dtype=torch.bfloat16)
+        a32, a16 = (torch.zeros(N, H2, W2, C, device=DEV, dtype=torch.uint8) for _ in range(2))
+        hip.call("detr_hip_maxpool3x3s2_fwd_f32", x.data_ptr(), p32.data_ptr(), a32.data_ptr(), N, H, W, C, H2, W2)
+        hip.call("detr_hip_maxpool3x3s2_fwd_bf16", b16(x).data_ptr(), p16.data_ptr(), a16.data_ptr(), N, H, W, C, H2, W2)
+        assert torch.equal(p16, b16(p32)) and torch.equal(a16, a32)
+        gp = g(_bf(torch.randn(N, H2, W2, C)).float())
+        d32, d16 = torch.zeros(N, H, W, C, device=DEV), torch.zeros(N, H, W, C, device=DEV, dtype=torch.bfloat16)
+        hip.call("detr_hip_maxpool3x3s2_bwd_f32", gp.data_ptr(), a32.data_ptr(), x.data_ptr(), d32.data_ptr(), N, H, W, C, H2, W2)
+        xb, gb = b16(x), b16(gp)
+        hip.call("detr_hip_maxpool3x3s2_bwd_bf16", gb.data_ptr(), a16.data_ptr(), xb.data_ptr(), d16.data_ptr(), N, H, W, C, H2, W2)
+        assert torch.equal(d16, b16(d32))
+
+
 def test_gemm_bf16_compute_split_k(hip):
     torch.manual_seed(31)
     M, N, K = 256, 512, 20000
