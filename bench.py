@@ -158,8 +158,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loss_first = None
     for i in range(args.warmup):
         last = step(i)
+        if i == 0:
+            loss_first = last          # device scalar: read after the timed region
     barrier()
     # HIP events around every GEMM / conv launch (roofline leg) cost ~4 us of host time per event (~3.5 ms per step),
     # so they are recorded in the LAST `event_steps` timed steps only; the other timed steps run uninstrumented.
@@ -190,18 +193,21 @@ def main():
         model.engine.dropout_p = args.dropout
     # fp32 parity mode (exact-f32 MFMA everywhere: the mode the oracle parity tests run in), reported beside the headline
     value_fp32 = None
+    bf16_loss_dev = None
     if args.mode == "train" and args.precision == "bf16" and world == 1 and not args.no_fp32_leg:
         model = opt = None
         torch.cuda.empty_cache()
         model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision="fp32")
         opt = setup_optimizers(model, cfg)
-        step(0)
+        loss_first_fp32 = float(step(0))          # same weights, batch and dropout masks as the first bf16 step
         barrier()
         t1 = time.perf_counter()
         for i in range(3):
             step(1 + i)
         barrier()
         value_fp32 = args.batch * 3 / (time.perf_counter() - t1)
+        if loss_first is not None:
+            bf16_loss_dev = abs(float(loss_first) - loss_first_fp32) / abs(loss_first_fp32)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -265,6 +271,7 @@ def main():
             "loss": round(loss_val, 5),
             "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
             "images_per_sec_fp32_parity_mode": round(value_fp32, 3) if value_fp32 else None,
+            "bf16_vs_fp32_loss_rel_dev_first_step": (float(f"{bf16_loss_dev:.3e}") if bf16_loss_dev is not None else None),
             "whole_step_fraction_of_f32_mfma_peak": round(value / world * gflop * scale / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }

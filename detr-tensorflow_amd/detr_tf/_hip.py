@@ -243,7 +243,9 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
         PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0,
                      f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
                      f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}",
-                     4.0 * batch * (M * K + K * N + M * N * (1 + (residual is not None) + (mask is not None))))
+                     float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
+                                     + (residual.element_size() * M * N if residual is not None else 0)
+                                     + (mask.element_size() * M * N if mask is not None else 0)))     # algorithmic bytes at the stored widths
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -313,7 +315,11 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
         rows = N * (Hi * Wi if mode == 1 else Ho * Wo)
         PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0,
                      f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}",
-                     4.0 * (N * Hi * Wi * Ci + N * Ho * Wo * Co + 9 * Ci * Co + (rows * (Ci if mode == 1 else Co) if mask is not None else 0)))
+                     float(x.element_size() * (N * Hi * Wi * Ci if mode != 1 else N * Ho * Wo * Co)
+                           + (w.element_size() * 9 * Ci * Co if mode != 2 else w.element_size() * N * Ho * Wo * Co)
+                           + y.element_size() * (N * Ho * Wo * Co if mode == 0 else (N * Hi * Wi * Ci if mode == 1 else 9 * Ci * Co))
+                           + (mask.element_size() * rows * (Ci if mode == 1 else Co) if mask is not None else 0)
+                           + (residual.element_size() * rows * (Ci if mode == 1 else Co) if residual is not None else 0)))
 
 
 def stem_conv(mode, img, w, y, N, H, W, Ho, Wo, *, alpha=1.0, scale=None, bias=None, act=0, split=0, compute=None):
