@@ -38,6 +38,13 @@ def gemm_case(M, N, K, ak, bk, batch=1, res=False, splits=(1,), tiles=(0, 1, 2, 
         Bm = torch.randn((batch,) + tuple(Bm.shape), device=dev)
     C = torch.zeros((batch, M, N) if batch > 1 else (M, N), device=dev)
     R = torch.randn(M, N, device=dev) if res else None
+    if os.environ.get("TUNE_ACT16") == "1" and batch == 1:      # bf16 storage: activations (A, C, residual) and weights (B)
+        A, C = A.to(torch.bfloat16), C.to(torch.bfloat16)
+        R = R.to(torch.bfloat16) if R is not None else None
+        if len(splits) == 1 and splits[0] == 1:
+            Bm = Bm.to(torch.bfloat16)
+        else:
+            Bm, C = Bm.to(torch.bfloat16), C.float()          # wgrad form: both operands activations, fp32 output
     lda, ldb = (K if ak else M), (K if bk else N)
     out = []
     for sk in splits:

@@ -160,3 +160,27 @@ def test_position_embedding_host_matches_oracle():
         got = position_embedding_sine_host(H, W)
         ref = R.position_embedding_sine(1, H, W)[0].reshape(H * W, 256).numpy()
         assert np.abs(got - ref).max() < 1e-6
+
+
+def test_param_store_layout_and_split_heuristics():
+    """Host logic without a GPU: every tensor of the flat parameter buffer starts on a 16-byte boundary in BOTH the fp32
+    buffer and its bf16 shadow (offsets % 8 == 0), buckets are contiguous prefixes, and pick_split_k stays in range."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "detr-tensorflow_amd"))
+    from detr_tf import _hip
+    from detr_tf.params import ParamStore
+    P = ParamStore("cpu")
+    assert all(o % 8 == 0 for o, _ in P.offsets.values())
+    assert P.total % 8 == 0 and P.total >= 41_500_000
+    bounds = P.bucket_bounds()
+    assert bounds[0][0] == 0 and bounds[-1][1] == P.total and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    P.shadow16()
+    assert P.views16["transformer/encoder/layer_0/linear1/kernel"].shape == P.views["transformer/encoder/layer_0/linear1/kernel"].shape
+    for bf in (0, 1):
+        _hip.COMPUTE_BF16 = bf
+        try:
+            for (M, N, K) in [(256, 256, 8400), (64, 256, 534400), (147, 64, 2134400), (256, 256, 800), (2048, 256, 8400), (4, 256, 4800)]:
+                sk = _hip.pick_split_k(M, N, K)
+                assert 1 <= sk <= 1024 and sk <= max(1, K // 16)
+        finally:
+            _hip.COMPUTE_BF16 = 0
