@@ -163,13 +163,13 @@ def main():
         last = step(i)
         if i == 0:
             loss_first = last          # device scalar: read after the timed region
-    barrier()
     # HIP events around every GEMM / conv launch (roofline leg) cost ~4 us of host time per event (~3.5 ms per step),
     # so they are recorded in the LAST `event_steps` timed steps only; the other timed steps run uninstrumented.
     prof = None
     ev_steps = 0 if (args.no_kernel_events or rank != 0) else max(1, min(args.event_steps, args.steps))
     if ev_steps:
-        prof = _hip.KernelProfiler()
+        prof = _hip.KernelProfiler(prealloc=1200 * ev_steps)     # event objects exist before the timed region
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof is not None and i == args.steps - ev_steps:

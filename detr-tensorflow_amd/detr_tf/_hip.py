@@ -118,16 +118,26 @@ class KernelProfiler:
     """Optional HIP-event timing of the GEMM-class launches (bench.py roofline leg): events are
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
-    def __init__(self):
-        self.records = []          # (family, flops, start_event, end_event)
+    def __init__(self, prealloc=0):
+        self.records = []          # (family, flops, start_event, end_event, signature, bytes)
+        # event objects are created (and recorded once, which instantiates the HIP event) BEFORE the timed region:
+        # creating them per launch costs more host time than the record itself
+        self._pool = []
+        for _ in range(prealloc):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._pool.append(ev)
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def begin(self):
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = self._event()
         ev.record()
         return ev
 
     def end(self, family, flops, ev0, sig=None, nbytes=0.0):
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1 = self._event()
         ev1.record()
         self.records.append((family, flops, ev0, ev1, sig, nbytes))
 
