@@ -217,14 +217,17 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
-// Reduction of the split-K partial slabs: 256 threads = 64 float4 outputs x 4 split groups (the groups
-// stride the split index, 4 independent loads in flight each), combined through LDS.
+// Reduction of the split-K partial slabs: 256 threads = (256 / G) float4 outputs x G split groups (the groups stride the
+// split index), combined through LDS in a fixed order.  G = 4 for large outputs; G = 16 for small ones (a 256 x 256
+// weight gradient has only 16 K float4 outputs: with G = 4 the launch is 256 blocks and purely latency bound).
+template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
                                                             int rows, int cols, float *__restrict__ C, long long ldc,
                                                             float alpha, const float *__restrict__ scale, int vec,
                                                             const float *__restrict__ rs_ws, float *__restrict__ rs_out,
                                                             float rs_alpha) {
-    __shared__ float4 red[4][64];
+    constexpr int OUT = 256 / G;
+    __shared__ float4 red[G][OUT];
     if (rs_ws) {     // fused bias gradient: partial row sums [splits][rows] -> rs_out[rows] (fixed summation order)
         for (int m = blockIdx.x * 256 + threadIdx.x; m < rows; m += gridDim.x * 256) {
             float t = 0.0f;
@@ -232,11 +235,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
             rs_out[m] += rs_alpha * t;
         }
     }
-    const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int lo = threadIdx.x % OUT, grp = threadIdx.x / OUT;
     if (vec) {
         const int c4n = cols >> 2;
         const long long total = (long long)rows * c4n;
-        for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        for (long long base = (long long)blockIdx.x * OUT; base < total; base += (long long)gridDim.x * OUT) {
             const long long i = base + lo;
             const bool valid = i < total;
             int r = 0, c = 0;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
                 c = (int)(i - (long long)r * c4n) * 4;
                 const float *p = ws + (long long)r * cols + c;
 #pragma unroll 4
-                for (int k = grp; k < splits; k += 4) {
+                for (int k = grp; k < splits; k += G) {
                     const float4 v = *reinterpret_cast<const float4 *>(p + k * part_stride);
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
@@ -254,9 +257,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
             red[grp][lo] = s;
             __syncthreads();
             if (grp == 0 && valid) {
-                const float4 s1 = red[1][lo], s2 = red[2][lo], s3 = red[3][lo];
-                s.x = (s.x + s1.x) + (s2.x + s3.x); s.y = (s.y + s1.y) + (s2.y + s3.y);
-                s.z = (s.z + s1.z) + (s2.z + s3.z); s.w = (s.w + s1.w) + (s2.w + s3.w);
+#pragma unroll
+                for (int q = 1; q < G; ++q) {
+                    const float4 t = red[q][lo];
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (scale) sc = *reinterpret_cast<const float4 *>(scale + c);
                 float4 *dst = reinterpret_cast<float4 *>(C + (long long)r * ldc + c);
@@ -283,11 +288,16 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
     const int vec = (cols % 4 == 0) && (ldc % 4 == 0) && (part_stride % 4 == 0) && aligned16(ws) && aligned16(C) &&
                     (!scale || aligned16(scale));
     const long long total = (long long)rows * (vec ? cols / 4 : cols);
-    long long grid = vec ? (total + 63) / 64 : (total + 255) / 256;
+    const bool small = vec && total <= 65536 && splits >= 8;
+    long long grid = vec ? (total + (small ? 15 : 63)) / (small ? 16 : 64) : (total + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols, C,
-                       ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
+    if (small)
+        hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
+                           C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
+                           C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
 }
 
 template <int BM, int BN, int WGM, int WGN>
