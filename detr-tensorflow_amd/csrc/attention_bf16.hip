@@ -21,6 +21,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int AB_LD = 40;        // bf16 per LDS tile row (80 B): 16-byte aligned rows, conflict-free ds_read_b128 fragments
+// One loop iteration stages AB_SUB sub-tiles of 32 keys (queries in the dK/dV kernel).  Measured (B=8, L=1050): 1 -> 35 / 45 /
+// 81 us (fwd / dQ / dKdV averages), 2 -> 37 / 45 / 76, 4 -> 39 / 47 / 98: the kernels are VALU-issue bound (SQ counters:
+// 48 % of the wave cycles issue instructions at ~2 waves per SIMD, MFMA busy 16 %), not load-latency bound, so fatter
+// iterations only cost registers / occupancy.
+constexpr int AB_SUB = 1;
+constexpr int AB_ROWS = AT_KEYS * AB_SUB;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2 r;
@@ -38,7 +44,7 @@ __device__ __forceinline__ bf16x8 pack8(const float *v) {
 // 32 x 32 fp32 tile -> bf16 LDS image [row][AB_LD], by a workgroup of NW waves (256 float4 per tile)
 template <int NW>
 struct TileB {
-    static constexpr int LPT = 4 / NW;
+    static constexpr int LPT = 4 * AB_SUB / NW;
     float4 v[LPT];
     __device__ __forceinline__ void load(const float *base, long long ld, int row0, int nrows, int tid) {
 #pragma unroll
@@ -83,8 +89,8 @@ __device__ __forceinline__ bf16x8 frag_col(const unsigned short (*S)[AB_LD], int
 // ------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AT_KEYS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AT_KEYS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AB_ROWS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AB_ROWS][AB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     float m = -INFINITY, lsum = 0.0f;
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
-    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
     TileB<NW> rk, rv;
     rk.load(Kb, a.ld, 0, a.S, tid);
     rv.load(Vb, a.ld, 0, a.S, tid);
@@ -119,15 +125,20 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
+            rv.load(Vb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
         }
+#pragma unroll 1
+        for (int sub = 0; sub < AB_SUB; ++sub) {
+        const int kbase = it * AB_ROWS + sub * AT_KEYS;
+        if (kbase >= a.S) break;                    // sub-tiles past the last key (wave-uniform)
+        const unsigned short (*Kt)[AB_LD] = Ks[cur] + sub * AT_KEYS;
+        const unsigned short (*Vt)[AB_LD] = Vs[cur] + sub * AT_KEYS;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-        s = MFMA_BF16(frag_row(Ks[cur], 0, lane), qb[0], s);
-        s = MFMA_BF16(frag_row(Ks[cur], 1, lane), qb[1], s);
-        const int kbase = it * AT_KEYS;
+        s = MFMA_BF16(frag_row(Kt, 0, lane), qb[0], s);
+        s = MFMA_BF16(frag_row(Kt, 1, lane), qb[1], s);
         if (kbase + AT_KEYS > a.S) {                // ragged last tile only (wave-uniform)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -156,8 +167,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
-        o = MFMA_BF16(frag_col(Vs[cur], 0, lane), pack8(p), o);
-        o = MFMA_BF16(frag_col(Vs[cur], 1, lane), pack8(p + 8), o);
+        o = MFMA_BF16(frag_col(Vt, 0, lane), pack8(p), o);
+        o = MFMA_BF16(frag_col(Vt, 1, lane), pack8(p + 8), o);
+        }   // sub
         if (more) {
             rk.store(Ks[cur ^ 1], tid);
             rv.store(Vs[cur ^ 1], tid);
@@ -179,8 +191,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AT_KEYS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AT_KEYS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AB_ROWS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AB_ROWS][AB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
 
-    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
     TileB<NW> rk, rv;
     rk.load(Kb, a.ld, 0, a.S, tid);
     rv.load(Vb, a.ld, 0, a.S, tid);
@@ -226,18 +238,23 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
+            rv.load(Vb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
         }
+#pragma unroll 1
+        for (int sub = 0; sub < AB_SUB; ++sub) {
+        const int kbase = it * AB_ROWS + sub * AT_KEYS;
+        if (kbase >= a.S) break;
+        const unsigned short (*Kt)[AB_LD] = Ks[cur] + sub * AT_KEYS;
+        const unsigned short (*Vt)[AB_LD] = Vs[cur] + sub * AT_KEYS;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            s = MFMA_BF16(frag_row(Ks[cur], st, lane), qb[st], s);
-            dp = MFMA_BF16(frag_row(Vs[cur], st, lane), dob[st], dp);
+            s = MFMA_BF16(frag_row(Kt, st, lane), qb[st], s);
+            dp = MFMA_BF16(frag_row(Vt, st, lane), dob[st], dp);
         }
-        const int kbase = it * AT_KEYS;
         float ds[16];
         if (a.drop_scale != 0.0f) {
             const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
@@ -251,8 +268,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r)
                 if (kbase + krow(r, hi) >= a.S) ds[r] = 0.0f;
         }
-        dq = MFMA_BF16(frag_col(Ks[cur], 0, lane), pack8(ds), dq);
-        dq = MFMA_BF16(frag_col(Ks[cur], 1, lane), pack8(ds + 8), dq);
+        dq = MFMA_BF16(frag_col(Kt, 0, lane), pack8(ds), dq);
+        dq = MFMA_BF16(frag_col(Kt, 1, lane), pack8(ds + 8), dq);
+        }   // sub
         if (more) {
             rk.store(Ks[cur ^ 1], tid);
             rv.store(Vs[cur ^ 1], tid);
@@ -272,9 +290,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AT_KEYS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AT_KEYS][AB_LD];
-    __shared__ float Ls[2][AT_KEYS], Dl[2][AT_KEYS];
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AB_ROWS][AB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AB_ROWS][AB_LD];
+    __shared__ float Ls[2][AB_ROWS], Dl[2][AB_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -304,63 +322,81 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.0f; dv[r] = 0.0f; }
 
-    const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
+    const int ntiles = (a.T + AB_ROWS - 1) / AB_ROWS;
+    constexpr int NTH = 64 * NW;                      // threads; each stages AB_ROWS / NTH (l, delta) pairs per iteration
+    constexpr int LPP = (AB_ROWS + NTH - 1) / NTH;
     TileB<NW> rq, rd;
     rq.load(Qb, a.ld, 0, a.T, tid);
     rd.load(Db, a.ld, 0, a.T, tid);
-    float rl = 0.f, rdl = 0.f;
-    if (tid < AT_KEYS) {
-        rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;
-        rdl = (tid < a.T) ? dlt[tid] : 0.0f;
+    float rl[LPP], rdl[LPP];
+#pragma unroll
+    for (int j = 0; j < LPP; ++j) {
+        const int t = tid + NTH * j;
+        rl[j] = (t < AB_ROWS && t < a.T) ? lse[t] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
+        rdl[j] = (t < AB_ROWS && t < a.T) ? dlt[t] : 0.0f;
     }
     rq.store(Qs[0], tid, AT_LOG2E);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
     rd.store(Ds[0], tid);                // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
-    if (tid < AT_KEYS) { Ls[0][tid] = rl; Dl[0][tid] = rdl; }
+#pragma unroll
+    for (int j = 0; j < LPP; ++j)
+        if (tid + NTH * j < AB_ROWS) { Ls[0][tid + NTH * j] = rl[j]; Dl[0][tid + NTH * j] = rdl[j]; }
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            const int t0 = (it + 1) * AT_KEYS;
+            const int t0 = (it + 1) * AB_ROWS;
             rq.load(Qb, a.ld, t0, a.T, tid);
             rd.load(Db, a.ld, t0, a.T, tid);
-            if (tid < AT_KEYS) {
-                rl = (t0 + tid < a.T) ? lse[t0 + tid] * AT_LOG2E : INFINITY;
-                rdl = (t0 + tid < a.T) ? dlt[t0 + tid] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < LPP; ++j) {
+                const int t = tid + NTH * j;
+                rl[j] = (t < AB_ROWS && t0 + t < a.T) ? lse[t0 + t] * AT_LOG2E : INFINITY;
+                rdl[j] = (t < AB_ROWS && t0 + t < a.T) ? dlt[t0 + t] : 0.0f;
             }
         }
+#pragma unroll 1
+        for (int sub = 0; sub < AB_SUB; ++sub) {
+        const int qbase = it * AB_ROWS + sub * AT_KEYS;
+        if (qbase >= a.T) break;                    // sub-tiles past the last query (wave-uniform)
+        const unsigned short (*Qt)[AB_LD] = Qs[cur] + sub * AT_KEYS;
+        const unsigned short (*Dt)[AB_LD] = Ds[cur] + sub * AT_KEYS;
+        const float *Lt = Ls[cur] + sub * AT_KEYS, *Dlt = Dl[cur] + sub * AT_KEYS;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            s = MFMA_BF16(frag_row(Qs[cur], st, lane), kb[st], s);
-            dp = MFMA_BF16(frag_row(Ds[cur], st, lane), vb[st], dp);
+            s = MFMA_BF16(frag_row(Qt, st, lane), kb[st], s);
+            dp = MFMA_BF16(frag_row(Dt, st, lane), vb[st], dp);
         }
         float p[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = krow(r, hi);
-            p[r] = fast_exp2(s[r] - Ls[cur][qr]);
+            p[r] = fast_exp2(s[r] - Lt[qr]);
             float dpr = dp[r];
             if (a.drop_scale != 0.0f) {
-                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * Sp + sk, a.drop_thresh);
+                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + qbase + qr) * Sp + sk, a.drop_thresh);
                 dpr = keep ? dpr * a.drop_scale : 0.0f;
-                ds[r] = p[r] * (dpr - Dl[cur][qr]);
+                ds[r] = p[r] * (dpr - Dlt[qr]);
                 p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
             } else {
-                ds[r] = p[r] * (dpr - Dl[cur][qr]);
+                ds[r] = p[r] * (dpr - Dlt[qr]);
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            dv = MFMA_BF16(frag_col(Ds[cur], s2, lane), pack8(p + 8 * s2), dv);
-            dk = MFMA_BF16(frag_col(Qs[cur], s2, lane), pack8(ds + 8 * s2), dk);
+            dv = MFMA_BF16(frag_col(Dt, s2, lane), pack8(p + 8 * s2), dv);
+            dk = MFMA_BF16(frag_col(Qt, s2, lane), pack8(ds + 8 * s2), dk);
         }
+        }   // sub
         if (more) {
             rq.store(Qs[cur ^ 1], tid, AT_LOG2E);
             rd.store(Ds[cur ^ 1], tid);
-            if (tid < AT_KEYS) { Ls[cur ^ 1][tid] = rl; Dl[cur ^ 1][tid] = rdl; }
+#pragma unroll
+            for (int j = 0; j < LPP; ++j)
+                if (tid + NTH * j < AB_ROWS) { Ls[cur ^ 1][tid + NTH * j] = rl[j]; Dl[cur ^ 1][tid + NTH * j] = rdl[j]; }
         }
         __syncthreads();
         cur ^= 1;
