@@ -225,37 +225,49 @@ def main():
                 with open(args.dump_shapes, "w") as f:
                     json.dump({"steps": ev_steps, "rows": prof.by_shape(60)}, f, indent=1)
             if fam:
+                # dominant kernel = the template instantiation (as rocprofv3 names it, tile sizes pooled) with the largest
+                # total time; its average launch duration is directly comparable with profiles/r01_rocprofv3_kernel_stats*.txt
                 dom = max(fam, key=lambda k: fam[k]["ms"])
                 d = fam[dom]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 traffic, traffic_src = None, None
                 tpath = os.path.join(ROOT, "profiles", "r01_traffic_bf16.json" if args.precision == "bf16" else "r01_traffic.json")
-                if os.path.exists(tpath) and dom == "gemm_f32":
+                if os.path.exists(tpath):
                     with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
                         tj = json.load(f)
-                    traffic = round(tj["traffic_bytes_per_launch"])
-                    traffic_src = f"profiles/{os.path.basename(tpath)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    if dom in tj.get("per_symbol", {}):
+                        traffic = round(tj["per_symbol"][dom]["traffic_bytes_per_launch"])
+                        traffic_src = f"profiles/{os.path.basename(tpath)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                gemm_all = {"ms": sum(v["ms"] for k, v in fam.items() if k.startswith("gemm_")),
+                            "launches": sum(v["launches"] for k, v in fam.items() if k.startswith("gemm_")),
+                            "flops": sum(v["flops"] for k, v in fam.items() if k.startswith("gemm_")),
+                            "bytes": sum(v["bytes"] for k, v in fam.items() if k.startswith("gemm_"))}
+                gemm_all_out = {"ms_per_step": round(gemm_all["ms"] / ev_steps, 3), "launches_per_step": gemm_all["launches"] // ev_steps,
+                                "tflops": round(gemm_all["flops"] / (gemm_all["ms"] * 1e-3) / 1e12, 2),
+                                "gbs": round(gemm_all["bytes"] / (gemm_all["ms"] * 1e-3) / 1e9, 1)}
                 if args.precision == "bf16":
                     # fp32 storage + bf16 MFMA: the GEMM-class kernels are HBM bound -> algorithmic bytes / time
                     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                    roofline = {"bound": "hbm", "kernel": dom + " (bf16 compute)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                    roofline = {"bound": "hbm", "kernel": "detr::" + dom + " (64x64 / 128x128 tiles pooled)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                 "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                                 "tflops": round(ach, 2), "launches_per_step": d["launches"] // ev_steps,
                                 "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                 "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
+                                "all_gemm_kernels": gemm_all_out,
                                 "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
                                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                  "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                                                  "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}
                 else:
-                  roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                  roofline = {"bound": "mfma", "kernel": "detr::" + dom + " (tile sizes pooled)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                             "traffic_source": traffic_src,
                             "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                             "launches_per_step": d["launches"] // ev_steps,
                             "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                             "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
+                            "all_gemm_kernels": gemm_all_out,
                             "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                              "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}

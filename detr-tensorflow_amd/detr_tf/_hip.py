@@ -250,7 +250,10 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
     if ev0 is not None:
-        PROFILER.end("gemm_f32", 2.0 * M * N * K * batch, ev0,
+        tf = lambda v: "true" if v else "false"      # family = the kernel symbol as rocprofv3 names it (tile sizes pooled)
+        fam = (f"gemm_bf16c_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}, {tf(d.a_dtype)}, {tf(d.b_dtype)}>" if d.compute == 1
+               else f"gemm_f32_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}>")
+        PROFILER.end(fam, 2.0 * M * N * K * batch, ev0,
                      f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
                      f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}",
                      float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
@@ -349,7 +352,8 @@ def stem_conv(mode, img, w, y, N, H, W, Ho, Wo, *, alpha=1.0, scale=None, bias=N
     _check(load().detr_hip_stem_conv7x7_f32(byref(d), mode, _stream()), "detr_hip_stem_conv7x7_f32")
     if ev0 is not None:
         M = N * Ho * Wo
-        PROFILER.end("gemm_f32", 2.0 * M * 64 * 147, ev0, f"stem7x7 mode{mode} M{M}", 4.0 * (N * H * W * 3 + M * 64 + 147 * 64))
+        PROFILER.end("stem_conv7x7", 2.0 * M * 64 * 147, ev0, f"stem7x7 mode{mode} M{M}",
+                     float(4 * N * H * W * 3 + (y if mode == 0 else w).element_size() * M * 64 + 4 * 147 * 64))
 
 
 def call(name, *args):
