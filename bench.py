@@ -1,14 +1,18 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of one DETR-R50 training step (forward with training=True, Hungarian
 set loss with 5 aux levels, backward, per-tensor clipnorm, 3x Adam) at 800x1333, batch 8 per GPU,
-fp32, synthetic data, random-init weights (BASELINE.json metric / SURVEY.md 8d).
+synthetic data, random-init weights (BASELINE.json metric / SURVEY.md 8d).  Default --precision bf16
+(BASELINE.json config C3: bf16 MFMA, bf16 weight shadow and backbone activation storage, fp32 master
+weights / accumulation / loss); --precision fp32 is the exact-f32 parity mode, whose rate the bf16 line
+also reports (`images_per_sec_fp32_parity_mode`).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel family timed live with HIP
-events on the launch stream; `cpu_baseline` = the CPU oracle (restatement of the TF reference; TF
-is not installable here) timed on a bounded sample on this box's host cores.
+Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel (template instantiation of the GEMM
+tile engine) timed live with HIP events on the launch stream; `cpu_baseline` = the CPU oracle
+(restatement of the TF reference; TF is not installable here) timed on a bounded sample on this box's
+host cores.
 """
 import argparse
 import json

@@ -843,8 +843,6 @@ __global__ __launch_bounds__(256) void maxpool_fwd_bf16_kernel(const uint2 *__re
         const int n = (int)(t / (unsigned)Ho);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         uint32_t bi[4] = {0, 0, 0, 0};
-        uint2 braw[2] = {make_uint2(0, 0), make_uint2(0, 0)};
-        (void)braw;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
