@@ -60,8 +60,13 @@ __device__ __forceinline__ void rowsum_finish(const float4 (&rs)[NSLOT], float *
     __syncthreads();
 }
 
+constexpr int GEMM_MAX_GROUP = 4;
+struct GemmGroupArgs {       // up to 4 independent GEMMs of one kernel variant in ONE launch (blockIdx.y = member)
+    GemmArgs g[GEMM_MAX_GROUP];
+};
+
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int bid, const int nwg, const int zidx) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
     GemmSmem<BM, BN> &sm = *reinterpret_cast<GemmSmem<BM, BN> *>(smem_raw);
@@ -71,11 +76,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int id = xcd_remap(bid, nwg);
     const int tn = id % g.tiles_n, tm = id / g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int z = blockIdx.z;
+    const int z = zidx;
     const int split = z % g.split_k;
     const int zb = z / g.split_k;
     const int z0 = zb / g.batch_inner, z1 = zb % g.batch_inner;
@@ -138,18 +143,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
+    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC>(g, blockIdx.x, gridDim.x, blockIdx.z);
+}
+// grouped launch: the members share the kernel variant; workgroups past a member's own tile / split count retire
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_group_kernel(GemmGroupArgs G) {
+    const GemmArgs &g = G.g[blockIdx.y];
+    const int nwg = g.tiles_m * g.tiles_n;
+    if ((int)blockIdx.x >= nwg || (int)blockIdx.z >= g.split_k) return;
+    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC>(g, blockIdx.x, nwg, blockIdx.z);
+}
+
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int bid, const int nwg, const int zidx) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
     BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int id = xcd_remap(bid, nwg);
     const int tn = id % g.tiles_n, tm = id / g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.z;
+    const int z = zidx;
     const int split = z % g.split_k;
     const int zb = z / g.split_k;
     const int z0 = zb / g.batch_inner, z1 = zb % g.batch_inner;
@@ -217,19 +235,37 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
+    gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, A16, B16>(g, blockIdx.x, gridDim.x, blockIdx.z);
+}
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
+    const GemmArgs &g = G.g[blockIdx.y];
+    const int nwg = g.tiles_m * g.tiles_n;
+    if ((int)blockIdx.x >= nwg || (int)blockIdx.z >= g.split_k) return;
+    gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, A16, B16>(g, blockIdx.x, nwg, blockIdx.z);
+}
+
 // Reduction of the split-K partial slabs: 256 threads = (256 / G) float4 outputs x G split groups (the groups stride the
 // split index), combined through LDS in a fixed order.  G = 4 for large outputs; G = 16 for small ones (a 256 x 256
 // weight gradient has only 16 K float4 outputs: with G = 4 the launch is 256 blocks and purely latency bound).
+struct ReduceOne {
+    const float *ws; int splits; long long part_stride; int rows, cols; float *C; long long ldc;
+    float alpha; const float *scale; int vec; const float *rs_ws; float *rs_out; float rs_alpha; int nblocks;
+};
+struct ReduceGroupArgs { ReduceOne r[GEMM_MAX_GROUP]; };
+
 template <int G>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
-                                                            int rows, int cols, float *__restrict__ C, long long ldc,
-                                                            float alpha, const float *__restrict__ scale, int vec,
-                                                            const float *__restrict__ rs_ws, float *__restrict__ rs_out,
-                                                            float rs_alpha) {
+__device__ __forceinline__ void splitk_reduce_body(const float *__restrict__ ws, int splits, long long part_stride,
+                                                   int rows, int cols, float *__restrict__ C, long long ldc,
+                                                   float alpha, const float *__restrict__ scale, int vec,
+                                                   const float *__restrict__ rs_ws, float *__restrict__ rs_out,
+                                                   float rs_alpha, const int bid, const int nbid) {
     constexpr int OUT = 256 / G;
     __shared__ float4 red[G][OUT];
     if (rs_ws) {     // fused bias gradient: partial row sums [splits][rows] -> rs_out[rows] (fixed summation order)
-        for (int m = blockIdx.x * 256 + threadIdx.x; m < rows; m += gridDim.x * 256) {
+        for (int m = bid * 256 + threadIdx.x; m < rows; m += nbid * 256) {
             float t = 0.0f;
             for (int k = 0; k < splits; ++k) t += rs_ws[(long long)k * rows + m];
             rs_out[m] += rs_alpha * t;
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     if (vec) {
         const int c4n = cols >> 2;
         const long long total = (long long)rows * c4n;
-        for (long long base = (long long)blockIdx.x * OUT; base < total; base += (long long)gridDim.x * OUT) {
+        for (long long base = (long long)bid * OUT; base < total; base += (long long)nbid * OUT) {
             const long long i = base + lo;
             const bool valid = i < total;
             int r = 0, c = 0;
@@ -273,13 +309,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         }
     } else {
         const long long total = (long long)rows * cols;
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = bid * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)nbid * blockDim.x) {
             const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
             float s = 0.f;
             for (int k = 0; k < splits; ++k) s += ws[k * part_stride + i];
             C[(long long)r * ldc + c] += alpha * (scale ? scale[c] : 1.0f) * s;
         }
     }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int splits, long long part_stride,
+                                                            int rows, int cols, float *__restrict__ C, long long ldc,
+                                                            float alpha, const float *__restrict__ scale, int vec,
+                                                            const float *__restrict__ rs_ws, float *__restrict__ rs_out,
+                                                            float rs_alpha) {
+    splitk_reduce_body<G>(ws, splits, part_stride, rows, cols, C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha, blockIdx.x,
+                          gridDim.x);
+}
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroupArgs R) {
+    const ReduceOne &r = R.r[blockIdx.y];
+    if ((int)blockIdx.x >= r.nblocks) return;
+    splitk_reduce_body<G>(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, r.vec, r.rs_ws, r.rs_out,
+                          r.rs_alpha, blockIdx.x, r.nblocks);
+}
+
+static void reduce_plan(ReduceOne &r, bool &small) {
+    r.vec = (r.cols % 4 == 0) && (r.ldc % 4 == 0) && (r.part_stride % 4 == 0) && aligned16(r.ws) && aligned16(r.C) &&
+            (!r.scale || aligned16(r.scale));
+    const long long total = (long long)r.rows * (r.vec ? r.cols / 4 : r.cols);
+    small = r.vec && total <= 65536 && r.splits >= 8;
+    long long grid = r.vec ? (total + (small ? 15 : 63)) / (small ? 16 : 64) : (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    r.nblocks = (int)grid;
 }
 
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
@@ -340,7 +404,19 @@ static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak,
 
 using namespace detr;
 
-extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
+// Host side of one GEMM: validation + kernel arguments (gemm_prepare), then the launch(es) (gemm_launch).  The grouped entry
+// point prepares every member the same way and, when they share one kernel variant, issues ONE launch for all of them.
+struct GemmPlan {
+    GemmArgs g;
+    int batch, split;
+    bool ak, bk, bf16c, partial;
+    int tile;                 // 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64
+    long long part;
+    EpiArgs final_e;
+    const detr_gemm_desc *d;
+};
+
+static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     DETR_REQUIRE(d != nullptr, "gemm: null descriptor");
     DETR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
     DETR_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
@@ -373,7 +449,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
     if (d->rowsum_a) DETR_REQUIRE(!d->a_kcontig && batch == 1, "gemm: rowsum_a needs an MN-contiguous A operand and batch == 1");
     DETR_REQUIRE((long long)batch * split <= 65535, "gemm: batch*split_k=%lld exceeds grid.z", (long long)batch * split);
 
-    GemmArgs g;
+    GemmArgs &g = p.g;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.A = d->A; g.lda = d->lda;
     g.B = d->B; g.ldb = d->ldb;
@@ -409,7 +485,6 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
               (!d->mask || (aligned16(d->mask) && d->ldmask % 4 == 0));
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
-    hipStream_t s = (hipStream_t)stream;
     const long long part = (long long)d->M * d->N;
     const bool partial = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace) &&
                          d->workspace_bytes >= (long long)split * (part + (d->rowsum_a ? d->M : 0)) * 4;
@@ -433,40 +508,159 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
             g.rowsum_partial = 1;
         }
     }
-    // tile selection: wide tiles when the problem fills the chip, narrower ones for thin N / small M
-    const long long big_tiles = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
+    // tile selection
     const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
+    int tile = 0;
     if (bf16c) {
         // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
-        // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (2 waves/SIMD, 4x the operand
+        // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (3 waves/SIMD, 4x the operand
         // reuse) pays only for the long split-K weight gradients (K >= 16384, N >= 128) and for unsplit K >= 1024 GEMMs
         // that still fill the chip with 128x128 tiles (M33600 N256 K1024: 54 vs 60 us)
         const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
         const bool small = (split > 1) ? !(d->N >= 128 && d->K >= 16384) : !(d->K >= 1024 && t128 >= 512);
-        if (force == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
-        else if (force == 5) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
-        else if (force == 3 || (force == 0 && small)) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
+        if (force == 2) tile = 2;
+        else if (force == 5) tile = 4;
+        else if (force == 3 || (force == 0 && small)) tile = 0;
+        else tile = 1;
+    } else if (force == 1) tile = 1;
+    else if (force == 2) tile = 2;
+    else if (force == 3) tile = 0;
+    else if (force == 4) tile = 3;
+    else if (force == 5) tile = 4;
+    else if (force == 6) tile = 5;
+    else if (d->N <= 32) tile = 3;
+    else tile = 0;      // measured (profiles/tune_r1.txt): 64x64 (8 waves/SIMD) beats 128x64 by 2-10 % and 128x128 by 15-50 % in fp32
+    p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
+    p.part = part; p.final_e = final_e; p.d = d;
+    return 0;
+}
+
+static int gemm_launch(const GemmPlan &p, hipStream_t s) {
+    const GemmArgs &g = p.g;
+    const detr_gemm_desc *d = p.d;
+    const int batch = p.batch;
+    const bool ak = p.ak, bk = p.bk;
+    if (p.bf16c) {
+        if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
+        else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
+        else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
-    } else if (force == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
-    else if (force == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
-    else if (force == 3) launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
-    else if (force == 4) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
-    else if (force == 5) launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);
-    else if (force == 6) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
-    else if (d->N <= 32) {
-        launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
-    } else {
-        // measured on MI355X (scripts/tune_gemm.py, profiles/tune_r1.txt): the 64x64 tile (one 32x32 MFMA tile
-        // per wave, 8 waves/SIMD resident) beats 128x64 by 2-10 % and 128x128 by 15-50 % on every DETR shape --
-        // fp32 MFMA needs few accumulators, so occupancy (latency hiding) and tile-count balance win.
-        (void)big_tiles;
-        launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
-    }
+    } else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
+    else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
+    else if (p.tile == 3) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
+    else if (p.tile == 4) launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);
+    else if (p.tile == 5) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
+    else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     DETR_LAUNCH_CHECK("gemm");
-    if (partial) {
-        launch_splitk_reduce(d->workspace, split, part, d->M, d->N, d->C, d->ldc, final_e.alpha, final_e.scale, s,
-                             d->rowsum_a ? d->workspace + (long long)split * part : nullptr, d->rowsum_a, d->rowsum_alpha);
+    if (p.partial) {
+        launch_splitk_reduce(d->workspace, p.split, p.part, d->M, d->N, d->C, d->ldc, p.final_e.alpha, p.final_e.scale, s,
+                             d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr, d->rowsum_a, d->rowsum_alpha);
         DETR_LAUNCH_CHECK("gemm split-k reduce");
+    }
+    return 0;
+}
+
+extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
+    GemmPlan p;
+    if (gemm_prepare(d, p)) return -1;
+    return gemm_launch(p, (hipStream_t)stream);
+}
+
+// ---- grouped launch ------------------------------------------------------------------------------
+template <bool AK, bool BKC>
+static void launch_group_f32(const GemmGroupArgs &G, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC>), grid, dim3(GEMM_THREADS), 0, s, G);
+}
+template <bool AK, bool BKC, bool A16, bool B16>
+static void launch_group_bf16(const GemmGroupArgs &G, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_bf16c_group_kernel<64, 64, 2, 2, AK, BKC, A16, B16>), grid, dim3(GEMM_THREADS), 0, s, G);
+}
+
+extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, void *stream) {
+    DETR_REQUIRE(descs != nullptr && n >= 1 && n <= 64, "gemm group: 1..64 descriptors");
+    hipStream_t s = (hipStream_t)stream;
+    int done = 0;
+    while (done < n) {
+        const int m = (n - done) < GEMM_MAX_GROUP ? (n - done) : GEMM_MAX_GROUP;
+        GemmPlan p[GEMM_MAX_GROUP];
+        for (int i = 0; i < m; ++i)
+            if (gemm_prepare(descs + done + i, p[i])) return -1;
+        // one launch needs ONE kernel variant: 64x64 tiles, same layouts / storage types, no batch; members may differ in shape
+        bool same = m > 1 && env_tile("DETR_HIP_GEMM_GROUP") != 2;
+        for (int i = 0; i < m && same; ++i)
+            same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
+                   p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial);
+        if (!same) {
+            for (int i = 0; i < m; ++i)
+                if (gemm_launch(p[i], s)) return -1;
+            done += m;
+            continue;
+        }
+        GemmGroupArgs G;
+        unsigned gx = 1, gz = 1;
+        for (int i = 0; i < m; ++i) {
+            G.g[i] = p[i].g;
+            G.g[i].tiles_m = cdiv(p[i].g.M, 64);
+            G.g[i].tiles_n = cdiv(p[i].g.N, 64);
+            const unsigned t = (unsigned)(G.g[i].tiles_m * G.g[i].tiles_n);
+            gx = t > gx ? t : gx;
+            gz = (unsigned)p[i].split > gz ? (unsigned)p[i].split : gz;
+        }
+        for (int i = m; i < GEMM_MAX_GROUP; ++i) G.g[i] = G.g[0];
+        const dim3 grid(gx, (unsigned)m, gz);
+        const bool ak = p[0].ak, bk = p[0].bk, a16 = p[0].g.a16 != 0, b16 = p[0].g.b16 != 0;
+#define DETR_GROUP_BF16(A16_, B16_)                                          \
+    do {                                                                     \
+        if (ak && bk) launch_group_bf16<true, true, A16_, B16_>(G, grid, s);    \
+        else if (ak) launch_group_bf16<true, false, A16_, B16_>(G, grid, s);    \
+        else if (bk) launch_group_bf16<false, true, A16_, B16_>(G, grid, s);    \
+        else launch_group_bf16<false, false, A16_, B16_>(G, grid, s);           \
+    } while (0)
+        if (p[0].bf16c) {
+            if (a16 && b16) DETR_GROUP_BF16(true, true);
+            else if (a16) DETR_GROUP_BF16(true, false);
+            else if (b16) DETR_GROUP_BF16(false, true);
+            else DETR_GROUP_BF16(false, false);
+        } else if (ak && bk) launch_group_f32<true, true>(G, grid, s);
+        else if (ak) launch_group_f32<true, false>(G, grid, s);
+        else if (bk) launch_group_f32<false, true>(G, grid, s);
+        else launch_group_f32<false, false>(G, grid, s);
+#undef DETR_GROUP_BF16
+        DETR_LAUNCH_CHECK("gemm group");
+        // the members' split-K reductions, again as one launch
+        ReduceGroupArgs R;
+        int nr = 0;
+        unsigned rx = 1;
+        bool all_small = true, any_small = false;
+        for (int i = 0; i < m; ++i) {
+            if (!p[i].partial) continue;
+            const detr_gemm_desc *d = p[i].d;
+            ReduceOne &r = R.r[nr];
+            r.ws = d->workspace; r.splits = p[i].split; r.part_stride = p[i].part; r.rows = d->M; r.cols = d->N;
+            r.C = d->C; r.ldc = d->ldc; r.alpha = p[i].final_e.alpha; r.scale = p[i].final_e.scale;
+            r.rs_ws = d->rowsum_a ? d->workspace + (long long)p[i].split * p[i].part : nullptr;
+            r.rs_out = d->rowsum_a; r.rs_alpha = d->rowsum_alpha;
+            bool small;
+            reduce_plan(r, small);
+            all_small = all_small && small;
+            any_small = any_small || small;
+            rx = (unsigned)r.nblocks > rx ? (unsigned)r.nblocks : rx;
+            ++nr;
+        }
+        if (nr > 0 && (all_small || !any_small)) {
+            for (int i = nr; i < GEMM_MAX_GROUP; ++i) R.r[i] = R.r[0];
+            if (all_small) hipLaunchKernelGGL(splitk_reduce_group_kernel<16>, dim3(rx, (unsigned)nr), dim3(256), 0, s, R);
+            else hipLaunchKernelGGL(splitk_reduce_group_kernel<4>, dim3(rx, (unsigned)nr), dim3(256), 0, s, R);
+            DETR_LAUNCH_CHECK("gemm group split-k reduce");
+        } else if (nr > 0) {
+            for (int i = 0; i < nr; ++i) {
+                const ReduceOne &r = R.r[i];
+                launch_splitk_reduce(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, s, r.rs_ws, r.rs_out,
+                                     r.rs_alpha);
+            }
+            DETR_LAUNCH_CHECK("gemm group split-k reduce (sequential)");
+        }
+        done += m;
     }
     return 0;
 }

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "detr_hip_abi_version": [],
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
+    "detr_hip_gemm_group_f32": [POINTER(GemmDesc), c_int32, c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -220,11 +221,11 @@ def _f32(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------
-def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
-         residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0, compute=None,
-         rowsum_a=None, rowsum_alpha=1.0):
-    """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
+def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
+               residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
+               sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0,
+               compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None):
+    """Fills a detr_gemm_desc; returns (desc, profiler info).  ws_slice = (index, count): this call's share of WORKSPACE."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.A, d.lda, d.a_kcontig = A.data_ptr() + A.element_size() * a_off, lda, int(a_kcontig)
@@ -246,19 +247,49 @@ def gemm(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, sc
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
     d.rowsum_a, d.rowsum_alpha = ptr(rowsum_a), rowsum_alpha
     ws = workspace if workspace is not None else WORKSPACE
-    d.workspace, d.workspace_bytes = (ws.data_ptr(), ws.numel() * 4) if ws is not None else (None, 0)
+    if ws is None:
+        d.workspace, d.workspace_bytes = None, 0
+    elif ws_slice is None:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    else:                      # members of a grouped launch run concurrently: disjoint, 256-byte aligned shares
+        idx, cnt = ws_slice
+        share = (ws.numel() * 4 // cnt) & ~255
+        d.workspace, d.workspace_bytes = ws.data_ptr() + idx * share, share
+    tf = lambda v: "true" if v else "false"      # family = the kernel symbol as rocprofv3 names it (tile sizes pooled)
+    fam = (f"gemm_bf16c_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}, {tf(d.a_dtype)}, {tf(d.b_dtype)}>" if d.compute == 1
+           else f"gemm_f32_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}>")
+    sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
+           f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")
+    nbytes = float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
+                             + (residual.element_size() * M * N if residual is not None else 0)
+                             + (mask.element_size() * M * N if mask is not None else 0))     # algorithmic bytes at the stored widths
+    return d, (fam, 2.0 * M * N * K * batch, sig, nbytes)
+
+
+def gemm(*args, **kw):
+    """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
+    d, (fam, flops, sig, nbytes) = _gemm_desc(*args, **kw)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
     if ev0 is not None:
-        tf = lambda v: "true" if v else "false"      # family = the kernel symbol as rocprofv3 names it (tile sizes pooled)
-        fam = (f"gemm_bf16c_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}, {tf(d.a_dtype)}, {tf(d.b_dtype)}>" if d.compute == 1
-               else f"gemm_f32_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}>")
-        PROFILER.end(fam, 2.0 * M * N * K * batch, ev0,
-                     f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
-                     f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}",
-                     float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
-                                     + (residual.element_size() * M * N if residual is not None else 0)
-                                     + (mask.element_size() * M * N if mask is not None else 0)))     # algorithmic bytes at the stored widths
+        PROFILER.end(fam, flops, ev0, sig, nbytes)
+
+
+def gemm_group(calls):
+    """Several independent GEMMs (list of (args, kwargs) of gemm()) issued through detr_hip_gemm_group_f32: members that share
+    one kernel variant (e.g. the Q / K / V projections of an attention block, their three dgrads, their three weight
+    gradients) run as ONE launch (+ one grouped split-K reduction); anything else falls back to sequential launches."""
+    n = len(calls)
+    arr = (GemmDesc * n)()
+    infos = []
+    for i, (a, kw) in enumerate(calls):
+        d, info = _gemm_desc(*a, ws_slice=(i, n), **kw)
+        arr[i] = d
+        infos.append(info)
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    _check(load().detr_hip_gemm_group_f32(arr, n, _stream()), "detr_hip_gemm_group_f32")
+    if ev0 is not None:
+        PROFILER.end(infos[0][0], sum(i[1] for i in infos), ev0, f"group{n}: " + infos[0][2], sum(i[3] for i in infos))
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -275,36 +306,50 @@ def pick_split_k(M, N, K, max_split=1024):
     return int(max(1, min(want, max_split, cap)))
 
 
-def linear_fwd(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0):
-    """out = act((x @ W^T + b) * alpha + residual); W is (out, in) like custom_layers.Linear."""
+def linear_fwd_call(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0):
+    """(args, kwargs) of the gemm() that computes out = act((x @ W^T + b) * alpha + residual); W is (out, in) like
+    custom_layers.Linear.  The *_call forms exist so that independent Linear products can be issued with gemm_group()."""
     M, K = x2d.shape
     N = w_out_in.shape[0]
-    gemm(M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0),
-         alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act,
-         dropout_p=dropout_p, dropout_seed=dropout_seed)
+    return ((M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0)),
+            dict(alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act,
+                 dropout_p=dropout_p, dropout_seed=dropout_seed))
 
 
-def linear_dgrad(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):
+def linear_dgrad_call(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):
     """dx = (dy @ W) * alpha (+ residual) (masked by mask > 0)."""
     M, N = dy2d.shape
     K = w_out_in.shape[1]
-    gemm(M, K, N, dy2d, dy2d.stride(0), 1, w_out_in, w_out_in.stride(0), 0, dx2d, dx2d.stride(0), alpha=alpha,
-         residual=residual, ldr=(residual.stride(0) if residual is not None else 0),
-         mask=mask, ldmask=(mask.stride(0) if mask is not None else 0))
+    return ((M, K, N, dy2d, dy2d.stride(0), 1, w_out_in, w_out_in.stride(0), 0, dx2d, dx2d.stride(0)),
+            dict(alpha=alpha, residual=residual, ldr=(residual.stride(0) if residual is not None else 0),
+                 mask=mask, ldmask=(mask.stride(0) if mask is not None else 0)))
 
 
-def linear_wgrad(dy2d, x2d, dw_out_in, *, alpha=1.0, bias_grad=None):
+def linear_wgrad_call(dy2d, x2d, dw_out_in, *, alpha=1.0, bias_grad=None):
     """dW(out,in) += alpha * dy^T @ x (deterministic split-K through the workspace; dW holds zeros / the running sum);
     bias_grad (out,) += alpha * column sums of dy, fused into the same launch (row sums of the A operand)."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     sk = pick_split_k(N, K, M)
+    args = (N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0))
     if sk == 1:
-        gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
-             residual=dw_out_in, ldr=dw_out_in.stride(0), rowsum_a=bias_grad, rowsum_alpha=alpha)
-    else:
-        gemm(N, K, M, dy2d, dy2d.stride(0), 0, x2d, x2d.stride(0), 0, dw_out_in, dw_out_in.stride(0), alpha=alpha,
-             split_k=sk, rowsum_a=bias_grad, rowsum_alpha=alpha)
+        return args, dict(alpha=alpha, residual=dw_out_in, ldr=dw_out_in.stride(0), rowsum_a=bias_grad, rowsum_alpha=alpha)
+    return args, dict(alpha=alpha, split_k=sk, rowsum_a=bias_grad, rowsum_alpha=alpha)
+
+
+def linear_fwd(*a, **kw):
+    args, kwargs = linear_fwd_call(*a, **kw)
+    gemm(*args, **kwargs)
+
+
+def linear_dgrad(*a, **kw):
+    args, kwargs = linear_dgrad_call(*a, **kw)
+    gemm(*args, **kwargs)
+
+
+def linear_wgrad(*a, **kw):
+    args, kwargs = linear_wgrad_call(*a, **kw)
+    gemm(*args, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------

@@ -183,9 +183,10 @@ class DetrEngine:
         q_in [B*T,256], k_in/v_in [B*S,256]; out = attn(q,k,v) @ Wo^T + bo + residual."""
         W, bias = self._w(f"{pfx}/in_proj_kernel"), self.P.views[f"{pfx}/in_proj_bias"]
         Qb, Kb, Vb = self.buf(f"{tag}:Q", (B * T, D)), self.buf(f"{tag}:K", (B * S, D)), self.buf(f"{tag}:V", (B * S, D))
-        hip.linear_fwd(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5)          # :297,:307
-        hip.linear_fwd(k_in, W[D:2 * D], bias[D:2 * D], Kb)
-        hip.linear_fwd(v_in, W[2 * D:], bias[2 * D:], Vb)
+        # the three projections are independent: ONE grouped launch (each alone fills only 1-2 workgroups per CU)
+        hip.gemm_group([hip.linear_fwd_call(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5),          # :297,:307
+                        hip.linear_fwd_call(k_in, W[D:2 * D], bias[D:2 * D], Kb),
+                        hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], Vb)])
         BH = B * HEADS
         O = self.buf(f"{tag}:O", (B * T, D))
         if FUSED_ATTENTION:
@@ -243,12 +244,19 @@ class DetrEngine:
             hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
         # in projection: Q = (q_in Wq^T + bq) * alpha
         alpha = float(HD) ** -0.5
-        hip.linear_wgrad(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D])      # bias gradients fused (row sums of dy^T)
-        hip.linear_wgrad(dK, k_in, gW[D:2 * D], bias_grad=gb[D:2 * D])
-        hip.linear_wgrad(dV, v_in, gW[2 * D:], bias_grad=gb[2 * D:])
-        hip.linear_dgrad(dQ, W[0:D], dq_in, alpha=alpha)
-        hip.linear_dgrad(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None)
-        hip.linear_dgrad(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)
+        # three weight gradients (bias gradients fused: row sums of dy^T) and three data gradients, one grouped launch each
+        hip.gemm_group([hip.linear_wgrad_call(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D]),
+                        hip.linear_wgrad_call(dK, k_in, gW[D:2 * D], bias_grad=gb[D:2 * D]),
+                        hip.linear_wgrad_call(dV, v_in, gW[2 * D:], bias_grad=gb[2 * D:])])
+        dcalls = [hip.linear_dgrad_call(dQ, W[0:D], dq_in, alpha=alpha),
+                  hip.linear_dgrad_call(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None),
+                  hip.linear_dgrad_call(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)]
+        outs = {dq_in.data_ptr(), dk_in.data_ptr(), dv_in.data_ptr()}
+        if len(outs) == 3 and not dk_accum and not dv_accum:
+            hip.gemm_group(dcalls)              # three distinct outputs: one grouped launch
+        else:                                   # cross-attention accumulates dK and dV into the same memory gradient: in order
+            for a, kw in dcalls:
+                hip.gemm(*a, **kw)
 
     def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0):
         V = self.P.views

@@ -90,6 +90,12 @@ typedef struct {
     int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask */
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
+/* n independent GEMMs in one call.  Consecutive members (up to 4) that share one kernel variant -- 64x64 tiles, same operand
+ * layouts / storage types, no batch -- are issued as ONE launch (members on blockIdx.y) and their split-K reductions as one
+ * more; otherwise the members are launched one after the other.  Members must not alias each other's outputs or workspaces.
+ * Used for the Q / K / V projections of an attention block and their gradients (transformer.py:297-309), whose individual
+ * launches fill only 1-2 workgroups per CU. */
+int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3 convolution (explicit zero pad `pad`, then VALID, stride 1|2, dilation 1), NHWC / HWIO,

@@ -867,6 +867,54 @@ def test_conv3x3_bf16_activation_storage(hip, N, H, W, Ci, Co, stride):
         assert torch.equal(d16, b16(d32))
 
 
+@pytest.mark.parametrize("compute", [0, 1])
+def test_gemm_group_matches_individual_launches(hip, compute):
+    """detr_hip_gemm_group_f32: members of one kernel variant (Q / K / V projections, their dgrads, their split-K weight
+    gradients with fused bias gradients) in ONE launch -- bit-identical to the individual launches; a mixed list falls
+    back to sequential launches."""
+    torch.manual_seed(50 + compute)
+    hip.ensure_workspace(DEV)
+    M, D = 8400, 256
+    xs = [g(torch.randn(M, D)) for _ in range(3)]
+    W = g(torch.randn(3 * D, D) / 16)
+    Wop = W.to(torch.bfloat16) if compute else W
+    bias = g(torch.randn(3 * D))
+    def fwd_calls(outs):
+        return [hip.linear_fwd_call(xs[i], Wop[i * D:(i + 1) * D], bias[i * D:(i + 1) * D], outs[i], alpha=(0.5 if i == 0 else 1.0))
+                for i in range(3)]
+    ref, grp = [torch.zeros(M, D, device=DEV) for _ in range(3)], [torch.zeros(M, D, device=DEV) for _ in range(3)]
+    old = hip.COMPUTE_BF16
+    hip.COMPUTE_BF16 = compute
+    try:
+        for a, kw in fwd_calls(ref):
+            hip.gemm(*a, **kw)
+        hip.gemm_group(fwd_calls(grp))
+        for i in range(3):
+            assert torch.equal(ref[i], grp[i]), f"grouped forward member {i} differs"
+        assert float(ref[0].abs().max()) > 0
+        # weight gradients (split-K + fused bias gradient) of different shapes in one group
+        dys = [g(torch.randn(M, D)) for _ in range(3)]
+        def wg_calls(dws, dbs):
+            return [hip.linear_wgrad_call(dys[i], xs[i], dws[i], alpha=(0.5 if i == 0 else 1.0), bias_grad=dbs[i]) for i in range(3)]
+        dw_r, db_r = [torch.zeros(D, D, device=DEV) for _ in range(3)], [torch.zeros(D, device=DEV) for _ in range(3)]
+        dw_g, db_g = [torch.zeros(D, D, device=DEV) for _ in range(3)], [torch.zeros(D, device=DEV) for _ in range(3)]
+        for a, kw in wg_calls(dw_r, db_r):
+            hip.gemm(*a, **kw)
+        hip.gemm_group(wg_calls(dw_g, db_g))
+        for i in range(3):
+            assert torch.equal(dw_r[i], dw_g[i]) and torch.equal(db_r[i], db_g[i]), f"grouped wgrad member {i} differs"
+        assert float(dw_r[1].abs().max()) > 0 and float(db_r[1].abs().max()) > 0
+        # mixed variants (K-contiguous and MN-contiguous B) -> sequential fallback, same results
+        o1, o2 = torch.zeros(M, D, device=DEV), torch.zeros(M, D, device=DEV)
+        hip.gemm_group([hip.linear_fwd_call(xs[0], Wop[0:D], bias[0:D], o1), hip.linear_dgrad_call(xs[1], Wop[0:D], o2)])
+        r1, r2 = torch.zeros(M, D, device=DEV), torch.zeros(M, D, device=DEV)
+        hip.linear_fwd(xs[0], Wop[0:D], bias[0:D], r1)
+        hip.linear_dgrad(xs[1], Wop[0:D], r2)
+        assert torch.equal(o1, r1) and torch.equal(o2, r2)
+    finally:
+        hip.COMPUTE_BF16 = old
+
+
 def test_gemm_bf16_compute_split_k(hip):
     torch.manual_seed(31)
     M, N, K = 256, 512, 20000
