@@ -221,8 +221,7 @@ class DetrEngine:
             hip.call("detr_hip_dropout_f32", d_out.data_ptr(), d_drop.data_ptr(), d_out.numel(), c_float(dp),
                      (dbase + seed + 1) & 0xFFFFFFFF)
             d_out = d_drop
-        # out projection
-        hip.linear_wgrad(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"])
+        # out projection (its weight gradient joins the grouped launch of the in-projection weight gradients below)
         dO = self.buf("scratch:dO", (B * T, D))
         hip.linear_dgrad(d_out, self._w(f"{pfx}/out_proj_kernel"), dO)
         # attention core
@@ -245,7 +244,8 @@ class DetrEngine:
         # in projection: Q = (q_in Wq^T + bq) * alpha
         alpha = float(HD) ** -0.5
         # three weight gradients (bias gradients fused: row sums of dy^T) and three data gradients, one grouped launch each
-        hip.gemm_group([hip.linear_wgrad_call(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D]),
+        hip.gemm_group([hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"]),
+                        hip.linear_wgrad_call(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D]),
                         hip.linear_wgrad_call(dK, k_in, gW[D:2 * D], bias_grad=gb[D:2 * D]),
                         hip.linear_wgrad_call(dV, v_in, gW[2 * D:], bias_grad=gb[2 * D:])])
         dcalls = [hip.linear_dgrad_call(dQ, W[0:D], dq_in, alpha=alpha),
@@ -277,11 +277,11 @@ class DetrEngine:
             d_y = self.buf("scratch:d_ffn_drop", d_f.shape)
             hip.call("detr_hip_dropout_f32", d_f.data_ptr(), d_y.data_ptr(), d_f.numel(), c_float(dp),
                      (dbase + seed + 1) & 0xFFFFFFFF)
-        hip.linear_wgrad(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"])
         dh = self.buf("scratch:dh", h.shape)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
         hip.linear_dgrad(d_y, self._w(f"{pfx}/linear2/kernel"), dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
-        hip.linear_wgrad(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])
+        hip.gemm_group([hip.linear_wgrad_call(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"]),
+                        hip.linear_wgrad_call(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])])
         hip.linear_dgrad(dh, self._w(f"{pfx}/linear1/kernel"), dx, residual=d_f)
 
     # ---- forward ----------------------------------------------------------------------------------
