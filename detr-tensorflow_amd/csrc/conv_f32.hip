@@ -405,7 +405,7 @@ struct LoaderConvAb {
 };
 
 template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool W16, bool X16>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void conv3x3_bf16c_kernel(ConvArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN == 64 * 64 ? DETR_GEMM64_MINW : 1)) void conv3x3_bf16c_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
     BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);

@@ -236,11 +236,11 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int bid
 }
 
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16c_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN == 64 * 64 ? DETR_GEMM64_MINW : 1)) void gemm_bf16c_kernel(GemmArgs g) {
     gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, A16, B16>(g, blockIdx.x, gridDim.x, blockIdx.z);
 }
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MINW : 1) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
     const GemmArgs &g = G.g[blockIdx.y];
     const int nwg = g.tiles_m * g.tiles_n;
     if ((int)blockIdx.x >= nwg || (int)blockIdx.z >= g.split_k) return;

@@ -454,7 +454,24 @@ __global__ void scale_cols_bf16_kernel(const float4 *__restrict__ w, const float
         out[i] = make_uint2(pk2_bf16(v.x * sc.x, v.y * sc.y), pk2_bf16(v.z * sc.z, v.w * sc.w));
     }
 }
+
+__global__ void scale_cols_bf16_group_kernel(const detr_scale_entry *__restrict__ tab) {
+    const detr_scale_entry e = tab[blockIdx.y];
+    const float4 *w = reinterpret_cast<const float4 *>(e.w), *scale = reinterpret_cast<const float4 *>(e.scale);
+    uint2 *out = reinterpret_cast<uint2 *>(e.out);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < e.n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = w[i], sc = scale[i % e.c4];
+        out[i] = make_uint2(pk2_bf16(v.x * sc.x, v.y * sc.y), pk2_bf16(v.z * sc.z, v.w * sc.w));
+    }
+}
 }  // namespace detr
+
+extern "C" int detr_hip_scale_cols_bf16_group(const detr_scale_entry *table, int32_t n, void *stream) {
+    DETR_REQUIRE(table && n > 0 && n <= 65535, "scale_cols_bf16_group: bad args");
+    hipLaunchKernelGGL(scale_cols_bf16_group_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table);
+    DETR_LAUNCH_CHECK("scale_cols_bf16_group");
+    return 0;
+}
 
 extern "C" int detr_hip_cvt_bf16(const float *x, uint16_t *out, int64_t n, void *stream) {
     DETR_REQUIRE(x && out && n > 0 && n % 4 == 0 && aligned16(x) && ((uintptr_t)out % 8 == 0), "cvt_bf16: bad args");

@@ -119,7 +119,12 @@ __device__ __forceinline__ double dpp_min_step(double x) {
     const double inf = (double)INFINITY;
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(inf), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(inf), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
-    return fmin(x, __hiloint2double(hi, lo));
+    // raw v_min_f64: the operands are never NaN here (the cost matrix is screened, +inf - finite stays +inf), so
+    // the two v_max_f64 canonicalisations fmin() would add to every step of the dependent chain are dead weight
+    const double y = __hiloint2double(hi, lo);
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 __device__ __forceinline__ double wave_min_f64_dpp(double x) {
     x = dpp_min_step<0x111, 0xf>(x);   // row_shr:1
@@ -142,7 +147,9 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
     const int p = blockIdx.x, b = p % B, lane = threadIdx.x;
     const int nmax = (R + 1) & ~1;
     const int n = header_n(t_bbox, b, R);
-    const int Qs = Q | 1;
+    const int cpl = (Q + 63) >> 6;
+    const int Qs = cpl * 64 + 1;        // row stride of the transposed cost (odd: the column-wise staging writes spread
+                                        // over the banks); slot s of lane l sits at 64*s + l
     double *u = reinterpret_cast<double *>(smem);
     int *col4row = reinterpret_cast<int *>(u + nmax);
     float *cT = reinterpret_cast<float *>(col4row + nmax);
@@ -163,6 +170,8 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
         cT[j * Qs + q] = c;
         bad |= !(c == c) || (c == -INFINITY);
     }
+    if (Qs > Q)
+        for (int idx = lane; idx < (Qs - Q) * n; idx += 64) cT[(idx / (Qs - Q)) * Qs + Q + idx % (Qs - Q)] = 0.0f;
     for (int i = lane; i < n; i += 64) {
         u[i] = 0.0;
         col4row[i] = -1;
@@ -172,7 +181,6 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
         if (lane == 0) status[p] = 1;   // SciPy raises "matrix contains invalid numeric entries"
         return;
     }
-    const int cpl = (Q + 63) >> 6;
     double v[MAXCPL], spc[MAXCPL];
     int path[MAXCPL], row4col[MAXCPL];
 #pragma unroll
@@ -228,26 +236,28 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
 #pragma unroll
         for (int s = 0; s < MAXCPL; ++s) spc[s] = INFINITY;
         while (true) {
+            // One Dijkstra step, straight-line: both LDS reads (u[i] and the cost row, one float per slot) are issued
+            // together, the per-slot relaxations are selects, and the only branches are the two loop exits.
             const double ui = u[i];
-            const float *crow = cT + i * Qs;
+            const float *crow = cT + i * Qs + lane;
+            float cf[MAXCPL];
+#pragma unroll
+            for (int s = 0; s < MAXCPL; ++s) cf[s] = crow[64 * (s < cpl ? s : cpl - 1)];
             double best = INFINITY;
-            int bestj = INT_MAX, bestfree = 0;
+            int bestj = INT_MAX, bestr4 = 0;
 #pragma unroll
             for (int s = 0; s < MAXCPL; ++s) {
                 const int j = lane + 64 * s;
-                if (s < cpl && j < Q && !((scmask >> s) & 1u)) {
-                    const double r = minVal + (double)crow[j] - ui - v[s];
-                    if (r < spc[s]) {
-                        spc[s] = r;
-                        path[s] = i;
-                    }
-                    const int fr = (row4col[s] == -1) ? 1 : 0;
-                    if (spc[s] < best || (spc[s] == best && (fr > bestfree || (fr == bestfree && j < bestj)))) {
-                        best = spc[s];
-                        bestj = j;
-                        bestfree = fr;
-                    }
-                }
+                const bool valid = (j < Q) & !((scmask >> s) & 1u);
+                const double r = minVal + (double)cf[s] - ui - v[s];
+                const bool upd = valid & (r < spc[s]);
+                spc[s] = upd ? r : spc[s];
+                path[s] = upd ? i : path[s];
+                const bool fr = row4col[s] == -1, bfr = bestr4 == -1;
+                const bool take = valid & ((spc[s] < best) | ((spc[s] == best) & ((fr & !bfr) | ((fr == bfr) & (j < bestj)))));
+                best = take ? spc[s] : best;
+                bestj = take ? j : bestj;
+                bestr4 = take ? row4col[s] : bestr4;
             }
             // wave argmin: DPP min of the value, then a ballot picks the owner lane (free columns
             // first, as SciPy's tie rule prefers a column that ends the search)
@@ -258,20 +268,12 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
                 break;
             }
             const bool cand = (best == gmin);
-            const unsigned long long mfree = __ballot(cand && bestfree);
+            const unsigned long long mfree = __ballot(cand & (bestr4 == -1));
             const unsigned long long mall = __ballot(cand);
             const int ownl = __ffsll((long long)(mfree ? mfree : mall)) - 1;
             const int jstar = __builtin_amdgcn_readlane(bestj, ownl);
-            const int owns = jstar >> 6;
-            int r4 = -1;
-#pragma unroll
-            for (int s = 0; s < MAXCPL; ++s) {
-                if (s == owns) {
-                    if (lane == ownl) scmask |= (1u << s);
-                    r4 = row4col[s];
-                }
-            }
-            r4 = __builtin_amdgcn_readlane(r4, ownl);
+            const int r4 = __builtin_amdgcn_readlane(bestr4, ownl);
+            if (lane == ownl) scmask |= 1u << (jstar >> 6);
             if (r4 == -1) {
                 sink = jstar;
                 break;
@@ -534,7 +536,7 @@ extern "C" int detr_hip_assign_f32(const float *cost, int32_t P, int32_t Q, int3
     DETR_REQUIRE(P > 0 && Q > 0 && Q <= SL_MAXQ && R > 1 && R <= SL_MAXR && ldc >= R - 1 && B > 0 && P % B == 0,
                  "assign: bad shape P=%d Q=%d ldc=%d B=%d R=%d", P, Q, ldc, B, R);
     const int nmax = (R + 1) & ~1;
-    const size_t smem = (size_t)nmax * 8 + (size_t)nmax * 4 + (size_t)(R - 1) * (Q | 1) * 4;
+    const size_t smem = (size_t)nmax * 8 + (size_t)nmax * 4 + (size_t)(R - 1) * (size_t)((Q + 63) / 64 * 64 + 1) * 4;
     hipStream_t s = (hipStream_t)stream;
     const int cpl = (Q + 63) / 64;
 #define DETR_ASSIGN_LAUNCH(MC)                                                                                       \

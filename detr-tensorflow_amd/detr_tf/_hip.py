@@ -75,6 +75,7 @@ _SIGNATURES = {
                                        c_void_p],
     "detr_hip_cvt_bf16": [f32p, c_void_p, c_int64, c_void_p],
     "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
+    "detr_hip_scale_cols_bf16_group": [c_void_p, c_int32, c_void_p],
     "detr_hip_stem_conv7x7_f32": [POINTER(StemDesc), c_int32, c_void_p],
     "detr_hip_stem_im2col_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_f32": [f32p, f32p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],

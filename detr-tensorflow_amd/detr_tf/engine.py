@@ -71,13 +71,31 @@ class DetrEngine:
         self._pos_cache = {}
         self._shape = None
         self.bn_scale, self.bn_shift = {}, {}
+        self._weights_version, self._built = 0, {}
         self.fold_bn()
-        self.weights_dirty = True        # scaled conv kernels must be refreshed after every optimiser step
         self.compute = 0                 # 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA, fp32 storage (config C3)
         self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
         self.dropout_seed = 0x5EED       # base seed; advanced by the step counter
         self._step_no = 0
         self._drop = (0.0, 0)
+
+    # Derived weight copies (BN-folded kernels, the bf16 shadow) are stamped with the weights version they were built
+    # from; `engine.weights_dirty = True` (optimizers.py after every apply, load_params, fold_bn) bumps the version, so
+    # a copy is rebuilt exactly when it is next needed -- also when fp32 and bf16 passes are interleaved.
+    @property
+    def weights_dirty(self):
+        return True
+
+    @weights_dirty.setter
+    def weights_dirty(self, value):
+        if value:
+            self._weights_version += 1
+
+    def _stale(self, key):
+        if self._built.get(key) == self._weights_version:
+            return False
+        self._built[key] = self._weights_version
+        return True
 
     # ---- buffers ------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
@@ -99,6 +117,7 @@ class DetrEngine:
                      sc.data_ptr(), sh.data_ptr(), c, c_float(BN_EPS))
             self.bn_scale[p], self.bn_shift[p] = sc, sh
         self.weights_dirty = True
+        self._fold_table = None
 
     def load_params(self, params):
         missing = self.P.load_dict(params)
@@ -116,19 +135,34 @@ class DetrEngine:
         """bf16 compute mode: one flat fp32 -> bf16 conversion of all parameters per optimiser step (~60 us)."""
         flat16 = self.P.shadow16()
         hip.call("detr_hip_cvt_bf16", self.P.flat.data_ptr(), flat16.data_ptr(), self.P.flat.numel())
+        self._refold_group()
+
+    def _refold_group(self):
+        """Frozen-BN fold of every bf16 conv kernel (all but the stem) in one launch: a device table of
+        (kernel, bn scale, bf16 out, n/4, cols/4) entries, built once -- the tensors it points at never move."""
+        if getattr(self, "_fold_table", None) is None:
+            rows = []
+            for bn_name in self.P.bn:
+                if bn_name == "backbone/bn1":
+                    continue
+                head, leaf = bn_name.rsplit("/", 1)
+                conv_name = f"{head}/downsample_0/kernel" if leaf == "downsample_1" else f"{head}/conv{leaf[2:]}/kernel"
+                w = self.P.views[conv_name]
+                co = w.shape[-1]
+                ws16 = self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)
+                rows.append([w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws16.data_ptr(), w.numel() // 4, co // 4])
+            self._fold_table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self._fold_keep = [self.bn_scale, self._bufs]
+        hip.call("detr_hip_scale_cols_bf16_group", self._fold_table.data_ptr(), self._fold_table.shape[0])
 
     def _scaled_kernel(self, conv_name, bn_name):
         """kernel * bn scale per output channel (the frozen-BN fold into the conv); bf16 compute mode: the bf16 copy."""
         w = self.P.views[conv_name]
         co = w.shape[-1]
         if self.compute == 1 and conv_name != "backbone/conv1/kernel":      # (the stem kernel takes the fp32 copy)
-            ws16 = self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)
-            if self.weights_dirty:
-                hip.call("detr_hip_scale_cols_bf16", w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws16.data_ptr(),
-                         w.numel() // co, co)
-            return ws16
+            return self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)     # filled by _refold_group()
         ws = self.buf(f"ws:{conv_name}", w.shape)
-        if self.weights_dirty:
+        if self._stale(f"ws:{conv_name}"):
             hip.call("detr_hip_scale_cols_f32", w.data_ptr(), self.bn_scale[bn_name].data_ptr(), ws.data_ptr(),
                      w.numel() // co, co)
         return ws
@@ -288,7 +322,7 @@ class DetrEngine:
     def forward(self, images, training=False):
         """See _forward_impl.  GEMM / conv compute mode: self.compute (0 = exact fp32, 1 = bf16 MFMA)."""
         hip.COMPUTE_BF16 = self.compute
-        if self.compute == 1 and (self.weights_dirty or self.P.views16 is None):
+        if self.compute == 1 and (self._stale("shadow16") or self.P.views16 is None):
             self._refresh_shadow()
         try:
             return self._forward_impl(images, training)

@@ -140,6 +140,17 @@ int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream)
  * out[r][c] = bf16(w[r][c] * scale[c]) (custom_layers.py:21-24 folded into the conv kernel). */
 int detr_hip_cvt_bf16(const float *x, uint16_t *out, int64_t n, void *stream);
 int detr_hip_scale_cols_bf16(const float *w, const float *scale, uint16_t *out, int64_t rows, int32_t cols, void *stream);
+/* The same fold for a whole list of kernels in ONE launch (the backbone has 52 folded convs and refolds them after every
+ * optimiser step).  `table` is DEVICE memory holding n entries of this layout; c4 = cols/4, n4 = rows*cols/4. */
+typedef struct detr_scale_entry {
+    const float *w;
+    const float *scale;
+    uint16_t *out;
+    int64_t n4;
+    int32_t c4;
+    int32_t reserved;
+} detr_scale_entry;
+int detr_hip_scale_cols_bf16_group(const detr_scale_entry *table, int32_t n, void *stream);
 int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W,
                              int32_t Ho, int32_t Wo, int32_t ldcol, void *stream);
 

@@ -957,3 +957,22 @@ def test_conv3x3_bf16_compute_all_modes(hip, N, H, W, Ci, Co, stride):
         close(dwd, w.grad * scale, rtol=5e-5, what="bf16c conv3x3 wgrad")
     finally:
         hip.WORKSPACE = old
+
+
+def test_scale_cols_bf16_group_matches_single_launches(hip):
+    """The one-launch frozen-BN fold over a device table == the per-kernel fold, bit for bit (custom_layers.py:21-24)."""
+    torch.manual_seed(77)
+    shapes = [(64, 64), (9 * 64, 64), (256, 1024), (9 * 512, 512), (1, 4), (37, 12)]
+    ws = [torch.randn(r, c, device=DEV) for r, c in shapes]
+    scs = [torch.rand(c, device=DEV) + 0.5 for _, c in shapes]
+    one = [torch.zeros(r, c, device=DEV, dtype=torch.bfloat16) for r, c in shapes]
+    grp = [torch.zeros(r, c, device=DEV, dtype=torch.bfloat16) for r, c in shapes]
+    for w, sc, o in zip(ws, scs, one):
+        hip.call("detr_hip_scale_cols_bf16", w.data_ptr(), sc.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1])
+    table = torch.tensor([[w.data_ptr(), sc.data_ptr(), o.data_ptr(), w.numel() // 4, w.shape[1] // 4]
+                          for w, sc, o in zip(ws, scs, grp)], dtype=torch.int64).to(DEV)
+    hip.call("detr_hip_scale_cols_bf16_group", table.data_ptr(), len(shapes))
+    torch.cuda.synchronize()
+    for w, sc, a, b in zip(ws, scs, one, grp):
+        assert torch.equal(a, b)
+        assert torch.equal(a, (w * sc).to(torch.bfloat16))

@@ -226,6 +226,41 @@ def test_bf16_compute_mode_deviation_from_fp32_oracle(hip):
     assert np.median([v for v, _ in l2]) < 0.1 and l2[len(l2) // 10][0] < 0.3, l2[:8]
 
 
+def test_interleaved_fp32_and_bf16_passes_rebuild_their_weight_copies(hip):
+    """The BN-folded kernels (fp32 and bf16) and the bf16 weight shadow are stamped with the weights version: after an
+    optimiser step each pass -- in either precision, in any order -- must see the NEW weights."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    cfg.backbone_lr.assign(1e-3)
+    params = R.make_params(8, num_enc=1, num_dec=1)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=1, dropout=0.0, precision="bf16")
+    model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    eng = model.engine
+    images = np.random.default_rng(5).normal(size=(1, 64, 96, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(1, seed=41, force_full=False)
+
+    def fwd(compute):
+        eng.compute = compute
+        return model(images, training=False)["pred_logits"].clone()
+
+    before16, before32 = fwd(1), fwd(0)
+    eng.compute = 1
+    _, _, _, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    for name in steps:
+        training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], 0, cfg)
+    a32 = fwd(0)                      # fp32 pass first: must not leave the bf16 copies looking fresh
+    a16 = fwd(1)
+    eng.weights_dirty = True          # force every derived copy to be rebuilt
+    b16, b32 = fwd(1), fwd(0)
+    torch.cuda.synchronize()
+    assert torch.equal(a16, b16) and torch.equal(a32, b32)
+    assert not torch.equal(a16, before16) and not torch.equal(a32, before32)
+
+
 def test_train_steps_vs_oracle_adam(hip):
     """Two full train steps (forward, set loss, backward, per-tensor clipnorm, 3x Adam) on a reduced
     depth model vs the oracle optimiser; also the accumulate/apply cadence with target_batch."""
