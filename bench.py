@@ -252,7 +252,8 @@ def main():
                 if args.precision == "bf16":
                     # fp32 storage + bf16 MFMA: the GEMM-class kernels are HBM bound -> algorithmic bytes / time
                     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                    roofline = {"bound": "hbm", "kernel": "detr::" + dom + " (64x64 / 128x128 tiles pooled)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                    roofline = {"bound": "hbm", "kernel": "detr::" + dom + (" (all K / layout / epilogue instantiations pooled)" if dom.startswith("gemm_stream")
+                                                                  else " (64x64 / 128x128 tiles pooled)"), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                 "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                                 "tflops": round(ach, 2), "launches_per_step": d["launches"] // ev_steps,

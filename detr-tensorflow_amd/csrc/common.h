@@ -34,7 +34,6 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
                           float alpha, const float *scale, hipStream_t stream, const float *rs_ws = nullptr,
                           float *rs_out = nullptr, float rs_alpha = 1.0f);
 
-// tuning hook: integer environment variable (0 when unset)
 // Minimum waves per SIMD requested for the 64x64-tile bf16 GEMM / conv kernels (second __launch_bounds__ argument):
 // tuning knob (make DEFS=-DDETR_GEMM64_MINW=6).  Measured: 6 (<= 64 VGPRs, 8 workgroups / CU instead of 5) buys the
 // HBM-bound short-K GEMMs 1-2 % and costs the long-K ones 10-25 % (tighter scheduling) -- left at 1.
@@ -42,6 +41,7 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 #define DETR_GEMM64_MINW 1
 #endif
 
+// tuning hook: integer environment variable (0 when unset)
 static inline int env_tile(const char *name) {
     const char *v = getenv(name);
     return v ? atoi(v) : 0;

@@ -3,6 +3,7 @@
 // gradients (see include/detr_hip.h for the reference lines).
 #include "gemm_core.h"
 #include "gemm_bf16_core.h"
+#include "gemm_stream.h"
 
 namespace detr {
 
@@ -535,11 +536,49 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     return 0;
 }
 
+// The streaming kernel (gemm_stream.h) takes the short-K, tall GEMMs whose operands, output, residual and mask are all
+// bf16 in memory: the layer1 / layer2 1x1 convolutions and their input gradients.  DETR_HIP_GEMM_STREAM=2 disables it.
+static bool gemm_stream_eligible(const GemmPlan &p) {
+    const detr_gemm_desc *d = p.d;
+    const GemmArgs &g = p.g;
+    if (!(p.bf16c && g.a16 && g.b16 && g.e.c16 && p.ak && p.batch == 1 && p.split == 1 && !g.rowsum)) return false;
+    if (!((d->K == 64 || d->K == 128 || d->K == 256) && d->N % 64 == 0 && d->M >= 16384)) return false;
+    if (d->scale || d->alpha != 1.0f || d->dropout_p > 0.0f || !(d->act == 0 || d->act == 1)) return false;
+    if (d->residual && !(g.e.r16 && d->ldr % 8 == 0 && aligned16(d->residual))) return false;
+    if (d->mask && !(g.e.m16 && d->ldmask % 8 == 0 && aligned16(d->mask))) return false;
+    if (!(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C))) return false;
+    const long long span = (long long)(d->M - 1) * (d->ldr > d->ldmask ? d->ldr : d->ldmask) + d->N;
+    if (span * 2 > BUF_MAX_BYTES) return false;
+    return env_tile("DETR_HIP_GEMM_STREAM") != 2;
+}
+
+static void gemm_stream_launch(const GemmPlan &p, hipStream_t s) {
+    const detr_gemm_desc *d = p.d;
+    StreamArgs a;
+    a.M = d->M; a.N = d->N;
+    a.A = reinterpret_cast<const unsigned short *>(d->A); a.lda = d->lda;
+    a.B = reinterpret_cast<const unsigned short *>(d->B); a.ldb = d->ldb;
+    a.C = reinterpret_cast<unsigned short *>(d->C); a.ldc = d->ldc;
+    a.res = reinterpret_cast<const unsigned short *>(d->residual); a.ldr = d->ldr;
+    a.mask = reinterpret_cast<const unsigned short *>(d->mask); a.ldm = d->ldmask;
+    a.bias = d->bias;
+    a.act = d->act;
+    a.n_tiles = a.row_tiles = a.q = 0;
+    if (d->K == 64) launch_gemm_stream<64>(a, p.bk, s);
+    else if (d->K == 128) launch_gemm_stream<128>(a, p.bk, s);
+    else launch_gemm_stream<256>(a, p.bk, s);
+}
+
 static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const GemmArgs &g = p.g;
     const detr_gemm_desc *d = p.d;
     const int batch = p.batch;
     const bool ak = p.ak, bk = p.bk;
+    if (gemm_stream_eligible(p)) {
+        gemm_stream_launch(p, s);
+        DETR_LAUNCH_CHECK("gemm (stream)");
+        return 0;
+    }
     if (p.bf16c) {
         if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
@@ -589,7 +628,8 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         bool same = m > 1 && env_tile("DETR_HIP_GEMM_GROUP") != 2;
         for (int i = 0; i < m && same; ++i)
             same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
-                   p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial);
+                   p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&
+                   !gemm_stream_eligible(p[i]);
         if (!same) {
             for (int i = 0; i < m; ++i)
                 if (gemm_launch(p[i], s)) return -1;

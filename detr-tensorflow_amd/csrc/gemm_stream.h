@@ -1,0 +1,250 @@
+// gemm_stream.h -- streaming short-K GEMM for the bf16-stored backbone activations.
+//
+// The 1x1 convolutions of ResNet layer1 / layer2 (resnet_backbone.py:119-135 and their input gradients) are
+// C[M, N] = A[M, K] * B with M = B*H*W in the hundreds of thousands and K = 64 .. 256: 1-4 MFMAs per 32x32 output
+// tile against an epilogue that reads the residual (and the ReLU mask) and writes C.  They are HBM streams, and the
+// generic tile engine (gemm_f32.hip) runs them at ~3 TB/s: per workgroup one operand round trip, two barriers and a
+// rolled four-item epilogue with a round trip per item, ~0.45 instructions per output element.  A plain elementwise
+// kernel moves the same traffic mix at 5.5-6 TB/s on this chip (scripts/experiments/hbm_mix_probe.py).
+//
+// This kernel is built like the elementwise kernel instead:
+//   * persistent waves: a workgroup stages its 64-column slice of B (K x 64 bf16, <= 17 KB) in LDS once and its four
+//     waves then walk independently over 32-row strips of A -- no workgroup barrier after the prologue;
+//   * the MFMA is issued with the operands swapped (D^T = B^T A^T), so (a) the A fragment of a lane is 16 contiguous
+//     bytes of one row of A in global memory and is loaded straight into registers, one strip ahead, and (b) every
+//     accumulator quad holds 4 consecutive columns of one row: the wave-private LDS transposition is 8 ds_write_b128
+//     + 8 ds_read_b128 per 32x64 strip and leaves each lane with 8 consecutive columns (16 bytes of bf16);
+//   * residual, mask and output are 16-byte accesses covering whole 128-byte lines (8 rows per wave instruction); the
+//     residual / mask of a strip are requested before its MFMAs, the A rows of the next strip before its epilogue;
+//   * the workgroups that share A rows (the N / 64 column slices) are placed on the same XCD so that A is read from
+//     HBM once and from that XCD's L2 otherwise.
+// Arithmetic: bf16 x bf16 -> fp32 MFMA (v_mfma_f32_32x32x16_bf16), epilogue in fp32 in the order of gemm_core.h
+// epi_one (bias, residual, ReLU, mask), one RNE rounding to bf16.
+#pragma once
+#include "gemm_core.h"
+#include "gemm_bf16_core.h"
+
+namespace detr {
+
+struct StreamArgs {
+    int M, N;
+    const unsigned short *A; long long lda;        // [M][lda] bf16, K contiguous
+    const unsigned short *B; long long ldb;        // BKC: [N][ldb] (K contiguous); else [K][ldb] (N contiguous)
+    unsigned short *C; long long ldc;              // [M][ldc] bf16
+    const unsigned short *res; long long ldr;      // optional [M][ldr] bf16
+    const unsigned short *mask; long long ldm;     // optional [M][ldm] bf16, keeps C where mask > 0
+    const float *bias;                             // optional [N] fp32
+    int act;                                       // 0 none, 1 ReLU
+    int n_tiles;                                   // N / 64
+    int row_tiles;                                 // cdiv(M, 32)
+    int q;                                         // workgroups per (XCD, column slice); grid = 8 * n_tiles * q
+};
+
+constexpr int STREAM_LD = 68;                      // floats per staged row (64 + 4): conflict-free b128 writes and reads
+
+template <int K>
+struct StreamSmem {
+    unsigned short B[64][K + 8];                   // [n][k], +8 bf16 of padding: 16-byte fragment reads spread over the banks
+    float stage[4][32][STREAM_LD];                 // one 32 x 64 fp32 strip per wave
+};
+
+__device__ __forceinline__ void stream_unpack8(uint4 r, float (&o)[8]) {
+    o[0] = bf16_bits_to_f32(r.x & 0xFFFFu); o[1] = __builtin_bit_cast(float, r.x & 0xFFFF0000u);
+    o[2] = bf16_bits_to_f32(r.y & 0xFFFFu); o[3] = __builtin_bit_cast(float, r.y & 0xFFFF0000u);
+    o[4] = bf16_bits_to_f32(r.z & 0xFFFFu); o[5] = __builtin_bit_cast(float, r.z & 0xFFFF0000u);
+    o[6] = bf16_bits_to_f32(r.w & 0xFFFFu); o[7] = __builtin_bit_cast(float, r.w & 0xFFFF0000u);
+}
+
+// workgroups per CU that fit the 160 KB of LDS (at most 3: 12 waves / CU already keep > 100 KB of requests in flight)
+template <int K>
+struct StreamOcc {
+    static constexpr int BYTES = (int)sizeof(StreamSmem<K>);
+    static constexpr int VALUE = (3 * BYTES <= 160 * 1024) ? 3 : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
+};
+
+template <int K, bool BKC, bool RES, bool MASK>
+__global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_kernel(StreamArgs a) {
+    constexpr int KC = (K > 128) ? 128 : K;       // A rows are held in registers one K chunk (<= 128) at a time
+    constexpr int NC = K / KC;                     // chunks per strip: 1, or an even number
+    constexpr int KK = KC / 16;                    // MFMA k-steps per chunk
+    static_assert(K % KC == 0 && (NC == 1 || NC % 2 == 0), "gemm_stream: K must be 64, 128 or a multiple of 256");
+    __shared__ __attribute__((aligned(16))) StreamSmem<K> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup id -> (XCD, column slice, walker): ids are dealt round-robin over the 8 XCDs, so the n_tiles slices of
+    // one walker p are consecutive multiples of 8 apart -- same XCD, dispatched together, same A rows
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int nt = j % a.n_tiles, p = (j / a.n_tiles) * 8 + xcd;
+    const int n0 = nt * 64;
+    const int stride = a.q * 8 * 4;                // wave slots per column slice
+
+    // ---- prologue: B slice -> LDS as [n][k] --------------------------------------------------------------------------
+    if (BKC) {
+        for (int c = tid; c < 64 * (K / 8); c += 256) {
+            const int n = c / (K / 8), kc = c - n * (K / 8);
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(n0 + n) * a.ldb + kc * 8);
+            *reinterpret_cast<uint4 *>(&sm.B[n][kc * 8]) = v;
+        }
+    } else {
+        for (int c = tid; c < K * 8; c += 256) {
+            const int k = c >> 3, nc = c & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + n0 + nc * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sm.B[nc * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
+                sm.B[nc * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane constants ----------------------------------------------------------------------------------------------
+    const int l31 = lane & 31, h = lane >> 5;
+    const int erow = lane >> 3, ecg = lane & 7;    // epilogue item: 8 rows x 8 column groups of 8
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = a.bias ? a.bias[n0 + ecg * 8 + i] : 0.0f;
+    BufSrc srcA, srcR, srcM;
+    srcA.init_bytes(a.A, ((long long)(a.M - 1) * a.lda + K) * 2);
+    if (RES) srcR.init_bytes(a.res, ((long long)(a.M - 1) * a.ldr + a.N) * 2);
+    if (MASK) srcM.init_bytes(a.mask, ((long long)(a.M - 1) * a.ldm + a.N) * 2);
+    float *stage = &sm.stage[wave][0][0];
+    const unsigned a_lane = (unsigned)(h * 16);    // byte offset of this lane's 8 k values inside a 16-k step
+
+    auto load_a = [&](int rt, int chunk, uint4 (&f)[KK]) {
+        const int row = rt * 32 + l31;
+        const unsigned base = (rt < a.row_tiles && row < a.M) ? (unsigned)((long long)row * a.lda * 2) + a_lane + chunk * (KC * 2) : BUF_OOB;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
+    };
+    // D^T[n][m] += sum_k B^T[n][k] A^T[k][m] over one chunk: lane&31 = m, accumulator r -> n = (r&3) + 8*(r>>2) + 4*h (+32*nh)
+    auto mma = [&](const uint4 (&f)[KK], int chunk, f32x16 (&acc)[2]) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, f[kk]);
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+                acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
+            }
+        }
+    };
+
+    // one strip: epilogue-operand requests, A prefetch, MFMAs, transposition, epilogue.  a_first holds chunk 0 of the
+    // strip on entry.  NC == 1: the next strip's rows go to a_other and the two buffers swap roles from strip to strip
+    // (the loop below is unrolled by two), so no register copy -- which would have to wait for the prefetch -- sits at
+    // the end of a strip.  NC even: the chunks alternate between the buffers and chunk 0 of the next strip lands in
+    // a_first again.
+    auto strip = [&](const int rt, uint4 (&a_first)[KK], uint4 (&a_other)[KK]) {
+        const int r0 = rt * 32;
+        uint4 rres[4], rmsk[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = r0 + it * 8 + erow;
+            const unsigned colb = (unsigned)((n0 + ecg * 8) * 2);
+            if (RES) rres[it] = srcR.ld16(row < a.M ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
+            if (MASK) rmsk[it] = srcM.ld16(row < a.M ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nh][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool last = (c + 1 == NC);
+            if (c % 2 == 0) {
+                load_a(last ? rt + stride : rt, last ? 0 : c + 1, a_other);
+                mma(a_first, c, acc);
+            } else {
+                load_a(last ? rt + stride : rt, last ? 0 : c + 1, a_first);
+                mma(a_other, c, acc);
+            }
+        }
+        // ---- wave-private transposition: quads of 4 consecutive columns -> rows of 8 consecutive columns per lane
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(stage + l31 * STREAM_LD + nh * 32 + 8 * g + 4 * h) =
+                    make_float4(acc[nh][4 * g], acc[nh][4 * g + 1], acc[nh][4 * g + 2], acc[nh][4 * g + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + erow;
+            const int row = r0 + rl;
+            const float4 v0 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8);
+            const float4 v1 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bias[i];
+            if (RES) {
+                float r[8];
+                stream_unpack8(rres[it], r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += r[i];
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            if (MASK) {
+                float m[8];
+                stream_unpack8(rmsk[it], m);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
+            }
+            if (row < a.M)
+                *reinterpret_cast<uint4 *>(a.C + (long long)row * a.ldc + n0 + ecg * 8) =
+                    make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]),
+                               f32_to_bf16_pair(v[6], v[7]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int rt = p * 4 + wave;
+    uint4 a0[KK], a1[KK];
+    load_a(rt, 0, a0);
+    while (rt < a.row_tiles) {
+        strip(rt, a0, a1);
+        rt += stride;
+        if (NC == 1) {
+            if (rt >= a.row_tiles) break;
+            strip(rt, a1, a0);
+            rt += stride;
+        }
+    }
+}
+
+// Host side: eligibility is decided by the caller (gemm_f32.hip); here only the grid.
+template <int K>
+static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
+    a.n_tiles = a.N / 64;
+    a.row_tiles = (a.M + 31) / 32;
+    const int wgs_per_cu = StreamOcc<K>::VALUE;
+    int q = (256 * wgs_per_cu) / (8 * a.n_tiles);
+    const int qmax = a.row_tiles / (8 * 4 * 2);                 // at least two strips per wave
+    if (q > qmax) q = qmax;
+    if (q < 1) q = 1;
+    a.q = q;
+    const dim3 grid((unsigned)(8 * a.n_tiles * q));
+    const bool r = a.res != nullptr, m = a.mask != nullptr;
+#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_>), grid, dim3(256), 0, s, a)
+    if (bkc) {
+        if (r && m) DETR_STREAM_LAUNCH(true, true, true);
+        else if (r) DETR_STREAM_LAUNCH(true, true, false);
+        else if (m) DETR_STREAM_LAUNCH(true, false, true);
+        else DETR_STREAM_LAUNCH(true, false, false);
+    } else {
+        if (r && m) DETR_STREAM_LAUNCH(false, true, true);
+        else if (r) DETR_STREAM_LAUNCH(false, true, false);
+        else if (m) DETR_STREAM_LAUNCH(false, false, true);
+        else DETR_STREAM_LAUNCH(false, false, false);
+    }
+#undef DETR_STREAM_LAUNCH
+}
+
+}  // namespace detr

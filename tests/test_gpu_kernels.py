@@ -976,3 +976,52 @@ def test_scale_cols_bf16_group_matches_single_launches(hip):
     for w, sc, a, b in zip(ws, scs, one, grp):
         assert torch.equal(a, b)
         assert torch.equal(a, (w * sc).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K,bk,use_res,use_mask,act", [
+    (20000, 256, 64, 0, True, False, 1),      # layer1 conv3 forward: bias + residual + ReLU
+    (16411, 256, 64, 1, True, True, 0),       # layer1 conv1 input gradient: residual + ReLU mask, ragged last strip
+    (16384, 64, 64, 0, False, False, 1),      # one column slice
+    (33600, 512, 128, 0, True, False, 1),     # layer2 conv3 forward
+    (17000, 512, 128, 1, True, True, 0),      # layer2 conv1 input gradient
+    (16390, 128, 128, 1, False, True, 0),
+    (16500, 64, 256, 0, False, False, 1),     # layer1 conv1 forward (two K chunks per strip)
+    (33600, 1024, 256, 1, True, True, 0),     # layer3 conv1 input gradient
+])
+def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
+    """The streaming short-K kernel (csrc/gemm_stream.h; bf16 A / B / C / residual / mask, K in {64, 128}, M >= 16384) against
+    fp64 on the same bf16 operands (one bf16 rounding of the result) and against the generic tile engine on the same call
+    (DETR_HIP_GEMM_STREAM=2): the two may differ by the order of the fp32 products inside an MFMA, i.e. by one bf16 ulp on
+    a small fraction of the outputs."""
+    import os
+    torch.manual_seed(M + N + K + bk)
+    A = _bf(torch.randn(M, K))
+    Bm = _bf(torch.randn(N, K) / K ** 0.5 if bk else torch.randn(K, N) / K ** 0.5)
+    res, msk, bias = _bf(torch.randn(M, N)), _bf(torch.randn(M, N)), torch.randn(N).double()
+    ref = A @ (Bm.t() if bk else Bm) + bias
+    if use_res:
+        ref = ref + res
+    if act:
+        ref = torch.relu(ref)
+    if use_mask:
+        ref = torch.where(msk > 0, ref, torch.zeros_like(ref))
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    Ad, Bd, rd, md, bd = b16(A), b16(Bm), b16(res), b16(msk), g(bias.float())
+    outs = []
+    for mode in ("0", "2"):
+        os.environ["DETR_HIP_GEMM_STREAM"] = mode
+        try:
+            C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm(M, N, K, Ad, K, 1, Bd, K if bk else N, bk, C, N, bias=bd, residual=rd if use_res else None, ldr=N if use_res else 0,
+                     mask=md if use_mask else None, ldmask=N if use_mask else 0, act=act, compute=1)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DETR_HIP_GEMM_STREAM", None)
+        outs.append(C.float().cpu().double())
+    stream, generic = outs
+    scale = float(ref.abs().max())
+    err = (stream - ref).abs()
+    assert float((err / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.05, "stream GEMM: more than one bf16 rounding from fp64"
+    diff = (stream - generic).abs()
+    assert float((diff > 0).double().mean()) < 2e-3, float((diff > 0).double().mean())
+    assert float((diff / (generic.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
