@@ -78,27 +78,6 @@ __global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_ker
     const int n0 = nt * 64;
     const int stride = a.q * 8 * 4;                // wave slots per column slice
 
-    // ---- prologue: B slice -> LDS as [n][k] --------------------------------------------------------------------------
-    if (BKC) {
-        for (int c = tid; c < 64 * (K / 8); c += 256) {
-            const int n = c / (K / 8), kc = c - n * (K / 8);
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(n0 + n) * a.ldb + kc * 8);
-            *reinterpret_cast<uint4 *>(&sm.B[n][kc * 8]) = v;
-        }
-    } else {
-        for (int c = tid; c < K * 8; c += 256) {
-            const int k = c >> 3, nc = c & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + n0 + nc * 8);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sm.B[nc * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
-                sm.B[nc * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
-            }
-        }
-    }
-    __syncthreads();
-
     // ---- per-lane constants ----------------------------------------------------------------------------------------------
     const int l31 = lane & 31, h = lane >> 5;
     const int erow = lane >> 3, ecg = lane & 7;    // epilogue item: 8 rows x 8 column groups of 8
@@ -207,7 +186,29 @@ __global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_ker
 
     int rt = p * 4 + wave;
     uint4 a0[KK], a1[KK];
-    load_a(rt, 0, a0);
+    load_a(rt, 0, a0);                             // first A rows: in flight while the B slice is staged
+
+    // ---- prologue: B slice -> LDS as [n][k] (the only workgroup barrier of the kernel) ---------------------------
+    if (BKC) {
+        for (int c = tid; c < 64 * (K / 8); c += 256) {
+            const int n = c / (K / 8), kc = c - n * (K / 8);
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(n0 + n) * a.ldb + kc * 8);
+            *reinterpret_cast<uint4 *>(&sm.B[n][kc * 8]) = v;
+        }
+    } else {
+        for (int c = tid; c < K * 8; c += 256) {
+            const int k = c >> 3, nc = c & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + n0 + nc * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sm.B[nc * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
+                sm.B[nc * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+
     while (rt < a.row_tiles) {
         strip(rt, a0, a1);
         rt += stride;

@@ -39,8 +39,28 @@ if len(sys.argv) >= 4:
         if pat in k:
             f = v.get("FETCH_SIZE", (0, 0)); w = v.get("WRITE_SIZE", (0, 0))
             n += max(f[0], w[0]); fetch += f[1]; write += w[1]
+    def fold(name):
+        """rocprofv3 kernel name -> the family name detr_tf/_hip.py reports (tile sizes pooled, grouped launches folded into
+        their base kernel, every instantiation of the streaming kernel pooled)."""
+        m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group)?_kernel<\d+, \d+, \d+, \d+, ([^>]*)>", name)
+        if m:
+            return f"{m.group(1)}_kernel<{m.group(2)}>"
+        if "detr::gemm_stream_bf16_kernel" in name:
+            return "gemm_stream_bf16_kernel"
+        return None
+
+    per = {}
+    for k, v in res.items():
+        key = fold(k)
+        if key is None:
+            continue
+        f = v.get("FETCH_SIZE", (0, 0)); w = v.get("WRITE_SIZE", (0, 0))
+        e = per.setdefault(key, {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
+        e["launches"] += max(f[0], w[0]); e["FETCH_SIZE_KB"] += f[1]; e["WRITE_SIZE_KB"] += w[1]
+    for e in per.values():
+        e["traffic_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024.0 / max(e["launches"], 1)
     if n:
-        json.dump({"kernel": pat + "*", "launches": n, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+        json.dump({"kernel": pat + "*", "per_symbol": per, "launches": n, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                    "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n,
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE separate passes over bench.py --steps 2 --warmup 1; bytes = "
                            "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md gfx950 correction; launches of all shapes pooled"},
