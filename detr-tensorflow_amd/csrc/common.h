@@ -41,6 +41,17 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 #define DETR_GEMM64_MINW 1
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire of ALL address
+// spaces, and on gfx9 loads and stores share vmcnt -- it therefore drains every outstanding global load, which would
+// serialise an operand prefetch that is meant to stay in flight across the barrier.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 // tuning hook: integer environment variable (0 when unset)
 static inline int env_tile(const char *name) {
     const char *v = getenv(name);

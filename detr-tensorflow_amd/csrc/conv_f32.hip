@@ -360,15 +360,21 @@ struct LoaderConvAb {
         }
     }
     // halo / stride-parity / tile-edge lanes take the out-of-range offset: the descriptor returns zeros, no branch
-    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, Reg (&r)[NV]) const {
+    // live = false: a request past the last K tile (operand pipeline tail) -- every lane takes the out-of-range offset
+    __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, Reg (&r)[NV], bool live = true) const {
         const int tap = kt / cpt;
-        const int c0 = (kt - tap * cpt) * BF_BK + kq;
         int kh, kw;
         conv_tap(a, tap, kh, kw);
+        load_tap(a, kh, kw, kt - tap * cpt, r, live);
+    }
+    // the same with the tap (kh, kw) and the channel tile kc inside the tap given by the caller (the main loop keeps them
+    // as running counters: the divisions of load() are ~40 scalar instructions per K tile, more than the tile's MFMAs)
+    __device__ __forceinline__ void load_tap(const ConvArgs &a, int kh, int kw, int kc, Reg (&r)[NV], bool live = true) const {
+        const int c0 = kc * BF_BK + kq;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int hs, ws;
-            bool v = ok[i];
+            bool v = ok[i] && live;
             if (DGRAD) {
                 const int th = h_[i] - kh, tw = w_[i] - kw;
                 v = v && th >= 0 && tw >= 0;
@@ -432,34 +438,52 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    typename LoaderConvAb<BM, DGRAD, X16>::Reg ra[LoaderConvAb<BM, DGRAD, X16>::NV];
-    typename LB::Reg rb[NRB];
-    auto load_b = [&](int kt) {
-        const int tap = kt / cpt;
-        int kh, kw;
-        conv_tap(a, tap, kh, kw);
-        lb.load((kt - tap * cpt) * BF_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * (W16 ? 2 : 4)));
+    // Operand pipeline two K tiles deep with LDS-only barriers -- see gemm_bf16c_body (gemm_f32.hip): requests and LDS
+    // stores are unconditional (past the last tile they resolve to the out-of-range offset / write a buffer nobody reads)
+    // so that the compiler's vmcnt waits stay exact.
+    using LAc = LoaderConvAb<BM, DGRAD, X16>;
+    typename LAc::Reg ra0[LAc::NV], ra1[LAc::NV];
+    typename LB::Reg rb0[NRB], rb1[NRB];
+    // K tiles are requested strictly in order (0, 1, 2, then kt + 3 per iteration): the tap and the channel tile inside it
+    // are running counters instead of kt / cpt and conv_tap()'s divisions
+    const int tap_cols = a.par_on ? a.ntw : 3;
+    int it_kc = 0, it_ti = 0, it_tj = 0;
+    auto load_ab = [&](int kt, typename LAc::Reg (&ra)[LAc::NV], typename LB::Reg (&rb)[NRB]) {
+        const bool live = kt < nkt;
+        const int kh = a.par_on ? a.kh0 + 2 * it_ti : it_ti;
+        const int kw = a.par_on ? a.kw0 + 2 * it_tj : it_tj;
+        la.load_tap(a, kh, kw, it_kc, ra, live);
+        lb.load(it_kc * BF_BK, live ? a.Cs : 0, rb, live ? (unsigned)((kh * 3 + kw) * tapstride * (W16 ? 2 : 4)) : 0u);
+        if (++it_kc == cpt) {
+            it_kc = 0;
+            if (++it_tj == tap_cols) {
+                it_tj = 0;
+                ++it_ti;
+            }
+        }
     };
-    la.load(a, 0, cpt, ra);
-    load_b(0);
-    la.store(sm.A[0], ra);
-    lb.store(sm.B[0], rb);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1) < nkt;
-        if (more) {
-            la.load(a, kt + 1, cpt, ra);
-            load_b(kt + 1);
-        }
+    load_ab(0, ra0, rb0);
+    la.store(sm.A[0], ra0);
+    lb.store(sm.B[0], rb0);
+    load_ab(1, ra0, rb0);
+    load_ab(2, ra1, rb1);
+    lds_barrier();
+    auto iter = [&](const int kt, const int cur, typename LAc::Reg (&rpa)[LAc::NV], typename LB::Reg (&rpb)[NRB]) {
+        la.store(sm.A[cur ^ 1], rpa);
+        lb.store(sm.B[cur ^ 1], rpb);
+        load_ab(kt + 3, rpa, rpb);
         mma_ktile_bf16<BM, BN, WGM, WGN, false, !DGRAD>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
-        if (more) {
-            la.store(sm.A[cur ^ 1], ra);
-            lb.store(sm.B[cur ^ 1], rb);
+        lds_barrier();
+    };
+    {
+        int kt = 0;
+        for (; kt + 2 <= nkt; kt += 2) {
+            iter(kt, 0, ra0, rb0);
+            iter(kt + 1, 1, ra1, rb1);
         }
-        __syncthreads();
-        cur ^= 1;
+        if (kt < nkt) iter(kt, 0, ra0, rb0);
     }
+    __syncthreads();
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), a.dst, a.Cd, a.M, a.Cd, m0, n0, wm, wn, lane, wave, a.e);
 }
 
@@ -614,19 +638,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     typedef typename std::conditional<S16, uint2, float4>::type Reg;     // 4 channels of one pixel
-    Reg rx[7], rd[2];
-    auto load_unit = [&](int u) {
-        const int chunk = u % chunks;
-        const int t = u / chunks;
-        const int ho = t % a.Ho, n = t / a.Ho;
-        const int wo0 = chunk * 32;
+    // two register sets: the operand pipeline is two units deep (see gemm_bf16c_body); requests past u_end take the
+    // out-of-range offset and every unit is stored, so that the vmcnt waits in front of the LDS stores stay exact
+    Reg rx0[7], rd0[2], rx1[7], rd1[2];
+    // units are requested strictly in order (u_begin, +1, +2, ...): (chunk, output row, image) are running counters
+    // instead of three divisions per unit
+    int it_chunk = u_begin % chunks, it_ho = (u_begin / chunks) % a.Ho, it_n = (u_begin / chunks) / a.Ho;
+    auto load_unit = [&](int u, Reg (&rx)[7], Reg (&rd)[2]) {
+        const bool live = u < u_end;
+        const int ho = it_ho, n = it_n;
+        const int wo0 = it_chunk * 32;
+        if (++it_chunk == chunks) {
+            it_chunk = 0;
+            if (++it_ho == a.Ho) {
+                it_ho = 0;
+                ++it_n;
+            }
+        }
         // dy tile: LoaderMNt<64> map (row = pixel j, col = co)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int v = tid + 256 * i;
             const int j = 4 * (v >> 6) + ((v >> 2) & 3);
             const int col = 16 * ((v >> 4) & 3) + 4 * (v & 3);
-            const bool ok = wo0 + j < a.Wo;
+            const bool ok = live && wo0 + j < a.Wo;
             const unsigned off = ((unsigned)((n * a.Ho + ho) * a.Wo + wo0 + j) * (unsigned)a.Co + (unsigned)(co0 + col)) * (S16 ? 2u : 4u);
             if constexpr (S16) rd[i] = ds.ld8(ok ? off : BUF_OOB);
             else rd[i] = ds.ld4(ok ? off : BUF_OOB);
@@ -638,13 +673,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             const int pp = v >> 4, c4 = v & 15;
             const int kh = pp / 34, c = pp - kh * 34;
             const int hi = ho - 1 + kh, wi = wo0 - 1 + c;
-            const bool ok = pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+            const bool ok = live && pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
             const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * (S16 ? 2u : 4u);
             if constexpr (S16) rx[i] = xs.ld8(ok ? off : BUF_OOB);
             else rx[i] = xs.ld4(ok ? off : BUF_OOB);
         }
     };
-    auto store_unit = [&](int buf) {
+    auto store_unit = [&](int buf, const Reg (&rx)[7], const Reg (&rd)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if constexpr (S16) *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = rd[i];
@@ -680,13 +715,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             }
         dofs[s2] = ((4 * s2 + 2 * (g >> 1)) * 4 + 2 * wn + (g & 1)) * 64 + t16 * 4;
     }
-    load_unit(u_begin);
-    store_unit(0);
-    __syncthreads();
-    int cur = 0;
-    for (int u = u_begin; u < u_end; ++u) {
-        const bool more = (u + 1) < u_end;
-        if (more) load_unit(u + 1);
+    load_unit(u_begin, rx0, rd0);
+    store_unit(0, rx0, rd0);
+    load_unit(u_begin + 1, rx0, rd0);
+    load_unit(u_begin + 2, rx1, rd1);
+    lds_barrier();
+    // one unit: the set `rp` holds unit u+1 (stored now, then refilled with unit u+3); LDS buffer cur holds unit u
+    auto iter = [&](const int u, const int cur, Reg (&rpx)[7], Reg (&rpd)[2]) {
+        store_unit(cur ^ 1, rpx, rpd);
+        load_unit(u + 3, rpx, rpd);
         const unsigned short *X = sm.X[cur];
         const unsigned short *D = sm.D[cur];
 #pragma unroll
@@ -705,10 +742,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
                     acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
                 }
         }
-        if (more) store_unit(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        lds_barrier();
+    };
+    {
+        int u = u_begin;
+        for (; u + 2 <= u_end; u += 2) {
+            iter(u, 0, rx0, rd0);
+            iter(u + 1, 1, rx1, rd1);
+        }
+        if (u < u_end) iter(u, 0, rx0, rd0);
     }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         f32x16 one[1][1];

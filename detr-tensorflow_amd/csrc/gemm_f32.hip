@@ -208,30 +208,47 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int bid
             for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
         }
     };
-    typename LA::Reg ra[NRA];
-    typename LB::Reg rb[NRB];
-    la.load(kt0 * BF_BK, g.K, ra);
-    lb.load(kt0 * BF_BK, g.K, rb);
-    if (do_rs) rs_add(ra);
-    la.store(sm.A[0], ra);
-    lb.store(sm.B[0], rb);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1) < kt1;
-        if (more) {
-            la.load((kt + 1) * BF_BK, g.K, ra);
-            lb.load((kt + 1) * BF_BK, g.K, rb);
-        }
+    // Operand pipeline, two K tiles deep: while tile kt is multiplied out of LDS, tile kt+1 sits in one register set
+    // (requested an iteration ago, stored to the other LDS buffer at the top of this iteration) and tile kt+2 is in
+    // flight into the second set.  The barrier orders LDS only (lds_barrier, common.h): __syncthreads() would drain
+    // vmcnt and with it the requests that are supposed to stay in flight -- with it, the iteration time of a workgroup
+    // was one HBM / L2 round trip however deep the register pipeline.
+    typename LA::Reg ra0[NRA], ra1[NRA];
+    typename LB::Reg rb0[NRB], rb1[NRB];
+    const int kend = min(g.K, kt1 * BF_BK);      // requests past this split's K range resolve to the out-of-range offset: no traffic
+    la.load(kt0 * BF_BK, kend, ra0);
+    lb.load(kt0 * BF_BK, kend, rb0);
+    if (do_rs) rs_add(ra0);
+    la.store(sm.A[0], ra0);
+    lb.store(sm.B[0], rb0);
+    // (the requests are unconditional -- past the last tile they fall outside the buffer descriptor or fetch a tile
+    //  that is never stored: with conditional requests the compiler cannot tell how many are outstanding and waits for
+    //  vmcnt(0) before every LDS store, which puts the full round trip back into each iteration)
+    la.load((kt0 + 1) * BF_BK, kend, ra0);
+    lb.load((kt0 + 1) * BF_BK, kend, rb0);
+    la.load((kt0 + 2) * BF_BK, kend, ra1);
+    lb.load((kt0 + 2) * BF_BK, kend, rb1);
+    lds_barrier();
+    // one iteration: `rp` holds tile kt+1 (stored now, then refilled with tile kt+3), LDS[cur] holds tile kt
+    auto iter = [&](const int kt, const int cur, typename LA::Reg (&rpa)[NRA], typename LB::Reg (&rpb)[NRB]) {
+        if (do_rs && kt + 1 < kt1) rs_add(rpa);
+        la.store(sm.A[cur ^ 1], rpa);              // (unconditional as well: after the last tile it writes a buffer nobody reads)
+        lb.store(sm.B[cur ^ 1], rpb);
+        la.load((kt + 3) * BF_BK, kend, rpa);
+        lb.load((kt + 3) * BF_BK, kend, rpb);
         mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
-        if (more) {
-            if (do_rs) rs_add(ra);
-            la.store(sm.A[cur ^ 1], ra);
-            lb.store(sm.B[cur ^ 1], rb);
+        lds_barrier();
+    };
+    {   // whole pairs in the loop, an odd last tile after it: every path into the loop header carries the same
+        // sequence of outstanding requests, so the compiler's vmcnt waits are exact (vmcnt(2) / vmcnt(3) before the stores)
+        int kt = kt0;
+        for (; kt + 2 <= kt1; kt += 2) {
+            iter(kt, 0, ra0, rb0);
+            iter(kt + 1, 1, ra1, rb1);
         }
-        __syncthreads();
-        cur ^= 1;
+        if (kt < kt1) iter(kt, 0, ra0, rb0);
     }
+    __syncthreads();
     if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, true);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
