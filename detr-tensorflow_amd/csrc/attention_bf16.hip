@@ -12,6 +12,7 @@
 // The backward kernels reuse the same two fragment forms (row fragments for the score-type products, transpose-read
 // fragments for the gradient-type products).  Softmax arithmetic, masks and dropout as in attention_f32.hip.
 #include "attention_common.h"
+#include "gemm_core.h"        // BufSrc: buffer-descriptor loads
 
 namespace detr {
 
@@ -55,6 +56,17 @@ struct TileB {
             v[i] = (row < nrows) ? *reinterpret_cast<const float4 *>(base + (long long)row * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // the same through a buffer descriptor: rows past nrows take the out-of-range offset (zeros), so the request is one
+    // unconditional instruction per float4 -- what the two-tile-deep pipelines below need for exact vmcnt waits
+    __device__ __forceinline__ void loadb(const BufSrc &src, unsigned ld_bytes, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int u = tid + 64 * NW * i;
+            const int r = u >> 3, c = (u & 7) * 4;
+            const int row = row0 + r;
+            v[i] = src.ld4(row < nrows ? (unsigned)row * ld_bytes + 4u * (unsigned)c : BUF_OOB);
+        }
+    }
     __device__ __forceinline__ void store(unsigned short (*S)[AB_LD], int tid, float scale = 1.0f) const {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -84,6 +96,15 @@ __device__ __forceinline__ bf16x8 frag_col(const unsigned short (*S)[AB_LD], int
 
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
+// 8 consecutive floats of one row through a buffer descriptor: two unconditional 16-byte requests (a lane outside the
+// tensor takes the out-of-range offset).  The per-element `ok ? p[i] : 0` form compiled to 16 dependent round trips in
+// the prologue of every workgroup -- about as long as the workgroup's whole key loop at S = 1050.
+__device__ __forceinline__ void ld_row8(const BufSrc &src, bool ok, unsigned byte_off, float (&t)[8]) {
+    const float4 x = src.ld4(ok ? byte_off : BUF_OOB), y = src.ld4(ok ? byte_off + 16u : BUF_OOB);
+    t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
+    t[4] = y.x; t[5] = y.y; t[6] = y.z; t[7] = y.w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -101,12 +122,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
 
     bf16x8 qb[2];                 // B operand of QK^T: Q[tq][16 s + 8 hi ..], in log2 units
+    {
+        BufSrc qsrc;
+        qsrc.init(Qb, (long long)(a.T - 1) * a.ld + 32);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float t[8];
+        for (int s = 0; s < 2; ++s) {
+            float t[8];
+            ld_row8(qsrc, qok, (unsigned)(((long long)tq * a.ld + 16 * s + 8 * hi) * 4), t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = qok ? Qb[(long long)tq * a.ld + 16 * s + 8 * hi + j] * AT_LOG2E : 0.0f;
-        qb[s] = pack8(t);
+            for (int j = 0; j < 8; ++j) t[j] *= AT_LOG2E;
+            qb[s] = pack8(t);
+        }
     }
     f32x16 o;
 #pragma unroll
@@ -115,19 +141,27 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
-    TileB<NW> rk, rv;
-    rk.load(Kb, a.ld, 0, a.S, tid);
-    rv.load(Vb, a.ld, 0, a.S, tid);
-    rk.store(Ks[0], tid);
-    rv.store(Vs[0], tid);
-    __syncthreads();
-    int cur = 0;
-    for (int it = 0; it < ntiles; ++it) {
-        const bool more = (it + 1) < ntiles;
-        if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
-        }
+    // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
+    // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
+    BufSrc ksrc, vsrc;
+    ksrc.init(Kb, (long long)(a.S - 1) * a.ld + 32);
+    vsrc.init(Vb, (long long)(a.S - 1) * a.ld + 32);
+    const unsigned ldb = (unsigned)(a.ld * 4);
+    TileB<NW> rk0, rv0, rk1, rv1;
+    rk0.loadb(ksrc, ldb, 0, a.S, tid);
+    rv0.loadb(vsrc, ldb, 0, a.S, tid);
+    rk0.store(Ks[0], tid);
+    rv0.store(Vs[0], tid);
+    rk0.loadb(ksrc, ldb, AB_ROWS, a.S, tid);
+    rv0.loadb(vsrc, ldb, AB_ROWS, a.S, tid);
+    rk1.loadb(ksrc, ldb, 2 * AB_ROWS, a.S, tid);
+    rv1.loadb(vsrc, ldb, 2 * AB_ROWS, a.S, tid);
+    lds_barrier();
+    auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
+        rpk.store(Ks[cur ^ 1], tid);
+        rpv.store(Vs[cur ^ 1], tid);
+        rpk.loadb(ksrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
+        rpv.loadb(vsrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
 #pragma unroll 1
         for (int sub = 0; sub < AB_SUB; ++sub) {
         const int kbase = it * AB_ROWS + sub * AT_KEYS;
@@ -170,12 +204,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
         o = MFMA_BF16(frag_col(Vt, 0, lane), pack8(p), o);
         o = MFMA_BF16(frag_col(Vt, 1, lane), pack8(p + 8), o);
         }   // sub
-        if (more) {
-            rk.store(Ks[cur ^ 1], tid);
-            rv.store(Vs[cur ^ 1], tid);
+        lds_barrier();
+    };
+    {
+        int it = 0;
+        for (; it + 2 <= ntiles; it += 2) {
+            tile(it, 0, rk0, rv0);
+            tile(it + 1, 1, rk1, rv1);
         }
-        __syncthreads();
-        cur ^= 1;
+        if (it < ntiles) tile(it, 0, rk0, rv0);
     }
     if (qok) {
         const float inv = 1.0f / lsum;
@@ -190,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
 // backward 1/2: dQ (per query tile, streams the keys) and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AB_ROWS][AB_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AB_ROWS][AB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,19 +241,27 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 
     bf16x8 qb[2], dob[2];
     float dl = 0.0f;
+    {
+        const long long hb = (long long)b * a.T * a.ld + h * 32, ext = (long long)(a.T - 1) * a.ld + 32;
+        BufSrc qsrc, dosrc, osrc;
+        qsrc.init(a.Q + hb, ext);
+        dosrc.init(a.dO + hb, ext);
+        osrc.init(a.O + hb, ext);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float tqv[8], tdo[8];
+        for (int s = 0; s < 2; ++s) {
+            float tqv[8], tdo[8], tov[8];
+            const unsigned off = (unsigned)(((long long)tq * a.ld + 16 * s + 8 * hi) * 4);
+            ld_row8(qsrc, qok, off, tqv);
+            ld_row8(dosrc, qok, off, tdo);
+            ld_row8(osrc, qok, off, tov);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * s + 8 * hi + j;
-            tqv[j] = qok ? a.Q[qoff + d] * AT_LOG2E : 0.0f;
-            tdo[j] = qok ? a.dO[qoff + d] : 0.0f;
-            const float ov = qok ? a.O[qoff + d] : 0.0f;
-            dl += tdo[j] * ov;
+            for (int j = 0; j < 8; ++j) {
+                tqv[j] *= AT_LOG2E;
+                dl += tdo[j] * tov[j];
+            }
+            qb[s] = pack8(tqv);
+            dob[s] = pack8(tdo);
         }
-        qb[s] = pack8(tqv);
-        dob[s] = pack8(tdo);
     }
     dl += __shfl_xor(dl, 32, 64);
     const float lse = qok ? a.LSE[(long long)bh * a.T + tq] * AT_LOG2E : INFINITY;
@@ -228,19 +273,27 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
 
     const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
-    TileB<NW> rk, rv;
-    rk.load(Kb, a.ld, 0, a.S, tid);
-    rv.load(Vb, a.ld, 0, a.S, tid);
-    rk.store(Ks[0], tid);
-    rv.store(Vs[0], tid);
-    __syncthreads();
-    int cur = 0;
-    for (int it = 0; it < ntiles; ++it) {
-        const bool more = (it + 1) < ntiles;
-        if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AB_ROWS, a.S, tid);
-        }
+    // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
+    // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
+    BufSrc ksrc, vsrc;
+    ksrc.init(Kb, (long long)(a.S - 1) * a.ld + 32);
+    vsrc.init(Vb, (long long)(a.S - 1) * a.ld + 32);
+    const unsigned ldb = (unsigned)(a.ld * 4);
+    TileB<NW> rk0, rv0, rk1, rv1;
+    rk0.loadb(ksrc, ldb, 0, a.S, tid);
+    rv0.loadb(vsrc, ldb, 0, a.S, tid);
+    rk0.store(Ks[0], tid);
+    rv0.store(Vs[0], tid);
+    rk0.loadb(ksrc, ldb, AB_ROWS, a.S, tid);
+    rv0.loadb(vsrc, ldb, AB_ROWS, a.S, tid);
+    rk1.loadb(ksrc, ldb, 2 * AB_ROWS, a.S, tid);
+    rv1.loadb(vsrc, ldb, 2 * AB_ROWS, a.S, tid);
+    lds_barrier();
+    auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
+        rpk.store(Ks[cur ^ 1], tid);
+        rpv.store(Vs[cur ^ 1], tid);
+        rpk.loadb(ksrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
+        rpv.loadb(vsrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
 #pragma unroll 1
         for (int sub = 0; sub < AB_SUB; ++sub) {
         const int kbase = it * AB_ROWS + sub * AT_KEYS;
@@ -271,12 +324,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
         dq = MFMA_BF16(frag_col(Kt, 0, lane), pack8(ds), dq);
         dq = MFMA_BF16(frag_col(Kt, 1, lane), pack8(ds + 8), dq);
         }   // sub
-        if (more) {
-            rk.store(Ks[cur ^ 1], tid);
-            rv.store(Vs[cur ^ 1], tid);
+        lds_barrier();
+    };
+    {
+        int it = 0;
+        for (; it + 2 <= ntiles; it += 2) {
+            tile(it, 0, rk0, rv0);
+            tile(it + 1, 1, rk1, rv1);
         }
-        __syncthreads();
-        cur ^= 1;
+        if (it < ntiles) tile(it, 0, rk0, rv0);
     }
     if (qok) {
 #pragma unroll
@@ -289,7 +345,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 // The Q tile is staged as bf16(Q * log2 e) -- the forward's rounded operand -- and K unscaled.
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AB_ROWS][AB_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AB_ROWS][AB_LD];
     __shared__ float Ls[2][AB_ROWS], Dl[2][AB_ROWS];
@@ -306,17 +362,20 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) 
     const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
     bf16x8 kb[2], vb[2];
+    {
+        const long long hb = (long long)b * a.S * a.ld + h * 32, ext = (long long)(a.S - 1) * a.ld + 32;
+        BufSrc ksrc, vsrc;
+        ksrc.init(a.K + hb, ext);
+        vsrc.init(a.V + hb, ext);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float tk[8], tv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * s + 8 * hi + j;
-            tk[j] = kok ? a.K[koff + d] : 0.0f;
-            tv[j] = kok ? a.V[koff + d] : 0.0f;
+        for (int s = 0; s < 2; ++s) {
+            float tk[8], tv[8];
+            const unsigned off = (unsigned)(((long long)sk * a.ld + 16 * s + 8 * hi) * 4);
+            ld_row8(ksrc, kok, off, tk);
+            ld_row8(vsrc, kok, off, tv);
+            kb[s] = pack8(tk);
+            vb[s] = pack8(tv);
         }
-        kb[s] = pack8(tk);
-        vb[s] = pack8(tv);
     }
     f32x16 dk, dv;
 #pragma unroll
@@ -325,6 +384,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) 
     const int ntiles = (a.T + AB_ROWS - 1) / AB_ROWS;
     constexpr int NTH = 64 * NW;                      // threads; each stages AB_ROWS / NTH (l, delta) pairs per iteration
     constexpr int LPP = (AB_ROWS + NTH - 1) / NTH;
+    // (one-tile-deep staging here: the two-deep form of the forward / dQ kernels needs a second register set, which takes
+    //  this kernel from 2 waves per SIMD to 1 -- measured +0.7 ms per step)
     TileB<NW> rq, rd;
     rq.load(Qb, a.ld, 0, a.T, tid);
     rd.load(Db, a.ld, 0, a.T, tid);
