@@ -389,6 +389,9 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
     TileB<NW> rq, rd;
     rq.load(Qb, a.ld, 0, a.T, tid);
     rd.load(Db, a.ld, 0, a.T, tid);
+    BufSrc lsrc, dlsrc;
+    lsrc.init(lse, a.T);
+    dlsrc.init(dlt, a.T);
     float rl[LPP], rdl[LPP];
 #pragma unroll
     for (int j = 0; j < LPP; ++j) {
@@ -409,11 +412,14 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             const int t0 = (it + 1) * AB_ROWS;
             rq.load(Qb, a.ld, t0, a.T, tid);
             rd.load(Db, a.ld, t0, a.T, tid);
+            // raw values only: scaling / padding happens when the set is stored -- arithmetic on a just-requested value
+            // would put a vmcnt wait (for this AND the older Q / dO requests) in front of this iteration's MFMAs
 #pragma unroll
             for (int j = 0; j < LPP; ++j) {
                 const int t = tid + NTH * j;
-                rl[j] = (t < AB_ROWS && t0 + t < a.T) ? lse[t0 + t] * AT_LOG2E : INFINITY;
-                rdl[j] = (t < AB_ROWS && t0 + t < a.T) ? dlt[t0 + t] : 0.0f;
+                const bool ok = t < AB_ROWS && t0 + t < a.T;
+                rl[j] = lsrc.ld1(ok ? 4u * (unsigned)(t0 + t) : BUF_OOB);
+                rdl[j] = dlsrc.ld1(ok ? 4u * (unsigned)(t0 + t) : BUF_OOB);
             }
         }
 #pragma unroll 1
@@ -456,8 +462,14 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             rq.store(Qs[cur ^ 1], tid, AT_LOG2E);
             rd.store(Ds[cur ^ 1], tid);
 #pragma unroll
-            for (int j = 0; j < LPP; ++j)
-                if (tid + NTH * j < AB_ROWS) { Ls[cur ^ 1][tid + NTH * j] = rl[j]; Dl[cur ^ 1][tid + NTH * j] = rdl[j]; }
+            for (int j = 0; j < LPP; ++j) {
+                const int t = tid + NTH * j;
+                if (t < AB_ROWS) {
+                    const bool ok = (it + 1) * AB_ROWS + t < a.T;
+                    Ls[cur ^ 1][t] = ok ? rl[j] * AT_LOG2E : INFINITY;     // +inf => p = exp2(-inf) = 0 for padded queries
+                    Dl[cur ^ 1][t] = ok ? rdl[j] : 0.0f;
+                }
+            }
         }
         __syncthreads();
         cur ^= 1;
