@@ -348,7 +348,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AB_ROWS][AB_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AB_ROWS][AB_LD];
-    __shared__ float Ls[2][AB_ROWS], Dl[2][AB_ROWS];
+    __shared__ __attribute__((aligned(16))) float Ls[2][AB_ROWS], Dl[2][AB_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -437,6 +437,30 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             s = MFMA_BF16(frag_row(Qt, st, lane), kb[st], s);
             dp = MFMA_BF16(frag_row(Dt, st, lane), vb[st], dp);
         }
+        // dropout keep bits of the 16 (query, key sk) elements of this lane.  One 32-bit hash serves the key PAIR
+        // (sk & ~1, sk | 1) of a query row (common.h), and the partner key lives in lane ^ 1: each lane hashes 8 of its 16
+        // query rows (registers r8 + 8 * parity) and takes the other 8 hashes from its neighbour with one DPP quad_perm
+        // each -- half of the integer multiplies (quarter rate) that dominated this loop.
+        uint32_t keepbits = 0xFFFFu;
+        if (a.drop_scale != 0.0f) {
+            const unsigned halfSp = (unsigned)(Sp >> 1);         // Sp is even: ((row * Sp + sk) >> 1) = row * Sp/2 + (sk >> 1)
+            const unsigned long long pbase = ((unsigned long long)bh * a.T + qbase) * halfSp + (unsigned)(sk >> 1);
+            const int odd = lane & 1;                            // == sk & 1 (the workgroup's first key is even)
+            uint32_t hown[8], hoth[8];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+                hown[r8] = drop_hash(a.drop_seed, pbase + (unsigned)(krow(r8, hi) + 16 * odd) * halfSp);
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8)
+                hoth[r8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[r8], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+            keepbits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t h = ((r >> 3) == odd) ? hown[r & 7] : hoth[r & 7];
+                const uint32_t half = odd ? (h >> 16) : (h & 0xFFFFu);
+                keepbits |= (half >= a.drop_thresh ? 1u : 0u) << r;
+            }
+        }
         float p[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             p[r] = fast_exp2(s[r] - Lt[qr]);
             float dpr = dp[r];
             if (a.drop_scale != 0.0f) {
-                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + qbase + qr) * Sp + sk, a.drop_thresh);
+                const bool keep = (keepbits >> r) & 1u;
                 dpr = keep ? dpr * a.drop_scale : 0.0f;
                 ds[r] = p[r] * (dpr - Dlt[qr]);
                 p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
