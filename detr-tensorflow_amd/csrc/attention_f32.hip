@@ -20,8 +20,26 @@
 // patterns (lanes over keys at fixed d, and lanes over d at fixed key).  Double-buffered
 // global->register->LDS pipeline, one barrier per key tile; 4 waves x 32 queries per workgroup.
 #include "attention_common.h"
+#include "gemm_core.h"        // BufSrc: buffer-descriptor loads
 
 namespace detr {
+
+// Elements hi, 2 + hi, 4 + hi, ... of one 32-float head row (the 32x32x2 MFMA operand map of a lane): the row is fetched with
+// eight unconditional 16-byte buffer-descriptor requests and the lane picks its half -- the per-element `ok ? p[i] : 0`
+// form compiled to 16 dependent round trips per tensor in the prologue of every workgroup.
+__device__ __forceinline__ void ld_row_stride2(const float *base, long long extent, bool ok, long long row_off, int hi, float (&out)[16]) {
+    BufSrc src;
+    src.init(base, extent);
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src.ld4(ok ? (unsigned)(row_off * 4) + 16u * i : BUF_OOB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        out[2 * i] = hi ? v[i].y : v[i].x;
+        out[2 * i + 1] = hi ? v[i].w : v[i].z;
+    }
+}
+
 
 constexpr int AT_LD = 33;
 
@@ -67,8 +85,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
 
     float q[16];
+    ld_row_stride2(Qb, (long long)(a.T - 1) * a.ld + 32, qok, (long long)tq * a.ld, hi, q);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) q[s] = qok ? Qb[(long long)tq * a.ld + 2 * s + hi] * AT_LOG2E : 0.0f;   // scores in log2 units
+    for (int s = 0; s < 16; ++s) q[s] *= AT_LOG2E;                                                      // scores in log2 units
 
     f32x16 o;
 #pragma unroll
@@ -162,12 +181,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
 
     float q[16], dout[16];
     float dl = 0.0f;
+    {
+        const long long hb = (long long)b * a.T * a.ld + h * 32, ext = (long long)(a.T - 1) * a.ld + 32;
+        float ov[16];
+        ld_row_stride2(a.Q + hb, ext, qok, (long long)tq * a.ld, hi, q);
+        ld_row_stride2(a.dO + hb, ext, qok, (long long)tq * a.ld, hi, dout);
+        ld_row_stride2(a.O + hb, ext, qok, (long long)tq * a.ld, hi, ov);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        q[s] = qok ? a.Q[qoff + 2 * s + hi] * AT_LOG2E : 0.0f;      // scores in log2 units (q feeds only s)
-        dout[s] = qok ? a.dO[qoff + 2 * s + hi] : 0.0f;
-        const float ov = qok ? a.O[qoff + 2 * s + hi] : 0.0f;
-        dl += dout[s] * ov;
+        for (int s = 0; s < 16; ++s) {
+            q[s] *= AT_LOG2E;                                       // scores in log2 units (q feeds only s)
+            dl += dout[s] * ov[s];
+        }
     }
     dl += __shfl_xor(dl, 32, 64);
     const float lse = qok ? a.LSE[(long long)bh * a.T + tq] * AT_LOG2E : INFINITY;
@@ -252,10 +276,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
     float kk[16], vv[16];
+    {
+        const long long hb = (long long)b * a.S * a.ld + h * 32, ext = (long long)(a.S - 1) * a.ld + 32;
+        ld_row_stride2(a.K + hb, ext, kok, (long long)sk * a.ld, hi, kk);
+        ld_row_stride2(a.V + hb, ext, kok, (long long)sk * a.ld, hi, vv);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        kk[s] = kok ? a.K[koff + 2 * s + hi] * AT_LOG2E : 0.0f;     // scores in log2 units (kk feeds only s)
-        vv[s] = kok ? a.V[koff + 2 * s + hi] : 0.0f;
+        for (int s = 0; s < 16; ++s) kk[s] *= AT_LOG2E;            // scores in log2 units (kk feeds only s)
     }
     f32x16 dk, dv;
 #pragma unroll

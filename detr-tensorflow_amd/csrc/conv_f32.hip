@@ -78,9 +78,13 @@ struct LoaderConvA {
     // halo / stride-parity / tile-edge lanes take the out-of-range offset: the descriptor returns zeros, no branch
     __device__ __forceinline__ void load(const ConvArgs &a, int kt, int cpt, float4 (&r)[NV]) const {
         const int tap = kt / cpt;
-        const int c0 = (kt - tap * cpt) * GEMM_BK + kq;
         int kh, kw;
         conv_tap(a, tap, kh, kw);
+        load_tap(a, kh, kw, kt - tap * cpt, r);
+    }
+    // tap (kh, kw) and channel tile kc given by the caller (running counters in the main loop instead of divisions)
+    __device__ __forceinline__ void load_tap(const ConvArgs &a, int kh, int kw, int kc, float4 (&r)[NV]) const {
+        const int c0 = kc * GEMM_BK + kq;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int hs, ws;
@@ -151,24 +155,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float4 ra[LoaderConvA<BM, DGRAD>::NV], rb[LB::NV];
-    auto load_b = [&](int kt) {
-        const int tap = kt / cpt;
-        int kh, kw;
-        conv_tap(a, tap, kh, kw);
-        lb.load((kt - tap * cpt) * GEMM_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * 4));
+    // K tiles are requested strictly in order: tap and channel tile are running counters (the kt / cpt and conv_tap()
+    // divisions cost ~40 scalar instructions per 16-deep K tile)
+    const int tap_cols = a.par_on ? a.ntw : 3;
+    int it_kc = 0, it_ti = 0, it_tj = 0;
+    auto load_ab = [&]() {
+        const int kh = a.par_on ? a.kh0 + 2 * it_ti : it_ti;
+        const int kw = a.par_on ? a.kw0 + 2 * it_tj : it_tj;
+        la.load_tap(a, kh, kw, it_kc, ra);
+        lb.load(it_kc * GEMM_BK, a.Cs, rb, (unsigned)((kh * 3 + kw) * tapstride * 4));
+        if (++it_kc == cpt) {
+            it_kc = 0;
+            if (++it_tj == tap_cols) {
+                it_tj = 0;
+                ++it_ti;
+            }
+        }
     };
-    la.load(a, 0, cpt, ra);
-    load_b(0);
+    load_ab();
     la.store(sm.A[0], ra);
     lb.store(sm.B[0], rb);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1) < nkt;
-        if (more) {
-            la.load(a, kt + 1, cpt, ra);
-            load_b(kt + 1);
-        }
+        if (more) load_ab();
         mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
