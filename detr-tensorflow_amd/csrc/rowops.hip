@@ -455,6 +455,9 @@ __global__ void scale_cols_bf16_kernel(const float4 *__restrict__ w, const float
     }
 }
 
+// detr_tf/engine.py builds the table as int64[n][5] rows (w, scale, out, n4, c4 | reserved << 32)
+static_assert(sizeof(detr_scale_entry) == 40, "detr_scale_entry layout changed: update Engine._refold_group");
+
 __global__ void scale_cols_bf16_group_kernel(const detr_scale_entry *__restrict__ tab) {
     const detr_scale_entry e = tab[blockIdx.y];
     const float4 *w = reinterpret_cast<const float4 *>(e.w), *scale = reinterpret_cast<const float4 *>(e.scale);
