@@ -5,7 +5,7 @@
 // is staged in LDS once per workgroup as B[n][tap * 64 + k] (k contiguous), eight independent waves then walk over strips of
 // 32 output pixels with NO workgroup barrier: the MFMA runs with swapped operands (D^T = W^T X^T), so a lane's A fragment
 // is 16 contiguous bytes -- 8 channels of one input pixel of one tap -- loaded straight from global memory (the halo takes
-// the buffer descriptor's out-of-range offset), three taps in flight; the accumulators go through a wave-private LDS
+// the buffer descriptor's out-of-range offset), requested one whole strip ahead; the accumulators go through a wave-private LDS
 // transposition and leave as 16-byte stores of whole 128-byte pixels.  Against the implicit-GEMM tile kernel
 // (conv_f32.hip) this removes the A tile's LDS round trip, both barriers per K tile and the per-tile loader arithmetic,
 // which is what bounds that kernel (~75 instructions around 2 MFMAs per K tile).
@@ -70,14 +70,41 @@ __global__ __launch_bounds__(64 * CS_WAVES) void conv3x3_stream64_kernel(ConvStr
     float *stage = stage_all + wave * 32 * STREAM_LD;
     const int HW = a.H * a.W;
 
-    for (int rt = blockIdx.x * CS_WAVES + wave; rt < a.row_tiles; rt += gridDim.x * CS_WAVES) {
+    // Rolling prefetch: the 36 fragment requests (9 taps x 4 k-steps) of a strip are issued one strip ahead, each into the
+    // registers the MFMAs of the same tap of the current strip have just consumed -- every request has a whole strip
+    // (72 MFMAs) to land, which is what the scattered, mostly HBM-latency input reads need at 2 waves per SIMD.
+    struct Pix { int n, h, w; bool ok; };
+    auto decode = [&](int rt) -> Pix {
+        const int m = rt * 32 + l31;
+        Pix p;
+        p.ok = rt < a.row_tiles && m < a.M;
+        const int mm = p.ok ? m : 0;
+        p.n = mm / HW;
+        const int rem = mm - p.n * HW;
+        p.h = rem / a.W;
+        p.w = rem - p.h * a.W;
+        return p;
+    };
+    auto load_tap = [&](const Pix &p, int tap, uint4 (&f)[4]) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int hs = DGRAD ? p.h + 1 - kh : p.h - 1 + kh;
+        const int ws = DGRAD ? p.w + 1 - kw : p.w - 1 + kw;
+        const bool v = p.ok && hs >= 0 && hs < a.H && ws >= 0 && ws < a.W;
+        const unsigned base = v ? (unsigned)(((p.n * a.H + hs) * a.W + ws) * 128 + hh * 16) : BUF_OOB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
+    };
+    const int stride = gridDim.x * CS_WAVES;
+    int rt = blockIdx.x * CS_WAVES + wave;
+    uint4 fa[9][4];
+    {
+        const Pix p0 = decode(rt);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) load_tap(p0, tap, fa[tap]);
+    }
+    for (; rt < a.row_tiles; rt += stride) {
         const int r0 = rt * 32;
-        // this lane's output pixel (column m of the swapped product)
-        const int m = r0 + l31;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW;
-        const int h = rem / a.W, w = rem - h * a.W;
+        const Pix pn = decode(rt + stride);
         uint4 rmsk[4];
         if (MASK) {
 #pragma unroll
@@ -86,39 +113,23 @@ __global__ __launch_bounds__(64 * CS_WAVES) void conv3x3_stream64_kernel(ConvStr
                 rmsk[it] = srcM.ld16(row < a.M ? (unsigned)(row * 128 + ecg * 16) : BUF_OOB);
             }
         }
-        // byte offset of (tap, first k-step) for this lane, or the out-of-range offset in the halo
-        auto tap_off = [&](int tap) -> unsigned {
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            const int hs = DGRAD ? h + 1 - kh : h - 1 + kh;
-            const int ws = DGRAD ? w + 1 - kw : w - 1 + kw;
-            const bool v = ok && hs >= 0 && hs < a.H && ws >= 0 && ws < a.W;
-            return v ? (unsigned)(((n * a.H + hs) * a.W + ws) * 128 + hh * 16) : BUF_OOB;
-        };
-        auto load_tap = [&](int tap, uint4 (&f)[4]) {
-            const unsigned base = tap_off(tap);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
-        };
         f32x16 acc[2];
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nh][r] = 0.0f;
-        uint4 fa[3][4];
-        load_tap(0, fa[0]);
-        load_tap(1, fa[1]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 2 < 9) load_tap(tap + 2, fa[(tap + 2) % 3]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 af = __builtin_bit_cast(bf16x8, fa[tap % 3][kk]);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, fa[tap][kk]);
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&Bs[nh * 32 + l31][tap * 64 + kk * 16 + hh * 8]);
                     acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
                 }
             }
+            load_tap(pn, tap, fa[tap]);                          // refill with the same tap of the next strip
         }
         // ---- wave-private transposition and epilogue (as in gemm_stream.h) ------------------------------------------
 #pragma unroll
