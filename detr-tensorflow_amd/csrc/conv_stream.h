@@ -12,8 +12,10 @@
 //   forward : y[p][co] = relu(sum_{kh,kw,ci} x[p - 1 + (kh,kw)][ci] w[kh][kw][ci][co] + bias[co])
 //   dgrad   : dx[p][ci] = (mask[p][ci] > 0) * sum_{kh,kw,co} dy[p + 1 - (kh,kw)][co] w[kh][kw][ci][co]
 // Opt-in (DETR_HIP_CONV_STREAM=1): parity-tested (tests/test_gpu_kernels.py::test_conv3x3_stream64_opt_in) but measured at the
-// same speed as the tile kernel in the full step (22.80 vs 22.84 ms) -- one 8-wave workgroup per CU is
-// too little latency cover for 36 scattered requests per strip; kept as the starting point for the next round.
+// same speed as the tile kernel in the full step, both with three taps in flight (22.80 vs 22.84 ms) and with the rolling
+// one-strip-ahead prefetch below (22.77 vs 22.77 ms): two very different schedules landing on the same
+// time says the bound is shared -- the 9x redundant, 16-bytes-per-lane input reads through the texture path are the
+// suspect; the next step is counters (TA busy, L1 hit rate) and LDS-staged input rows.  Kept as the starting point.
 #pragma once
 #include "gemm_stream.h"
 
