@@ -117,20 +117,22 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
-    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
-    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
-    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+    const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ldv + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
 
     bf16x8 qb[2];                 // B operand of QK^T: Q[tq][16 s + 8 hi ..], in log2 units
     {
         BufSrc qsrc;
-        qsrc.init(Qb, (long long)(a.T - 1) * a.ld + 32);
+        qsrc.init(Qb, (long long)(a.T - 1) * a.ldq + 32);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float t[8];
-            ld_row8(qsrc, qok, (unsigned)(((long long)tq * a.ld + 16 * s + 8 * hi) * 4), t);
+            ld_row8(qsrc, qok, (unsigned)(((long long)tq * a.ldq + 16 * s + 8 * hi) * 4), t);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] *= AT_LOG2E;
+            for (int j = 0; j < 8; ++j) t[j] *= qmul;
             qb[s] = pack8(t);
         }
     }
@@ -144,24 +146,24 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
     // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
     BufSrc ksrc, vsrc;
-    ksrc.init(Kb, (long long)(a.S - 1) * a.ld + 32);
-    vsrc.init(Vb, (long long)(a.S - 1) * a.ld + 32);
-    const unsigned ldb = (unsigned)(a.ld * 4);
+    ksrc.init(Kb, (long long)(a.S - 1) * a.ldk + 32);
+    vsrc.init(Vb, (long long)(a.S - 1) * a.ldv + 32);
+    const unsigned ldbk = (unsigned)(a.ldk * 4), ldbv = (unsigned)(a.ldv * 4);
     TileB<NW> rk0, rv0, rk1, rv1;
-    rk0.loadb(ksrc, ldb, 0, a.S, tid);
-    rv0.loadb(vsrc, ldb, 0, a.S, tid);
+    rk0.loadb(ksrc, ldbk, 0, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 0, a.S, tid);
     rk0.store(Ks[0], tid);
     rv0.store(Vs[0], tid);
-    rk0.loadb(ksrc, ldb, AB_ROWS, a.S, tid);
-    rv0.loadb(vsrc, ldb, AB_ROWS, a.S, tid);
-    rk1.loadb(ksrc, ldb, 2 * AB_ROWS, a.S, tid);
-    rv1.loadb(vsrc, ldb, 2 * AB_ROWS, a.S, tid);
+    rk0.loadb(ksrc, ldbk, AB_ROWS, a.S, tid);
+    rv0.loadb(vsrc, ldbv, AB_ROWS, a.S, tid);
+    rk1.loadb(ksrc, ldbk, 2 * AB_ROWS, a.S, tid);
+    rv1.loadb(vsrc, ldbv, 2 * AB_ROWS, a.S, tid);
     lds_barrier();
     auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
         rpk.store(Ks[cur ^ 1], tid);
         rpv.store(Vs[cur ^ 1], tid);
-        rpk.loadb(ksrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
-        rpv.loadb(vsrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
+        rpk.loadb(ksrc, ldbk, (it + 3) * AB_ROWS, a.S, tid);
+        rpv.loadb(vsrc, ldbv, (it + 3) * AB_ROWS, a.S, tid);
 #pragma unroll 1
         for (int sub = 0; sub < AB_SUB; ++sub) {
         const int kbase = it * AB_ROWS + sub * AT_KEYS;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
         lsum = lsum * corr + rs;
         m = mn;
         if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
+            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
         }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     }
     if (qok) {
         const float inv = 1.0f / lsum;
-        float *Ob = a.O + ((long long)b * a.T + tq) * a.ld + h * 32;
+        float *Ob = a.O + ((long long)b * a.T + tq) * a.ldo + h * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
         if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);
@@ -235,28 +237,29 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
-    const long long qoff = ((long long)b * a.T + tq) * a.ld + h * 32;
-    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
-    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+    const long long qoff = ((long long)b * a.T + tq) * a.lddq + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ldv + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
 
     bf16x8 qb[2], dob[2];
     float dl = 0.0f;
     {
-        const long long hb = (long long)b * a.T * a.ld + h * 32, ext = (long long)(a.T - 1) * a.ld + 32;
         BufSrc qsrc, dosrc, osrc;
-        qsrc.init(a.Q + hb, ext);
-        dosrc.init(a.dO + hb, ext);
-        osrc.init(a.O + hb, ext);
+        qsrc.init(a.Q + (long long)b * a.T * a.ldq + h * 32, (long long)(a.T - 1) * a.ldq + 32);
+        dosrc.init(a.dO + (long long)b * a.T * a.lddo + h * 32, (long long)(a.T - 1) * a.lddo + 32);
+        osrc.init(a.O + (long long)b * a.T * a.ldo + h * 32, (long long)(a.T - 1) * a.ldo + 32);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float tqv[8], tdo[8], tov[8];
-            const unsigned off = (unsigned)(((long long)tq * a.ld + 16 * s + 8 * hi) * 4);
-            ld_row8(qsrc, qok, off, tqv);
-            ld_row8(dosrc, qok, off, tdo);
-            ld_row8(osrc, qok, off, tov);
+            const unsigned cb = (unsigned)(16 * s + 8 * hi) * 4u;
+            ld_row8(qsrc, qok, (unsigned)((long long)tq * a.ldq * 4) + cb, tqv);
+            ld_row8(dosrc, qok, (unsigned)((long long)tq * a.lddo * 4) + cb, tdo);
+            ld_row8(osrc, qok, (unsigned)((long long)tq * a.ldo * 4) + cb, tov);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                tqv[j] *= AT_LOG2E;
+                tqv[j] *= qmul;
                 dl += tdo[j] * tov[j];
             }
             qb[s] = pack8(tqv);
@@ -276,24 +279,24 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
     // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
     // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
     BufSrc ksrc, vsrc;
-    ksrc.init(Kb, (long long)(a.S - 1) * a.ld + 32);
-    vsrc.init(Vb, (long long)(a.S - 1) * a.ld + 32);
-    const unsigned ldb = (unsigned)(a.ld * 4);
+    ksrc.init(Kb, (long long)(a.S - 1) * a.ldk + 32);
+    vsrc.init(Vb, (long long)(a.S - 1) * a.ldv + 32);
+    const unsigned ldbk = (unsigned)(a.ldk * 4), ldbv = (unsigned)(a.ldv * 4);
     TileB<NW> rk0, rv0, rk1, rv1;
-    rk0.loadb(ksrc, ldb, 0, a.S, tid);
-    rv0.loadb(vsrc, ldb, 0, a.S, tid);
+    rk0.loadb(ksrc, ldbk, 0, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 0, a.S, tid);
     rk0.store(Ks[0], tid);
     rv0.store(Vs[0], tid);
-    rk0.loadb(ksrc, ldb, AB_ROWS, a.S, tid);
-    rv0.loadb(vsrc, ldb, AB_ROWS, a.S, tid);
-    rk1.loadb(ksrc, ldb, 2 * AB_ROWS, a.S, tid);
-    rv1.loadb(vsrc, ldb, 2 * AB_ROWS, a.S, tid);
+    rk0.loadb(ksrc, ldbk, AB_ROWS, a.S, tid);
+    rv0.loadb(vsrc, ldbv, AB_ROWS, a.S, tid);
+    rk1.loadb(ksrc, ldbk, 2 * AB_ROWS, a.S, tid);
+    rv1.loadb(vsrc, ldbv, 2 * AB_ROWS, a.S, tid);
     lds_barrier();
     auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
         rpk.store(Ks[cur ^ 1], tid);
         rpv.store(Vs[cur ^ 1], tid);
-        rpk.loadb(ksrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
-        rpv.loadb(vsrc, ldb, (it + 3) * AB_ROWS, a.S, tid);
+        rpk.loadb(ksrc, ldbk, (it + 3) * AB_ROWS, a.S, tid);
+        rpv.loadb(vsrc, ldbv, (it + 3) * AB_ROWS, a.S, tid);
 #pragma unroll 1
         for (int sub = 0; sub < AB_SUB; ++sub) {
         const int kbase = it * AB_ROWS + sub * AT_KEYS;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
         }
         float ds[16];
         if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
+            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = ((keep >> r) & 1u) ? dp[r] * a.drop_scale : 0.0f;
         }
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
     }
     if (qok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.dQ[qoff + krow(r, hi)] = dq[r];
+        for (int r = 0; r < 16; ++r) a.dQ[qoff + krow(r, hi)] = dq[r] * a.qscale;     // gradient w.r.t. the unscaled q
     }
 }
 
@@ -354,25 +357,26 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int sk = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool kok = sk < a.S;
-    const long long koff = ((long long)b * a.S + sk) * a.ld + h * 32;
-    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
-    const float *Db = a.dO + (long long)b * a.T * a.ld + h * 32;
+    const long long dkoff = ((long long)b * a.S + sk) * a.lddk + h * 32, dvoff = ((long long)b * a.S + sk) * a.lddv + h * 32;
+    const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
+    const float *Db = a.dO + (long long)b * a.T * a.lddo + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
     const float *lse = a.LSE + (long long)bh * a.T;
     const float *dlt = a.delta + (long long)bh * a.T;
     const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
     bf16x8 kb[2], vb[2];
     {
-        const long long hb = (long long)b * a.S * a.ld + h * 32, ext = (long long)(a.S - 1) * a.ld + 32;
         BufSrc ksrc, vsrc;
-        ksrc.init(a.K + hb, ext);
-        vsrc.init(a.V + hb, ext);
+        ksrc.init(a.K + (long long)b * a.S * a.ldk + h * 32, (long long)(a.S - 1) * a.ldk + 32);
+        vsrc.init(a.V + (long long)b * a.S * a.ldv + h * 32, (long long)(a.S - 1) * a.ldv + 32);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float tk[8], tv[8];
-            const unsigned off = (unsigned)(((long long)sk * a.ld + 16 * s + 8 * hi) * 4);
-            ld_row8(ksrc, kok, off, tk);
-            ld_row8(vsrc, kok, off, tv);
+            const unsigned cb = (unsigned)(16 * s + 8 * hi) * 4u;
+            ld_row8(ksrc, kok, (unsigned)((long long)sk * a.ldk * 4) + cb, tk);
+            ld_row8(vsrc, kok, (unsigned)((long long)sk * a.ldv * 4) + cb, tv);
             kb[s] = pack8(tk);
             vb[s] = pack8(tv);
         }
@@ -387,8 +391,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
     // (one-tile-deep staging here: the two-deep form of the forward / dQ kernels needs a second register set, which takes
     //  this kernel from 2 waves per SIMD to 1 -- measured +0.7 ms per step)
     TileB<NW> rq, rd;
-    rq.load(Qb, a.ld, 0, a.T, tid);
-    rd.load(Db, a.ld, 0, a.T, tid);
+    rq.load(Qb, a.ldq, 0, a.T, tid);
+    rd.load(Db, a.lddo, 0, a.T, tid);
     BufSrc lsrc, dlsrc;
     lsrc.init(lse, a.T);
     dlsrc.init(dlt, a.T);
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
         rl[j] = (t < AB_ROWS && t < a.T) ? lse[t] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
         rdl[j] = (t < AB_ROWS && t < a.T) ? dlt[t] : 0.0f;
     }
-    rq.store(Qs[0], tid, AT_LOG2E);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
+    rq.store(Qs[0], tid, qmul);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
     rd.store(Ds[0], tid);                // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
 #pragma unroll
     for (int j = 0; j < LPP; ++j)
@@ -410,8 +414,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
         const bool more = (it + 1) < ntiles;
         if (more) {
             const int t0 = (it + 1) * AB_ROWS;
-            rq.load(Qb, a.ld, t0, a.T, tid);
-            rd.load(Db, a.ld, t0, a.T, tid);
+            rq.load(Qb, a.ldq, t0, a.T, tid);
+            rd.load(Db, a.lddo, t0, a.T, tid);
             // raw values only: scaling / padding happens when the set is stored -- arithmetic on a just-requested value
             // would put a vmcnt wait (for this AND the older Q / dO requests) in front of this iteration's MFMAs
 #pragma unroll
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             uint32_t hown[8], hoth[8];
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
-                hown[r8] = drop_hash(a.drop_seed, pbase + (unsigned)(krow(r8, hi) + 16 * odd) * halfSp);
+                hown[r8] = drop_hash(dkey, pbase + (unsigned)(krow(r8, hi) + 16 * odd) * halfSp);
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
                 hoth[r8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[r8], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
         }
         }   // sub
         if (more) {
-            rq.store(Qs[cur ^ 1], tid, AT_LOG2E);
+            rq.store(Qs[cur ^ 1], tid, qmul);
             rd.store(Ds[cur ^ 1], tid);
 #pragma unroll
             for (int j = 0; j < LPP; ++j) {
@@ -501,50 +505,31 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
     if (kok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a.dK[koff + krow(r, hi)] = dk[r] * AT_LN2;
-            a.dV[koff + krow(r, hi)] = dv[r];
+            a.dK[dkoff + krow(r, hi)] = dk[r] * AT_LN2;      // (the staged Q carries qscale * log2 e)
+            a.dV[dvoff + krow(r, hi)] = dv[r];
         }
     }
 }
 
 }  // namespace detr
 
-using namespace detr;
+namespace detr {
 
-extern "C" int detr_hip_attention_fwd_bf16c(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
-                                            int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                            uint32_t dropout_seed, void *stream) {
-    if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
-    DETR_REQUIRE(o && lse, "attention fwd: null output");
-    AttnArgs a = {};
-    a.Q = q; a.K = k; a.V = v; a.O = o; a.LSE = lse;
-    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
-    if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
-    hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+int attn_fwd_bf16_launch(const AttnArgs &a, hipStream_t s) {
+    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention fwd (bf16 MFMA)");
     return 0;
 }
 
-extern "C" int detr_hip_attention_bwd_bf16c(const float *q, const float *k, const float *v, const float *o, const float *lse,
-                                            const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
-                                            int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                            uint32_t dropout_seed, void *stream) {
-    if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
-    DETR_REQUIRE(o && lse && d_o && dq && dk && dv && delta, "attention bwd: null operand");
-    DETR_REQUIRE(aligned16(d_o), "attention bwd: dO must be 16-byte aligned");
-    AttnArgs a = {};
-    a.Q = q; a.K = k; a.V = v; a.O = const_cast<float *>(o); a.LSE = const_cast<float *>(lse);
-    a.dO = d_o; a.dQ = dq; a.dK = dk; a.dV = dv; a.delta = delta;
-    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
-    if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
-    hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+int attn_bwd_bf16_launch(const AttnArgs &a, hipStream_t s) {
+    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq (bf16 MFMA)");
-    if (attn_waves(S, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, dim3((unsigned)cdiv(S, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, dim3((unsigned)cdiv(S, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (attn_waves(a.S, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, dim3((unsigned)cdiv(a.S, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, dim3((unsigned)cdiv(a.S, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dkv (bf16 MFMA)");
     return 0;
 }
+
+}  // namespace detr

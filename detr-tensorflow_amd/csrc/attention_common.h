@@ -17,9 +17,14 @@ struct AttnArgs {
     float *dQ, *dK, *dV;
     float *delta;                // [B*H, T] rowsum(dO * O)
     int B, H, T, S;
-    long long ld;
+    // row strides (floats) of the batch-first token matrices: every tensor has its own, so that Q / K / V (and their
+    // gradients) may be column blocks of one packed projection buffer ([rows, 768] self-attention, [rows, 12*256] for the
+    // layer-invariant decoder cross-attention K / V)
+    long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    float qscale;           // softmax(qscale * q.k): folded into the log2(e) factor Q is loaded with; dQ is returned w.r.t. the UNSCALED q
     float drop_scale;       // 1/(1-p) or 0
-    uint32_t drop_thresh, drop_seed;
+    uint32_t drop_thresh, drop_seed;      // drop_seed = dropout SITE id
+    const uint32_t *drop_step;            // per-step seed in device memory (may be null), see common.h drop_key
 };
 
 __device__ __forceinline__ int krow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -42,12 +47,39 @@ __device__ __forceinline__ uint32_t keep_bits16(uint32_t seed, unsigned long lon
 }
 
 
-static int attn_check_args(const float *q, const float *k, const float *v, int B, int H, int T, int S, long long ld) {
-    DETR_REQUIRE(q && k && v, "attention: null operand");
-    DETR_REQUIRE(B > 0 && H > 0 && T > 0 && S > 0, "attention: bad shape B=%d H=%d T=%d S=%d", B, H, T, S);
-    DETR_REQUIRE(ld >= (long long)H * 32 && ld % 4 == 0, "attention: row stride %lld must be >= heads*32 and a multiple of 4", ld);
-    DETR_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "attention: operands must be 16-byte aligned");
-    DETR_REQUIRE((long long)B * H <= 65535, "attention: B*H=%lld exceeds grid.y", (long long)B * H);
+static int attn_check_ld(long long ld, int H, const char *what) {
+    DETR_REQUIRE(ld >= (long long)H * 32 && ld % 4 == 0, "attention: row stride of %s (%lld) must be >= heads*32 and a multiple of 4", what, ld);
+    return 0;
+}
+
+// fills AttnArgs from the C-ABI descriptor; bwd = 1 also checks the gradient operands
+static int attn_from_desc(const detr_attn_desc *d, int bwd, AttnArgs &a) {
+    DETR_REQUIRE(d, "attention: null descriptor");
+    DETR_REQUIRE(d->q && d->k && d->v && d->o && d->lse, "attention: null operand");
+    DETR_REQUIRE(d->B > 0 && d->H > 0 && d->T > 0 && d->S > 0, "attention: bad shape B=%d H=%d T=%d S=%d", d->B, d->H, d->T, d->S);
+    if (attn_check_ld(d->ldq, d->H, "q") || attn_check_ld(d->ldk, d->H, "k") || attn_check_ld(d->ldv, d->H, "v") ||
+        attn_check_ld(d->ldo, d->H, "o")) return -1;
+    DETR_REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->v) && aligned16(d->o), "attention: operands must be 16-byte aligned");
+    DETR_REQUIRE((long long)d->B * d->H <= 65535, "attention: B*H=%lld exceeds grid.y", (long long)d->B * d->H);
+    DETR_REQUIRE(d->dropout_p >= 0.0f && d->dropout_p < 1.0f, "attention: dropout p=%f out of range", d->dropout_p);
+    DETR_REQUIRE(d->scale > 0.0f, "attention: scale must be positive (1 = q already scaled)");
+    a = AttnArgs{};
+    a.Q = d->q; a.K = d->k; a.V = d->v; a.O = d->o; a.LSE = d->lse;
+    a.B = d->B; a.H = d->H; a.T = d->T; a.S = d->S;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+    a.qscale = d->scale;
+    a.drop_scale = d->dropout_p > 0.0f ? 1.0f / (1.0f - d->dropout_p) : 0.0f;
+    a.drop_thresh = drop_thresh16(d->dropout_p);
+    a.drop_seed = d->dropout_site;
+    a.drop_step = d->dropout_step;
+    if (bwd) {
+        DETR_REQUIRE(d->d_o && d->dq && d->dk && d->dv && d->delta, "attention bwd: null operand");
+        if (attn_check_ld(d->ldd_o, d->H, "d_o") || attn_check_ld(d->lddq, d->H, "dq") || attn_check_ld(d->lddk, d->H, "dk") ||
+            attn_check_ld(d->lddv, d->H, "dv")) return -1;
+        DETR_REQUIRE(aligned16(d->d_o) && aligned16(d->dq) && aligned16(d->dk) && aligned16(d->dv), "attention bwd: gradients must be 16-byte aligned");
+        a.dO = d->d_o; a.dQ = d->dq; a.dK = d->dk; a.dV = d->dv; a.delta = d->delta;
+        a.lddo = d->ldd_o; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+    }
     return 0;
 }
 
@@ -59,12 +91,7 @@ static int attn_waves(int rows, int bh) {
     return ((long long)cdiv(rows, 128) * bh < 2048) ? 2 : 4;
 }
 
-static int attn_set_drop(AttnArgs &a, float p, uint32_t seed) {
-    DETR_REQUIRE(p >= 0.0f && p < 1.0f, "attention: dropout p=%f out of range", p);
-    a.drop_scale = p > 0.0f ? 1.0f / (1.0f - p) : 0.0f;
-    a.drop_thresh = drop_thresh16(p);
-    a.drop_seed = seed;
-    return 0;
-}
+int attn_fwd_bf16_launch(const AttnArgs &a, hipStream_t s);      // attention_bf16.hip
+int attn_bwd_bf16_launch(const AttnArgs &a, hipStream_t s);
 
 }  // namespace detr

@@ -80,14 +80,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
-    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
-    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
-    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+    const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ldv + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
 
     float q[16];
-    ld_row_stride2(Qb, (long long)(a.T - 1) * a.ld + 32, qok, (long long)tq * a.ld, hi, q);
+    ld_row_stride2(Qb, (long long)(a.T - 1) * a.ldq + 32, qok, (long long)tq * a.ldq, hi, q);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) q[s] *= AT_LOG2E;                                                      // scores in log2 units
+    for (int s = 0; s < 16; ++s) q[s] *= qmul;                                                          // scores in log2 units
 
     f32x16 o;
 #pragma unroll
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
     Tile<NW> rk, rv;
-    rk.load(Kb, a.ld, 0, a.S, tid);
-    rv.load(Vb, a.ld, 0, a.S, tid);
+    rk.load(Kb, a.ldk, 0, a.S, tid);
+    rv.load(Vb, a.ldv, 0, a.S, tid);
     rk.store(Ks[0], tid);
     rv.store(Vs[0], tid);
     __syncthreads();
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ldk, (it + 1) * AT_KEYS, a.S, tid);
+            rv.load(Vb, a.ldv, (it + 1) * AT_KEYS, a.S, tid);
         }
         f32x16 s;
 #pragma unroll
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         lsum = lsum * corr + rs;
         m = mn;
         if (a.drop_scale != 0.0f) {          // dropout on the attention probabilities (after normalisation == on p)
-            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
+            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
         }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     }
     if (qok) {
         const float inv = 1.0f / lsum;
-        float *Ob = a.O + ((long long)b * a.T + tq) * a.ld + h * 32;
+        float *Ob = a.O + ((long long)b * a.T + tq) * a.ldo + h * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
         if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);   // natural-log units
@@ -175,21 +177,22 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool qok = tq < a.T;
-    const long long qoff = ((long long)b * a.T + tq) * a.ld + h * 32;
-    const float *Kb = a.K + (long long)b * a.S * a.ld + h * 32;
-    const float *Vb = a.V + (long long)b * a.S * a.ld + h * 32;
+    const long long qoff = ((long long)b * a.T + tq) * a.lddq + h * 32;
+    const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
+    const float *Vb = a.V + (long long)b * a.S * a.ldv + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
 
     float q[16], dout[16];
     float dl = 0.0f;
     {
-        const long long hb = (long long)b * a.T * a.ld + h * 32, ext = (long long)(a.T - 1) * a.ld + 32;
         float ov[16];
-        ld_row_stride2(a.Q + hb, ext, qok, (long long)tq * a.ld, hi, q);
-        ld_row_stride2(a.dO + hb, ext, qok, (long long)tq * a.ld, hi, dout);
-        ld_row_stride2(a.O + hb, ext, qok, (long long)tq * a.ld, hi, ov);
+        ld_row_stride2(a.Q + (long long)b * a.T * a.ldq + h * 32, (long long)(a.T - 1) * a.ldq + 32, qok, (long long)tq * a.ldq, hi, q);
+        ld_row_stride2(a.dO + (long long)b * a.T * a.lddo + h * 32, (long long)(a.T - 1) * a.lddo + 32, qok, (long long)tq * a.lddo, hi, dout);
+        ld_row_stride2(a.O + (long long)b * a.T * a.ldo + h * 32, (long long)(a.T - 1) * a.ldo + 32, qok, (long long)tq * a.ldo, hi, ov);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            q[s] *= AT_LOG2E;                                       // scores in log2 units (q feeds only s)
+            q[s] *= qmul;                                           // scores in log2 units (q feeds only s)
             dl += dout[s] * ov[s];
         }
     }
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
     Tile<NW> rk, rv;
-    rk.load(Kb, a.ld, 0, a.S, tid);
-    rv.load(Vb, a.ld, 0, a.S, tid);
+    rk.load(Kb, a.ldk, 0, a.S, tid);
+    rv.load(Vb, a.ldv, 0, a.S, tid);
     rk.store(Ks[0], tid);
     rv.store(Vs[0], tid);
     __syncthreads();
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int it = 0; it < ntiles; ++it) {
         const bool more = (it + 1) < ntiles;
         if (more) {
-            rk.load(Kb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
-            rv.load(Vb, a.ld, (it + 1) * AT_KEYS, a.S, tid);
+            rk.load(Kb, a.ldk, (it + 1) * AT_KEYS, a.S, tid);
+            rv.load(Vb, a.ldv, (it + 1) * AT_KEYS, a.S, tid);
         }
         f32x16 s, dp;
 #pragma unroll
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         const int kbase = it * AT_KEYS;
         float ds[16];
         if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(a.drop_seed, rowbase, kbase, hi, a.drop_thresh);
+            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = ((keep >> r) & 1u) ? dp[r] * a.drop_scale : 0.0f;
         }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     if (qok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.dQ[qoff + krow(r, hi)] = dq[r];
+        for (int r = 0; r < 16; ++r) a.dQ[qoff + krow(r, hi)] = dq[r] * a.qscale;     // gradient w.r.t. the unscaled q
     }
 }
 
@@ -268,20 +271,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int sk = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool kok = sk < a.S;
-    const long long koff = ((long long)b * a.S + sk) * a.ld + h * 32;
-    const float *Qb = a.Q + (long long)b * a.T * a.ld + h * 32;
-    const float *Db = a.dO + (long long)b * a.T * a.ld + h * 32;
+    const long long dkoff = ((long long)b * a.S + sk) * a.lddk + h * 32, dvoff = ((long long)b * a.S + sk) * a.lddv + h * 32;
+    const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
+    const float *Db = a.dO + (long long)b * a.T * a.lddo + h * 32;
+    const float qmul = a.qscale * AT_LOG2E;
+    const uint32_t dkey = a.drop_scale != 0.0f ? drop_key(a.drop_seed, a.drop_step) : 0u;
     const float *lse = a.LSE + (long long)bh * a.T;
     const float *dlt = a.delta + (long long)bh * a.T;
     const unsigned long long Sp = (unsigned long long)((a.S + 1) & ~1);
 
     float kk[16], vv[16];
     {
-        const long long hb = (long long)b * a.S * a.ld + h * 32, ext = (long long)(a.S - 1) * a.ld + 32;
-        ld_row_stride2(a.K + hb, ext, kok, (long long)sk * a.ld, hi, kk);
-        ld_row_stride2(a.V + hb, ext, kok, (long long)sk * a.ld, hi, vv);
+        ld_row_stride2(a.K + (long long)b * a.S * a.ldk + h * 32, (long long)(a.S - 1) * a.ldk + 32, kok, (long long)sk * a.ldk, hi, kk);
+        ld_row_stride2(a.V + (long long)b * a.S * a.ldv + h * 32, (long long)(a.S - 1) * a.ldv + 32, kok, (long long)sk * a.ldv, hi, vv);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) kk[s] *= AT_LOG2E;            // scores in log2 units (kk feeds only s)
+        for (int s = 0; s < 16; ++s) kk[s] *= qmul;                // scores in log2 units (kk feeds only s)
     }
     f32x16 dk, dv;
 #pragma unroll
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
     Tile<NW> rq, rd;
-    rq.load(Qb, a.ld, 0, a.T, tid);
-    rd.load(Db, a.ld, 0, a.T, tid);
+    rq.load(Qb, a.ldq, 0, a.T, tid);
+    rd.load(Db, a.lddo, 0, a.T, tid);
     float rl = 0.f, rdl = 0.f;
     if (tid < AT_KEYS) {
         rl = (tid < a.T) ? lse[tid] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         const bool more = (it + 1) < ntiles;
         if (more) {
             const int t0 = (it + 1) * AT_KEYS;
-            rq.load(Qb, a.ld, t0, a.T, tid);
-            rd.load(Db, a.ld, t0, a.T, tid);
+            rq.load(Qb, a.ldq, t0, a.T, tid);
+            rd.load(Db, a.lddo, t0, a.T, tid);
             if (tid < AT_KEYS) {
                 rl = (t0 + tid < a.T) ? lse[t0 + tid] * AT_LOG2E : INFINITY;
                 rdl = (t0 + tid < a.T) ? dlt[t0 + tid] : 0.0f;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
             p[r] = fast_exp2(s[r] - Ls[cur][qr]);
             float dpr = dp[r];
             if (a.drop_scale != 0.0f) {
-                const bool keep = drop_keep(a.drop_seed, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * Sp + sk, a.drop_thresh);
+                const bool keep = drop_keep(dkey, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * Sp + sk, a.drop_thresh);
                 dpr = keep ? dpr * a.drop_scale : 0.0f;
                 ds[r] = p[r] * (dpr - Dl[cur][qr]);
                 p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
@@ -352,8 +356,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (kok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a.dK[koff + krow(r, hi)] = dk[r];
-            a.dV[koff + krow(r, hi)] = dv[r];
+            a.dK[dkoff + krow(r, hi)] = dk[r] * a.qscale;     // the staged Q is unscaled (K carries qscale * log2 e)
+            a.dV[dvoff + krow(r, hi)] = dv[r];
         }
     }
 }
@@ -362,40 +366,29 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 using namespace detr;
 
-extern "C" int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                          uint32_t dropout_seed, void *stream) {
-    if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
-    DETR_REQUIRE(o && lse, "attention fwd: null output");
-    AttnArgs a = {};
-    a.Q = q; a.K = k; a.V = v; a.O = o; a.LSE = lse;
-    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
-    if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
+/* one entry point per direction; detr_attn_desc.compute selects the exact-fp32 kernels above or the bf16-MFMA kernels of
+ * attention_bf16.hip */
+extern "C" int detr_hip_attention_fwd(const detr_attn_desc *d, void *stream) {
+    AttnArgs a;
+    if (attn_from_desc(d, 0, a)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (d->compute == 1) return attn_fwd_bf16_launch(a, s);
+    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention fwd");
     return 0;
 }
 
-extern "C" int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
-                                          const float *d_o, float *dq, float *dk, float *dv, float *delta, int32_t B,
-                                          int32_t H, int32_t T, int32_t S, int64_t ld, float dropout_p,
-                                          uint32_t dropout_seed, void *stream) {
-    if (attn_check_args(q, k, v, B, H, T, S, ld)) return -1;
-    DETR_REQUIRE(o && lse && d_o && dq && dk && dv && delta, "attention bwd: null operand");
-    DETR_REQUIRE(aligned16(d_o), "attention bwd: dO must be 16-byte aligned");
-    AttnArgs a = {};
-    a.Q = q; a.K = k; a.V = v; a.O = const_cast<float *>(o); a.LSE = const_cast<float *>(lse);
-    a.dO = d_o; a.dQ = dq; a.dK = dk; a.dV = dv; a.delta = delta;
-    a.B = B; a.H = H; a.T = T; a.S = S; a.ld = ld;
-    if (attn_set_drop(a, dropout_p, dropout_seed)) return -1;
+extern "C" int detr_hip_attention_bwd(const detr_attn_desc *d, void *stream) {
+    AttnArgs a;
+    if (attn_from_desc(d, 1, a)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (attn_waves(T, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3((unsigned)cdiv(T, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3((unsigned)cdiv(T, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (d->compute == 1) return attn_bwd_bf16_launch(a, s);
+    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq");
-    if (attn_waves(S, B * H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3((unsigned)cdiv(S, 64), (unsigned)(B * H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((unsigned)cdiv(S, 128), (unsigned)(B * H)), dim3(256), 0, s, a);
+    if (attn_waves(a.S, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3((unsigned)cdiv(a.S, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((unsigned)cdiv(a.S, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dkv");
     return 0;
 }

@@ -61,23 +61,39 @@ static inline int env_tile(const char *name) {
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// Counter-based dropout: element `idx` of dropout site `seed` is kept iff the top 24 bits of a 32-bit
-// integer hash are >= thresh16 = p * 2^16.  Forward and backward kernels regenerate the same mask from
-// (seed, idx); tests/oracle restate the same hash in numpy (Keras Dropout semantics: kept values are
+// Counter-based dropout: element `idx` of dropout site `site` in training step `*step` is kept iff 16 bits of a
+// keyed 32-bit integer hash are >= thresh16 = p * 2^16.  Forward and backward kernels regenerate the same mask from
+// (site, step seed, idx); tests/oracle restate the same hash in numpy (Keras Dropout semantics: kept values are
 // scaled by 1/(1-p); the reference's TF RNG stream itself is not reproducible).
+//   key  = mix32(step_seed + site * 0x9E3779B9)      -- step_seed is read from DEVICE memory (hipGraph replays of a
+//          captured training step see a new seed without re-capturing); the host mixes (base seed, step, DP rank) into it
+//   hash = two-round multiply-xorshift of the pair index with `key` injected before the first round and a second,
+//          key-derived word injected between the rounds: two sites / steps / ranks are NOT related by an XOR
+//          permutation of one random field (round-1 defect: mask_B(i) == mask_A(i ^ (A ^ B))).
 // One 32-bit hash serves the element PAIR (idx & ~1, idx | 1): the low / high 16 bits are compared with
 // thresh16 = p * 2^16 (p = 0.1 -> 6553/65536).  Kernels whose lanes own adjacent elements (attention
 // probabilities, float4 epilogues) therefore evaluate one hash per two elements.
-__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, unsigned long long pair) {
-    uint32_t x = (uint32_t)pair ^ seed;
-    x ^= (uint32_t)(pair >> 32) * 0x9E3779B9u;
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, unsigned long long idx, uint32_t thresh16) {
-    const uint32_t h = drop_hash(seed, idx >> 1);
+__host__ __device__ __forceinline__ uint32_t drop_key(uint32_t site, const uint32_t *step) {
+    return mix32((step ? *step : 0u) + site * 0x9E3779B9u);
+}
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t key, unsigned long long pair) {
+    const uint32_t key2 = key * 0x85EBCA6Bu + 0xC2B2AE35u;      // wave-uniform: scalar ALU
+    uint32_t x = (uint32_t)pair ^ key;
+    x ^= (uint32_t)(pair >> 32) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= key2;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t key, unsigned long long idx, uint32_t thresh16) {
+    const uint32_t h = drop_hash(key, idx >> 1);
     return ((idx & 1ull) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
 }
 static inline uint32_t drop_thresh16(float p) { return (uint32_t)(p * 65536.0f); }

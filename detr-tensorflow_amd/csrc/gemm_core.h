@@ -38,8 +38,8 @@ struct EpiArgs {
     int atomic;  // 1: atomicAdd into C (split-K / wgrad)
     int vec;     // 1: C / residual / mask rows and scale / bias are 16-byte aligned -> float4 epilogue
     float drop_scale;        // 1/(1-p), 0 = no dropout; element index = row * N + col
-    uint32_t drop_thresh;    // p * 2^24
-    uint32_t drop_seed;
+    uint32_t drop_thresh;    // p * 2^16
+    uint32_t drop_seed;      // dropout SITE id; the per-step seed is read from *drop_step (device memory, may be null = 0)
     // optional output-row remap (stride-2 conv dgrad, one launch per pixel-parity class): GEMM row r of the class
     // (n, h2, w2) addresses pixel (n, 2*h2 + remap_ph, 2*w2 + remap_pw) of the [.., remap_H, remap_W, N] tensors
     // C / residual / mask.  remap_w2 == 0: identity.
@@ -47,6 +47,7 @@ struct EpiArgs {
     // bf16 STORAGE of the activation tensors (backbone, DETR_HIP_ACT16): C / residual / mask are bf16 in memory (uint16,
     // leading dimensions in elements); the arithmetic of the epilogue stays fp32, the result is rounded once (RNE)
     int c16 = 0, r16 = 0, m16 = 0;
+    const uint32_t *drop_step = nullptr;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
@@ -330,6 +331,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
     const int l31 = lane & 31;
     const int rh = (lane >> 5) * 4;
     const int colbase = n0 + wn * T::WTN;
+    const uint32_t dkey = e.drop_scale != 0.0f ? drop_key(e.drop_seed, e.drop_step) : 0u;
 #pragma unroll
     for (int mi = 0; mi < T::TM; ++mi) {
         __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
@@ -371,12 +373,12 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                 bool k0 = true, k1 = true, k2 = true, k3 = true;
                 if (e.drop_scale != 0.0f) {
                     if ((di & 1ull) == 0) {      // two hashes serve the four elements (common.h: 16 bits per element)
-                        const uint32_t h0 = drop_hash(e.drop_seed, di >> 1), h1 = drop_hash(e.drop_seed, (di >> 1) + 1);
+                        const uint32_t h0 = drop_hash(dkey, di >> 1), h1 = drop_hash(dkey, (di >> 1) + 1);
                         k0 = (h0 & 0xFFFFu) >= e.drop_thresh; k1 = (h0 >> 16) >= e.drop_thresh;
                         k2 = (h1 & 0xFFFFu) >= e.drop_thresh; k3 = (h1 >> 16) >= e.drop_thresh;
                     } else {
-                        k0 = drop_keep(e.drop_seed, di, e.drop_thresh); k1 = drop_keep(e.drop_seed, di + 1, e.drop_thresh);
-                        k2 = drop_keep(e.drop_seed, di + 2, e.drop_thresh); k3 = drop_keep(e.drop_seed, di + 3, e.drop_thresh);
+                        k0 = drop_keep(dkey, di, e.drop_thresh); k1 = drop_keep(dkey, di + 1, e.drop_thresh);
+                        k2 = drop_keep(dkey, di + 2, e.drop_thresh); k3 = drop_keep(dkey, di + 3, e.drop_thresh);
                     }
                 }
                 o.x = epi_one(a.x, sc.x, bi.x, e, rs.x, mk.x, k0);
@@ -402,7 +404,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
                         const float bi = e.bias ? e.bias[col + j] : 0.0f;
                         const float rs = !e.residual ? 0.0f : (e.r16 ? ld_bf16x1(e.residual, prow * e.ldr + col + j) : e.residual[prow * e.ldr + col + j]);
                         const float mk = !e.mask ? 1.0f : (e.m16 ? ld_bf16x1(e.mask, prow * e.ldmask + col + j) : e.mask[prow * e.ldmask + col + j]);
-                        const bool kp = e.drop_scale == 0.0f || drop_keep(e.drop_seed, (unsigned long long)prow * N + col + j, e.drop_thresh);
+                        const bool kp = e.drop_scale == 0.0f || drop_keep(dkey, (unsigned long long)prow * N + col + j, e.drop_thresh);
                         const float o = epi_one(av[j], sc, bi, e, rs, mk, kp);
                         if (e.atomic) unsafeAtomicAdd(dst + j, o);
                         else if (e.c16) dst16[j] = (unsigned short)(f32_to_bf16_pair(o, 0.0f) & 0xFFFFu);

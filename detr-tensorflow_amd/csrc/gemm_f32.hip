@@ -495,6 +495,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
         g.e.drop_scale = 1.0f / (1.0f - d->dropout_p);
         g.e.drop_thresh = drop_thresh16(d->dropout_p);
         g.e.drop_seed = d->dropout_seed;
+        g.e.drop_step = d->dropout_step;
     }
     g.e.c16 = d->c_dtype == 1; g.e.r16 = d->r_dtype == 1; g.e.m16 = d->m_dtype == 1;
     g.e.vec = aligned16(d->C) && (d->ldc % 4 == 0) && (d->sC0 % 4 == 0) && (d->sC1 % 4 == 0) &&

@@ -15,7 +15,8 @@ constexpr int LN_MAXV = 4;
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float *__restrict__ y,
                                                             float *__restrict__ mean, float *__restrict__ rstd,
-                                                            int rows, int C, float eps) {
+                                                            int rows, int C, float eps, const float *__restrict__ add,
+                                                            int add_rows, float *__restrict__ y2) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nv = C >> 2;  // float4 per row
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
                 o.z = (v[i].z - mu) * rs * g.z + b.z;
                 o.w = (v[i].w - mu) * rs * g.w + b.w;
                 yr[j] = o;
+                if (y2) {        // the `+ pos` / `+ query_pos` operand of the next attention block, written while y is in registers
+                    const float4 p = reinterpret_cast<const float4 *>(add + (long long)(row % add_rows) * C)[j];
+                    reinterpret_cast<float4 *>(y2 + (long long)row * C)[j] = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+                }
             }
         }
         if (lane == 0) {
@@ -69,7 +74,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, float *__restrict__ dx,
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                            int rows, int C, float *__restrict__ partial) {
+                                                            int rows, int C, float *__restrict__ partial,
+                                                            const float *__restrict__ dx_add, float *__restrict__ dx_drop,
+                                                            float drop_scale, uint32_t drop_thresh, uint32_t drop_site,
+                                                            const uint32_t *__restrict__ drop_step) {
     __shared__ float red[2][4][64 * LN_MAXV * 4 / 4];  // [gamma|beta][wave][C] ; C <= 1024 -> see below
     // (partial sums are kept per lane in registers and reduced through LDS at the end)
     const int lane = threadIdx.x & 63;
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         pg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const uint32_t dkey = dx_drop ? drop_key(drop_site, drop_step) : 0u;
     for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
         const float4 *xr = reinterpret_cast<const float4 *>(x + (long long)row * C);
         const float4 *dr = reinterpret_cast<const float4 *>(dy + (long long)row * C);
@@ -117,7 +126,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                 o.y = rs * (g[i].y - m1 - xh[i].y * m2);
                 o.z = rs * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                if (dx_add) {    // a second gradient branch into the same tensor (e.g. the residual path of the next layer)
+                    const float4 e = reinterpret_cast<const float4 *>(dx_add + (long long)row * C)[j];
+                    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+                }
                 oxr[j] = o;
+                if (dx_drop) {   // gradient through the dropout that precedes the residual add (same mask as the forward GEMM epilogue)
+                    const unsigned long long di = (unsigned long long)row * C + 4 * j;      // even: two hashes serve the four elements
+                    const uint32_t h0 = drop_hash(dkey, di >> 1), h1 = drop_hash(dkey, (di >> 1) + 1);
+                    float4 d;
+                    d.x = (h0 & 0xFFFFu) >= drop_thresh ? o.x * drop_scale : 0.0f;
+                    d.y = (h0 >> 16) >= drop_thresh ? o.y * drop_scale : 0.0f;
+                    d.z = (h1 & 0xFFFFu) >= drop_thresh ? o.z * drop_scale : 0.0f;
+                    d.w = (h1 >> 16) >= drop_thresh ? o.w * drop_scale : 0.0f;
+                    reinterpret_cast<float4 *>(dx_drop + (long long)row * C)[j] = d;
+                }
             }
         }
     }
@@ -316,7 +339,8 @@ __global__ void sigmoid_bwd_kernel(const float *__restrict__ dy, const float *__
 }
 
 __global__ void dropout_kernel(const float *__restrict__ x, float *__restrict__ out, long long n, float scale,
-                               uint32_t thresh, uint32_t seed) {
+                               uint32_t thresh, uint32_t site, const uint32_t *__restrict__ step) {
+    const uint32_t seed = drop_key(site, step);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = drop_keep(seed, (unsigned long long)i, thresh) ? x[i] * scale : 0.0f;
 }
@@ -375,34 +399,41 @@ static inline int ew_grid(long long total, int block) {
 
 using namespace detr;
 
-extern "C" int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean,
-                                          float *rstd, int32_t rows, int32_t C, float eps, void *stream) {
-    DETR_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm fwd: null operand");
+extern "C" int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream) {
+    DETR_REQUIRE(d && d->x && d->gamma && d->beta && d->y && d->mean && d->rstd, "layernorm fwd: null operand");
+    const int C = d->C, rows = d->rows;
     DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm fwd: C=%d rows=%d unsupported", C, rows);
-    DETR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm fwd: alignment");
+    DETR_REQUIRE(aligned16(d->x) && aligned16(d->y) && aligned16(d->gamma) && aligned16(d->beta), "layernorm fwd: alignment");
+    if (d->y2) DETR_REQUIRE(d->add && d->add_rows > 0 && aligned16(d->add) && aligned16(d->y2), "layernorm fwd: y2 needs add / add_rows (16-byte aligned)");
     const int grid = min(cdiv(rows, 4), 4096);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
-                       rows, C, eps);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->x, d->gamma, d->beta, d->y, d->mean,
+                       d->rstd, rows, C, d->eps, d->add, d->add_rows, d->y2);
     DETR_LAUNCH_CHECK("layernorm fwd");
     return 0;
 }
 
-extern "C" int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
-                                          const float *rstd, float *dx, float *dgamma, float *dbeta, int32_t rows,
-                                          int32_t C, float *workspace, int64_t workspace_bytes, void *stream) {
-    DETR_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm bwd: null operand");
+extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream) {
+    DETR_REQUIRE(d && d->dy && d->x && d->gamma && d->mean && d->rstd && d->dx && d->dgamma && d->dbeta, "layernorm bwd: null operand");
+    const int C = d->C, rows = d->rows;
     DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm bwd: C=%d rows=%d unsupported", C, rows);
-    DETR_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma), "layernorm bwd: alignment");
+    DETR_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma), "layernorm bwd: alignment");
+    if (d->dx_add) DETR_REQUIRE(aligned16(d->dx_add), "layernorm bwd: dx_add alignment");
+    float drop_scale = 0.0f;
+    if (d->dx_drop) {
+        DETR_REQUIRE(aligned16(d->dx_drop) && d->dropout_p > 0.0f && d->dropout_p < 1.0f, "layernorm bwd: dx_drop needs 0 < p < 1 (16-byte aligned)");
+        drop_scale = 1.0f / (1.0f - d->dropout_p);
+    }
     const int grid = min(cdiv(rows, 8), 512);
     // with a workspace of grid*2*C floats the gamma / beta gradients are reduced deterministically (per-block partials +
     // a finish launch); without one they are accumulated with fp32 atomics
-    float *partial = (workspace && workspace_bytes >= (long long)grid * 2 * C * 4) ? workspace : nullptr;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C, partial);
+    float *partial = (d->workspace && d->workspace_bytes >= (long long)grid * 2 * C * 4) ? d->workspace : nullptr;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->gamma, d->mean, d->rstd,
+                       d->dx, d->dgamma, d->dbeta, rows, C, partial, d->dx_add, d->dx_drop, drop_scale, drop_thresh16(d->dropout_p),
+                       d->dropout_site, d->dropout_step);
     DETR_LAUNCH_CHECK("layernorm bwd");
     if (partial) {
         hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, grid,
-                           C, dgamma, dbeta);
+                           C, d->dgamma, d->dbeta);
         DETR_LAUNCH_CHECK("layernorm bwd finish");
     }
     return 0;
@@ -536,11 +567,51 @@ extern "C" int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *
     return 0;
 }
 
-extern "C" int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t seed, void *stream) {
+extern "C" int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t site, const uint32_t *step,
+                                    void *stream) {
     DETR_REQUIRE(x && out && n > 0 && p >= 0.0f && p < 1.0f, "dropout: bad args");
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n,
-                       1.0f / (1.0f - p), drop_thresh16(p), seed);
+                       1.0f / (1.0f - p), drop_thresh16(p), site, step);
     DETR_LAUNCH_CHECK("dropout");
+    return 0;
+}
+
+namespace detr {
+// n independent flat copies / accumulations described by a DEVICE table, one launch (blockIdx.y = entry): gathers the
+// per-layer decoder cross-attention K / V weights into one [12*256, 256] operand and scatters its gradient back.
+__global__ __launch_bounds__(256) void multi_copy_kernel(const detr_copy_entry *__restrict__ table) {
+    const detr_copy_entry e = table[blockIdx.y];
+    const uint4 *src = reinterpret_cast<const uint4 *>(e.src);
+    uint4 *dst = reinterpret_cast<uint4 *>(e.dst);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < e.n16; i += (long long)gridDim.x * blockDim.x) {
+        if (e.mode == 0) {
+            dst[i] = src[i];
+        } else {
+            const float4 a = reinterpret_cast<const float4 *>(src)[i];
+            float4 b = reinterpret_cast<float4 *>(dst)[i];
+            b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+            reinterpret_cast<float4 *>(dst)[i] = b;
+        }
+    }
+}
+__global__ void set_u32x8_kernel(uint32_t *dst, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5,
+                                 uint32_t v6, uint32_t v7) {
+    if (threadIdx.x == 0) { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4; dst[5] = v5; dst[6] = v6; dst[7] = v7; }
+}
+}  // namespace detr
+
+extern "C" int detr_hip_multi_copy(const detr_copy_entry *table, int32_t n, int32_t blocks_per_entry, void *stream) {
+    DETR_REQUIRE(table && n > 0 && n <= 65535 && blocks_per_entry > 0, "multi_copy: bad args");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks_per_entry, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table);
+    DETR_LAUNCH_CHECK("multi_copy");
+    return 0;
+}
+
+extern "C" int detr_hip_set_u32x8(uint32_t *dst, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5,
+                                  uint32_t v6, uint32_t v7, void *stream) {
+    DETR_REQUIRE(dst, "set_u32x8: null destination");
+    hipLaunchKernelGGL(set_u32x8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, v0, v1, v2, v3, v4, v5, v6, v7);
+    DETR_LAUNCH_CHECK("set_u32x8");
     return 0;
 }
 

@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void set_loss_sums_kernel(SetLossArgs a, const
                 acc[3] += 1.f;
             } else {
                 const int cls = (int)a.t_class[(long long)b * a.R + 1 + t];
-                const float ce = lse - row[cls];
+                // a label outside [0, C) (e.g. the wrong nb_class when finetuning): no out-of-bounds read; the loss turns
+                // NaN like tf.nn.sparse_softmax_cross_entropy_with_logits on the GPU (the CPU op raises)
+                const float ce = (cls >= 0 && cls < a.C) ? lse - row[cls] : NAN;
                 acc[0] += ce;
                 acc[1] += 1.0f;
                 acc[4] += 1.f;

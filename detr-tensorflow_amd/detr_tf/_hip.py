@@ -32,7 +32,28 @@ class GemmDesc(Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
                 ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32),
-                ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
+                ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32),
+                ("dropout_step", c_void_p)]
+
+
+class AttnDesc(Structure):
+    _fields_ = [("B", c_int32), ("H", c_int32), ("T", c_int32), ("S", c_int32),
+                ("q", c_void_p), ("ldq", c_int64), ("k", c_void_p), ("ldk", c_int64), ("v", c_void_p), ("ldv", c_int64),
+                ("o", c_void_p), ("ldo", c_int64), ("lse", c_void_p),
+                ("d_o", c_void_p), ("ldd_o", c_int64), ("dq", c_void_p), ("lddq", c_int64), ("dk", c_void_p), ("lddk", c_int64),
+                ("dv", c_void_p), ("lddv", c_int64), ("delta", c_void_p),
+                ("scale", c_float), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p),
+                ("compute", c_int32)]
+
+
+class LayerNormDesc(Structure):
+    _fields_ = [("rows", c_int32), ("C", c_int32), ("eps", c_float),
+                ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("add", c_void_p), ("add_rows", c_int32), ("y2", c_void_p),
+                ("dy", c_void_p), ("dx", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64),
+                ("dx_add", c_void_p),
+                ("dx_drop", c_void_p), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p)]
 
 
 class StemDesc(Structure):
@@ -82,17 +103,15 @@ _SIGNATURES = {
     "detr_hip_maxpool3x3s2_bwd_f32": [f32p, c_void_p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_subsample2_fwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_subsample2_bwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
-    "detr_hip_layernorm_fwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_float, c_void_p],
-    "detr_hip_layernorm_bwd_f32": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, f32p, c_int64, c_void_p],
+    "detr_hip_layernorm_fwd": [POINTER(LayerNormDesc), c_void_p],
+    "detr_hip_layernorm_bwd": [POINTER(LayerNormDesc), c_void_p],
     "detr_hip_softmax_rows_fwd_f32": [f32p, c_int64, c_int32, c_int64, c_void_p],
     "detr_hip_softmax_rows_bwd_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_void_p],
-    "detr_hip_attention_fwd_f32": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,
-                                   ctypes.c_uint32, c_void_p],
-    "detr_hip_attention_bwd_f32": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_float, ctypes.c_uint32, c_void_p],
-    "detr_hip_attention_fwd_bf16c": [f32p, f32p, f32p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int64, c_float,
-                                   ctypes.c_uint32, c_void_p],
-    "detr_hip_attention_bwd_bf16c": [f32p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_float, ctypes.c_uint32, c_void_p],
-    "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p],
+    "detr_hip_attention_fwd": [POINTER(AttnDesc), c_void_p],
+    "detr_hip_attention_bwd": [POINTER(AttnDesc), c_void_p],
+    "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p, c_void_p],
+    "detr_hip_multi_copy": [c_void_p, c_int32, c_int32, c_void_p],
+    "detr_hip_set_u32x8": [c_void_p] + [ctypes.c_uint32] * 8 + [c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],
     "detr_hip_add_f32": [f32p, f32p, f32p, c_int64, c_void_p],
@@ -225,7 +244,7 @@ def _f32(t, name="tensor"):
 def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
                residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0,
-               compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None):
+               dropout_step=None, compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None):
     """Fills a detr_gemm_desc; returns (desc, profiler info).  ws_slice = (index, count): this call's share of WORKSPACE."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -244,7 +263,8 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     d.residual, d.ldr = ptr(residual), ldr
     d.mask, d.ldmask = ptr(mask), ldmask
     d.act, d.split_k = act, split_k
-    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF        # dropout_seed = SITE id; the step seed lives on the device
+    d.dropout_step = ptr(dropout_step)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
     d.rowsum_a, d.rowsum_alpha = ptr(rowsum_a), rowsum_alpha
     ws = workspace if workspace is not None else WORKSPACE
@@ -313,14 +333,15 @@ def pick_split_k(M, N, K, max_split=1024):
     return int(max(1, min(want, max_split, cap)))
 
 
-def linear_fwd_call(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0):
+def linear_fwd_call(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0,
+                    dropout_step=None):
     """(args, kwargs) of the gemm() that computes out = act((x @ W^T + b) * alpha + residual); W is (out, in) like
     custom_layers.Linear.  The *_call forms exist so that independent Linear products can be issued with gemm_group()."""
     M, K = x2d.shape
     N = w_out_in.shape[0]
     return ((M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0)),
             dict(alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act,
-                 dropout_p=dropout_p, dropout_seed=dropout_seed))
+                 dropout_p=dropout_p, dropout_seed=dropout_seed, dropout_step=dropout_step))
 
 
 def linear_dgrad_call(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):
@@ -416,3 +437,70 @@ def call(name, *args):
 def zero_(t):
     call("detr_hip_memset_zero", t.data_ptr(), t.numel() * t.element_size())
     return t
+
+
+# ------------------------------------------------------------------------------------------
+# attention / LayerNorm descriptors
+# ------------------------------------------------------------------------------------------
+def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_site=0, dropout_step=None, compute=None,
+              d_o=None, dq=None, dk=None, dv=None, delta=None):
+    """Fused attention core (include/detr_hip.h detr_attn_desc).  q / k / v / o (and the gradients) are 2-D views
+    [rows, >= H*32] whose row stride is taken from the tensor, so they may be column blocks of a packed projection buffer.
+    Forward when d_o is None, otherwise the backward (dq / dk / dv / delta written)."""
+    d = AttnDesc()
+    d.B, d.H, d.T, d.S = B, H, T, S
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.stride(1) != 1 or t.dtype != torch.float32:
+            raise TypeError(f"attention: {name} must be fp32 with a unit column stride")
+        setattr(d, name, t.data_ptr())
+        setattr(d, "ld" + name, t.stride(0))
+    d.lse = lse.data_ptr()
+    d.scale, d.dropout_p, d.dropout_site, d.dropout_step = scale, dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
+    d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    if d_o is None:
+        _check(load().detr_hip_attention_fwd(byref(d), _stream()), "detr_hip_attention_fwd")
+        return
+    for name, ldn, t in (("d_o", "ldd_o", d_o), ("dq", "lddq", dq), ("dk", "lddk", dk), ("dv", "lddv", dv)):
+        if t.stride(1) != 1 or t.dtype != torch.float32:
+            raise TypeError(f"attention: {name} must be fp32 with a unit column stride")
+        setattr(d, name, t.data_ptr())
+        setattr(d, ldn, t.stride(0))
+    d.delta = delta.data_ptr()
+    _check(load().detr_hip_attention_bwd(byref(d), _stream()), "detr_hip_attention_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None):
+    d = LayerNormDesc()
+    d.rows, d.C, d.eps = x.shape[0], x.shape[1], eps
+    d.x, d.gamma, d.beta, d.y, d.mean, d.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    if y2 is not None:
+        d.add, d.add_rows, d.y2 = add.data_ptr(), add.shape[0], y2.data_ptr()
+    _check(load().detr_hip_layernorm_fwd(byref(d), _stream()), "detr_hip_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, dx_drop=None, dropout_p=0.0, dropout_site=0,
+                  dropout_step=None):
+    d = LayerNormDesc()
+    d.rows, d.C = x.shape[0], x.shape[1]
+    d.dy, d.x, d.gamma, d.mean, d.rstd = dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    d.dx, d.dgamma, d.dbeta = dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+    if WORKSPACE is not None:                                       # deterministic gamma / beta reduction
+        d.workspace, d.workspace_bytes = WORKSPACE.data_ptr(), WORKSPACE.numel() * 4
+    d.dx_add = ptr(dx_add)
+    if dx_drop is not None:
+        d.dx_drop, d.dropout_p, d.dropout_site, d.dropout_step = dx_drop.data_ptr(), dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
+    _check(load().detr_hip_layernorm_bwd(byref(d), _stream()), "detr_hip_layernorm_bwd")
+
+
+def copy_table(entries, device):
+    """Device table for detr_hip_multi_copy: entries = [(src tensor, dst tensor, mode)], equal byte sizes, multiples of 16."""
+    rows = []
+    for src, dst, mode in entries:
+        nb = src.numel() * src.element_size()
+        assert nb == dst.numel() * dst.element_size() and nb % 16 == 0 and src.is_contiguous() and dst.is_contiguous()
+        rows.append([src.data_ptr(), dst.data_ptr(), nb // 16, mode])      # (mode, reserved) share one int64 slot: little endian
+    return torch.tensor(rows, dtype=torch.int64).to(device)
+
+
+def multi_copy(table, blocks_per_entry=16):
+    call("detr_hip_multi_copy", table.data_ptr(), table.shape[0], blocks_per_entry)

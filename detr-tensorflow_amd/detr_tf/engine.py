@@ -35,8 +35,25 @@ IMPLICIT_STEM = os.environ.get("DETR_HIP_IMPLICIT_STEM", "1") != "0"
 # bf16 STORAGE of the backbone activations and their gradients in precision="bf16" (default on; DETR_HIP_ACT16=0 keeps
 # fp32 storage with bf16 MFMA operands only)
 ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
-# fused flash-style attention (default) vs the materialised GEMM + softmax + GEMM path (DETR_HIP_FUSED_ATTN=0)
-FUSED_ATTENTION = os.environ.get("DETR_HIP_FUSED_ATTN", "1") != "0"
+# bf16 STORAGE of the FFN hidden activation in precision="bf16" (bit-identical: it only feeds GEMM operands; DETR_HIP_H16=0 = fp32)
+H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
+
+
+def mix32(x):
+    """csrc/common.h::mix32."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def step_seed(base_seed, step_no, rank=0):
+    """uint32 seed of one training step: base seed, step counter and data-parallel rank, mixed on the host (the kernels
+    mix it once more with the dropout site id, csrc/common.h::drop_key)."""
+    return mix32(mix32((base_seed + 0x9E3779B9 * step_no) & 0xFFFFFFFF) ^ ((rank * 0x85EBCA6B) & 0xFFFFFFFF))
 
 
 def position_embedding_sine_host(H, W, num_pos_features=128, temperature=10000.0, eps=1e-6):
@@ -75,9 +92,14 @@ class DetrEngine:
         self.fold_bn()
         self.compute = 0                 # 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA, fp32 storage (config C3)
         self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
-        self.dropout_seed = 0x5EED       # base seed; advanced by the step counter
+        self.dropout_seed = 0x5EED       # base seed; mixed with the step counter and the data-parallel rank
+        self.dp_rank = 0                 # parallel.DataParallel sets it: every rank draws its own masks
         self._step_no = 0
         self._drop = (0.0, 0)
+        self._step_seed = 0
+        self._seed_dev = torch.zeros(8, dtype=torch.int32, device=self.device)   # [0] = uint32 seed of the current training step
+        self._cross = {}
+        self._graph_replay = False       # True while a captured step is being recorded / replayed (training.GraphedTrainStep)
 
     # Derived weight copies (BN-folded kernels, the bf16 shadow) are stamped with the weights version they were built
     # from; `engine.weights_dirty = True` (optimizers.py after every apply, load_params, fold_bn) bumps the version, so
@@ -96,6 +118,14 @@ class DetrEngine:
             return False
         self._built[key] = self._weights_version
         return True
+
+    def advance_dropout_step(self):
+        """Next training step: a new uint32 step seed (base seed, step counter, DP rank) is written to DEVICE memory; every
+        dropout site derives its key from it inside the kernels, so a captured hipGraph sees the new masks on replay."""
+        self._step_no += 1
+        self._step_seed = step_seed(self.dropout_seed, self._step_no, self.dp_rank)
+        hip.call("detr_hip_set_u32x8", self._seed_dev.data_ptr(), self._step_seed, 0, 0, 0, 0, 0, 0, 0)
+        return self._step_seed
 
     # ---- buffers ------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
@@ -190,133 +220,130 @@ class DetrEngine:
         hip.call("detr_hip_colsum_f32", x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], x2d.stride(0),
                  c_float(alpha))
 
-    def _ln_fwd(self, x, pfx, y, tag):
+    def _ln_fwd(self, x, pfx, y, tag, add=None, y2=None):
+        """LayerNormalization(eps 1e-5) transformer.py:151-152; optional fused y2 = y + add[r % rows(add)] -- the
+        `+ pos` / `+ query_pos` operand of the next attention block (transformer.py:161-163,209,219)."""
         rows = x.shape[0]
         mean = self.buf(f"{tag}:mean", (rows,))
         rstd = self.buf(f"{tag}:rstd", (rows,))
-        hip.call("detr_hip_layernorm_fwd_f32", x.data_ptr(), self.P.views[f"{pfx}/gamma"].data_ptr(),
-                 self.P.views[f"{pfx}/beta"].data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D,
-                 c_float(LN_EPS))
+        hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2)
 
-    def _ln_bwd(self, dy, x, pfx, dx, tag):
-        rows = x.shape[0]
-        hip.call("detr_hip_layernorm_bwd_f32", dy.data_ptr(), x.data_ptr(), self.P.views[f"{pfx}/gamma"].data_ptr(),
-                 self._bufs[f"{tag}:mean"].data_ptr(), self._bufs[f"{tag}:rstd"].data_ptr(), dx.data_ptr(),
-                 self.P.gviews[f"{pfx}/gamma"].data_ptr(), self.P.gviews[f"{pfx}/beta"].data_ptr(), rows, D,
-                 hip.WORKSPACE.data_ptr(), hip.WORKSPACE.numel() * 4)        # deterministic gamma / beta reduction
-
-    def _add(self, a, b, out):
-        hip.call("detr_hip_add_f32", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())
+    def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None):
+        """Backward of _ln_fwd w.r.t. x (+ dx_add).  drop_site: also return dropout_bwd(dx) -- the gradient through the
+        Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the same launch."""
+        dp, _ = self._drop
+        dx_drop = None
+        if drop_site is not None and dp > 0.0:
+            dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}", dx.shape)
+        hip.layernorm_bwd(dy, x, self.P.views[f"{pfx}/gamma"], self._bufs[f"{tag}:mean"], self._bufs[f"{tag}:rstd"], dx,
+                          self.P.gviews[f"{pfx}/gamma"], self.P.gviews[f"{pfx}/beta"], dx_add=dx_add, dx_drop=dx_drop,
+                          dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev)
+        return dx if dx_drop is None else dx_drop
 
     def _add_bcast(self, x, p, out):
         hip.call("detr_hip_add_bcast_f32", x.data_ptr(), p.data_ptr(), out.data_ptr(), x.numel(), p.numel())
 
     # ---- attention --------------------------------------------------------------------------------
-    def _mha_fwd(self, tag, pfx, q_in, k_in, v_in, B, T, S, out, residual, seed=0):
-        """MultiHeadAttention.call transformer.py:285-356 + the residual add of the caller.
-        q_in [B*T,256], k_in/v_in [B*S,256]; out = attn(q,k,v) @ Wo^T + bo + residual."""
+    # MultiHeadAttention.call transformer.py:285-356.  The three projections write column blocks of ONE packed buffer
+    # QKV [rows, 768] = [Q | K | V]; q and k share their input (src + pos / tgt + query_pos), so Q and K are ONE GEMM
+    # with N = 512 against rows 0..511 of in_proj_kernel.  The query scaling head_dim**-0.5 (:307) is folded into the
+    # attention kernels (detr_attn_desc.scale).  In the backward the packed dQKV buffer turns the three data gradients
+    # and the three residual-style adds into ONE GEMM with K = 768:  d_x = dQKV @ in_proj_kernel + d_residual.
+    def _self_attn_fwd(self, tag, pfx, qk_in, v_in, B, T, out, site):
         W, bias = self._w(f"{pfx}/in_proj_kernel"), self.P.views[f"{pfx}/in_proj_bias"]
-        Qb, Kb, Vb = self.buf(f"{tag}:Q", (B * T, D)), self.buf(f"{tag}:K", (B * S, D)), self.buf(f"{tag}:V", (B * S, D))
-        # the three projections are independent: ONE grouped launch (each alone fills only 1-2 workgroups per CU)
-        hip.gemm_group([hip.linear_fwd_call(q_in, W[0:D], bias[0:D], Qb, alpha=float(HD) ** -0.5),          # :297,:307
-                        hip.linear_fwd_call(k_in, W[D:2 * D], bias[D:2 * D], Kb),
-                        hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], Vb)])
-        BH = B * HEADS
+        QKV = self.buf(f"{tag}:QKV", (B * T, 3 * D))
+        hip.gemm_group([hip.linear_fwd_call(qk_in, W[0:2 * D], bias[0:2 * D], QKV[:, 0:2 * D]),        # :294-300
+                        hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], QKV[:, 2 * D:])])          # :302-304
         O = self.buf(f"{tag}:O", (B * T, D))
-        if FUSED_ATTENTION:
-            # fused flash-style core: the [T,S] probabilities never reach HBM (csrc/attention_f32.hip)
-            lse = self.buf(f"{tag}:lse", (BH, T))
-            dp, dbase = self._drop
-            hip.call("detr_hip_attention_fwd_bf16c" if hip.COMPUTE_BF16 else "detr_hip_attention_fwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(), lse.data_ptr(),
-                     B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)        # :317,:340,:341,:343
-        else:
-            Sp = (S + 3) // 4 * 4
-            Pm = self.buf(f"{tag}:P", (B * HEADS, T, Sp))
-            hip.gemm(T, S, HD, Qb, D, 1, Kb, D, 1, Pm, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD),
-                     sC=(HEADS * T * Sp, T * Sp))                                      # :317
-            hip.call("detr_hip_softmax_rows_fwd_f32", Pm.data_ptr(), BH * T, S, Sp)     # :340
-            hip.gemm(T, HD, S, Pm, Sp, 1, Vb, D, 0, O, D, batch=BH, batch_inner=HEADS, sA=(HEADS * T * Sp, T * Sp),
-                     sB=(S * D, HD), sC=(T * D, HD))                                   # :343-345
-        hip.linear_fwd(O, self._w(f"{pfx}/out_proj_kernel"), self.P.views[f"{pfx}/out_proj_bias"], out,
-                       residual=residual, dropout_p=self._drop[0], dropout_seed=self._drop[1] + seed + 1)   # :346-347 + :169
+        lse = self.buf(f"{tag}:lse", (B * HEADS, T))
+        dp, _ = self._drop
+        hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, lse, B, HEADS, T, T, scale=float(HD) ** -0.5,
+                      dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)                    # :307-345
+        hip.linear_fwd(O, self._w(f"{pfx}/out_proj_kernel"), self.P.views[f"{pfx}/out_proj_bias"], out, residual=v_in,
+                       dropout_p=dp, dropout_seed=site + 1, dropout_step=self._seed_dev)               # :346-347 + :169
 
-
-    def _mha_bwd(self, tag, pfx, d_out, q_in, k_in, v_in, B, T, S, dq_in, dk_in, dv_in, dk_accum=False, dv_accum=False,
-                 seed=0):
-        """Backward of _mha_fwd w.r.t. q_in, k_in, v_in and the MHA parameters.
-        d_out: gradient of the out-projection output.  dk_in/dv_in may be accumulated onto."""
-        V, G = self.P.views, self.P.gviews
+    def _self_attn_bwd(self, tag, pfx, d_out, d_res, qk_in, v_in, B, T, d_x, site, acc_qk=None):
+        """d_out: gradient of the out-projection output (dropout backward already applied), d_res: gradient of the
+        block output (residual path).  Writes d_x = gradient w.r.t. v_in, including the q / k branch when qk_in is
+        v_in + const (d_x = None: not needed).  acc_qk: buffer that ACCUMULATES the gradient of the q / k input alone
+        (the decoder's query_pos gradient)."""
+        G = self.P.gviews
         W, gW, gb = self._w(f"{pfx}/in_proj_kernel"), G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
-        Qb, Kb, Vb, O = (self._bufs[f"{tag}:{n}"] for n in ("Q", "K", "V", "O"))
-        BH = B * HEADS
-        dp, dbase = self._drop
-        if dp > 0.0:    # gradient through the dropout that follows the out-projection (same mask as the forward)
-            d_drop = self.buf("scratch:d_drop", d_out.shape)
-            hip.call("detr_hip_dropout_f32", d_out.data_ptr(), d_drop.data_ptr(), d_out.numel(), c_float(dp),
-                     (dbase + seed + 1) & 0xFFFFFFFF)
-            d_out = d_drop
-        # out projection (its weight gradient joins the grouped launch of the in-projection weight gradients below)
-        dO = self.buf("scratch:dO", (B * T, D))
+        QKV, O = self._bufs[f"{tag}:QKV"], self._bufs[f"{tag}:O"]
+        dO = self.buf(f"scratch:dO:{B * T}", (B * T, D))
         hip.linear_dgrad(d_out, self._w(f"{pfx}/out_proj_kernel"), dO)
-        # attention core
-        dQ, dK, dV = self.buf("scratch:dQ", (B * T, D)), self.buf("scratch:dK", (B * S, D)), self.buf("scratch:dV", (B * S, D))
-        if FUSED_ATTENTION:
-            delta = self.buf("scratch:attn_delta", (BH, T))
-            hip.call("detr_hip_attention_bwd_bf16c" if hip.COMPUTE_BF16 else "detr_hip_attention_bwd_f32", Qb.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), O.data_ptr(),
-                     self._bufs[f"{tag}:lse"].data_ptr(), dO.data_ptr(), dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(),
-                     delta.data_ptr(), B, HEADS, T, S, D, c_float(dp), (dbase + seed) & 0xFFFFFFFF)
-        else:
-            Pm = self._bufs[f"{tag}:P"]
-            Sp = Pm.shape[2]
-            dP = self.buf("scratch:dP", (BH, T, Sp))
-            sP = (HEADS * T * Sp, T * Sp)
-            hip.gemm(S, HD, T, Pm, Sp, 0, dO, D, 0, dV, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
-            hip.gemm(T, S, HD, dO, D, 1, Vb, D, 1, dP, Sp, batch=BH, batch_inner=HEADS, sA=(T * D, HD), sB=(S * D, HD), sC=sP)
-            hip.call("detr_hip_softmax_rows_bwd_f32", Pm.data_ptr(), dP.data_ptr(), BH * T, S, Sp)
-            hip.gemm(T, HD, S, dP, Sp, 1, Kb, D, 0, dQ, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(S * D, HD), sC=(T * D, HD))
-            hip.gemm(S, HD, T, dP, Sp, 0, Qb, D, 0, dK, D, batch=BH, batch_inner=HEADS, sA=sP, sB=(T * D, HD), sC=(S * D, HD))
-        # in projection: Q = (q_in Wq^T + bq) * alpha
-        alpha = float(HD) ** -0.5
-        # three weight gradients (bias gradients fused: row sums of dy^T) and three data gradients, one grouped launch each
+        dQKV = self.buf(f"scratch:dQKV:{B * T}", (B * T, 3 * D))
+        delta = self.buf(f"scratch:delta:{B * T}", (B * HEADS, T))
+        dp, _ = self._drop
+        hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, self._bufs[f"{tag}:lse"], B, HEADS, T, T,
+                      scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev,
+                      d_o=dO, dq=dQKV[:, 0:D], dk=dQKV[:, D:2 * D], dv=dQKV[:, 2 * D:], delta=delta)
+        # weight gradients (bias gradients fused: row sums of dy^T), one grouped launch
         hip.gemm_group([hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"]),
-                        hip.linear_wgrad_call(dQ, q_in, gW[0:D], alpha=alpha, bias_grad=gb[0:D]),
-                        hip.linear_wgrad_call(dK, k_in, gW[D:2 * D], bias_grad=gb[D:2 * D]),
-                        hip.linear_wgrad_call(dV, v_in, gW[2 * D:], bias_grad=gb[2 * D:])])
-        dcalls = [hip.linear_dgrad_call(dQ, W[0:D], dq_in, alpha=alpha),
-                  hip.linear_dgrad_call(dK, W[D:2 * D], dk_in, residual=dk_in if dk_accum else None),
-                  hip.linear_dgrad_call(dV, W[2 * D:], dv_in, residual=dv_in if dv_accum else None)]
-        outs = {dq_in.data_ptr(), dk_in.data_ptr(), dv_in.data_ptr()}
-        if len(outs) == 3 and not dk_accum and not dv_accum:
-            hip.gemm_group(dcalls)              # three distinct outputs: one grouped launch
-        else:                                   # cross-attention accumulates dK and dV into the same memory gradient: in order
-            for a, kw in dcalls:
-                hip.gemm(*a, **kw)
+                        hip.linear_wgrad_call(dQKV[:, 0:2 * D], qk_in, gW[0:2 * D], bias_grad=gb[0:2 * D]),
+                        hip.linear_wgrad_call(dQKV[:, 2 * D:], v_in, gW[2 * D:], bias_grad=gb[2 * D:])])
+        calls = []
+        if acc_qk is not None:
+            calls.append(hip.linear_dgrad_call(dQKV[:, 0:2 * D], W[0:2 * D], acc_qk, residual=acc_qk))
+        if d_x is not None:
+            calls.append(hip.linear_dgrad_call(dQKV, W, d_x, residual=d_res))
+        if len(calls) == 1:
+            hip.gemm(*calls[0][0], **calls[0][1])
+        elif calls:
+            hip.gemm_group(calls)
 
     def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0):
         V = self.P.views
-        dp, dbase = self._drop
-        h = self.buf(f"{tag}:h", (x.shape[0], FF))
+        dp, _ = self._drop
+        # the hidden activation feeds only GEMM operands (rounded to bf16 there anyway): bf16 STORAGE in bf16 compute
+        # mode is bit-identical and halves the traffic of the four GEMMs that touch it
+        h = self.buf(f"{tag}:h", (x.shape[0], FF), torch.bfloat16 if (self.compute == 1 and H16) else torch.float32)
         hip.linear_fwd(x, self._w(f"{pfx}/linear1/kernel"), V[f"{pfx}/linear1/bias"], h, act=1, dropout_p=dp,
-                       dropout_seed=dbase + seed)                                      # :172-174
+                       dropout_seed=seed, dropout_step=self._seed_dev)                 # :172-174
         hip.linear_fwd(h, self._w(f"{pfx}/linear2/kernel"), V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
-                       dropout_seed=dbase + seed + 1)                                  # :175-176
+                       dropout_seed=seed + 1, dropout_step=self._seed_dev)             # :175-176
 
-    def _ffn_bwd(self, tag, pfx, d_f, x, dx, seed=0):
-        """d_f: grad of (drop(linear2(drop(relu(linear1(x))))) + x); dx = full gradient w.r.t. x."""
-        V, G = self.P.views, self.P.gviews
+    def _ffn_bwd(self, tag, pfx, d_y, d_f, x, dx):
+        """d_f: grad of (drop(linear2(drop(relu(linear1(x))))) + x); d_y = dropout_bwd(d_f) (from the LayerNorm backward
+        launch); dx = full gradient w.r.t. x."""
+        G = self.P.gviews
         h = self._bufs[f"{tag}:h"]                 # post-ReLU, post-dropout hidden activation
-        dp, dbase = self._drop
-        d_y = d_f
-        if dp > 0.0:
-            d_y = self.buf("scratch:d_ffn_drop", d_f.shape)
-            hip.call("detr_hip_dropout_f32", d_f.data_ptr(), d_y.data_ptr(), d_f.numel(), c_float(dp),
-                     (dbase + seed + 1) & 0xFFFFFFFF)
-        dh = self.buf("scratch:dh", h.shape)
+        dp, _ = self._drop
+        dh = self.buf(f"scratch:dh:{h.shape[0]}", h.shape)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
         hip.linear_dgrad(d_y, self._w(f"{pfx}/linear2/kernel"), dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
         hip.gemm_group([hip.linear_wgrad_call(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"]),
                         hip.linear_wgrad_call(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])])
         hip.linear_dgrad(dh, self._w(f"{pfx}/linear1/kernel"), dx, residual=d_f)
+
+    # ---- layer-invariant decoder cross-attention K / V (transformer.py:221-223: memory is the same for every layer) ------
+    def _cross_tables(self):
+        """Wkv [2*nd*256, 256] = [Wk_0 .. Wk_nd-1 ; Wv_0 .. Wv_nd-1] (rows 256..767 of every multihead_attn in_proj_kernel) and
+        its bias: a derived weight copy like the BN-folded conv kernels, gathered by ONE multi-copy launch per weights
+        version; the gradient of the copy is scattered back by one more."""
+        nd = self.num_dec
+        key = ("cross", self.compute)
+        if key not in self._cross:
+            wdt = torch.bfloat16 if self.compute == 1 else torch.float32
+            Wkv = self.buf(f"cross:Wkv:{self.compute}", (2 * nd * D, D), wdt)
+            bkv = self.buf("cross:bkv", (2 * nd * D,))
+            gW = self.buf("cross:gWkv", (2 * nd * D, D))
+            gb = self.buf("cross:gbkv", (2 * nd * D,))
+            gather, scatter = [], []
+            src_views = self.P.views16 if self.compute == 1 else self.P.views
+            for i in range(nd):
+                pfx = f"transformer/decoder/layer_{i}/multihead_attn"
+                w, b = src_views[f"{pfx}/in_proj_kernel"], self.P.views[f"{pfx}/in_proj_bias"]
+                g, gbias = self.P.gviews[f"{pfx}/in_proj_kernel"], self.P.gviews[f"{pfx}/in_proj_bias"]
+                for part, row0 in ((0, i * D), (1, (nd + i) * D)):             # part 0 = K rows, 1 = V rows
+                    lo = (1 + part) * D
+                    gather.append((w[lo:lo + D], Wkv[row0:row0 + D], 0))
+                    gather.append((b[lo:lo + D], bkv[row0:row0 + D], 0))
+                    scatter.append((gW[row0:row0 + D], g[lo:lo + D], 1))
+                    scatter.append((gb[row0:row0 + D], gbias[lo:lo + D], 1))
+            self._cross[key] = dict(Wkv=Wkv, bkv=bkv, gW=gW, gb=gb, gather=hip.copy_table(gather, self.device),
+                                    scatter=hip.copy_table(scatter, self.device))
+        return self._cross[key]
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, images, training=False):
@@ -342,9 +369,9 @@ class DetrEngine:
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
         if training and self.dropout_p > 0.0:
-            assert FUSED_ATTENTION, "training-mode dropout is implemented in the fused attention path only"
-            self._step_no += 1
-            self._drop = (float(self.dropout_p), (self.dropout_seed + 7919 * self._step_no) & 0xFFFFFFFF)
+            if not self._graph_replay:          # a captured step is fed its seed by training.GraphedTrainStep before every replay
+                self.advance_dropout_step()
+            self._drop = (float(self.dropout_p), self._step_seed)
         else:
             self._drop = (0.0, 0)
         dp, dseed = self._drop
@@ -416,47 +443,70 @@ class DetrEngine:
         self.pos = pos
         # ---------------- encoder (transformer.py:157-179) ----------------
         x = src
+        qk = self.buf("enc0:qk", (B * L, D))
+        self._add_bcast(x, pos, qk)                              # src + pos (:161-163); later layers get it from LayerNorm 2
         for i in range(self.num_enc):
             pfx, tag = f"transformer/encoder/layer_{i}", f"enc{i}"
-            qk = self.buf(f"{tag}:qk", (B * L, D))
-            self._add_bcast(x, pos, qk)
             a = self.buf(f"{tag}:a", (B * L, D))
-            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, qk, x, B, L, L, a, residual=x, seed=16 * i)
+            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, x, B, L, a, site=16 * i)
             x1 = self.buf(f"{tag}:x1", (B * L, D))
             self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1")
             f = self.buf(f"{tag}:f", (B * L, D))
             self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2)
             x2 = self.buf(f"{tag}:x2", (B * L, D))
-            self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2")
+            # x2 + pos = the q / k input of the next layer, or `memory + pos` of the decoder (:219), in the same launch
+            qk = self.buf(f"enc{i + 1}:qk" if i + 1 < self.num_enc else "dec:mem_pos", (B * L, D))
+            self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2", add=pos, y2=qk)
             x = x2
-        memory = x
-        mem_pos = self.buf("dec:mem_pos", (B * L, D))
-        self._add_bcast(memory, pos, mem_pos)
+        memory, mem_pos = x, qk
+        if self.num_enc == 0:
+            mem_pos = qk                                          # = src + pos
         # ---------------- decoder (transformer.py:207-234, :104-133) ----------------
-        Q = self.Q
+        Q, nd = self.Q, self.num_dec
         qpos = V["query_embed/kernel"]
         tgt = self.buf("dec:tgt0", (B * Q, D))
         hip.zero_(tgt)                                           # transformer.py:45
-        hs = self.buf("dec:hs", (self.num_dec, B * Q, D))
-        for i in range(self.num_dec):
+        hs = self.buf("dec:hs", (nd, B * Q, D))
+        dp, _ = self._drop
+        # K / V projections of `memory` for ALL decoder layers at once: memory is layer-invariant (:221-223)
+        ct = self._cross_tables()
+        if self._stale(f"cross:{self.compute}"):
+            hip.multi_copy(ct["gather"])
+        KV = self.buf("dec:KV", (B * L, 2 * nd * D))
+        hip.gemm_group([hip.linear_fwd_call(mem_pos, ct["Wkv"][0:nd * D], ct["bkv"][0:nd * D], KV[:, 0:nd * D]),
+                        hip.linear_fwd_call(memory, ct["Wkv"][nd * D:], ct["bkv"][nd * D:], KV[:, nd * D:])])
+        qin = self.buf("dec0:qin", (B * Q, D))
+        self._add_bcast(tgt, qpos, qin)                          # tgt + query_pos (:209); later layers: from LayerNorm 3
+        for i in range(nd):
             pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
-            qin = self.buf(f"{tag}:qin", (B * Q, D))
-            self._add_bcast(tgt, qpos, qin)
-            a1 = self.buf(f"{tag}:a1", (B * Q, D))
             ds = 16 * (32 + i)
-            self._mha_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, qin, tgt, B, Q, Q, a1, residual=tgt, seed=ds)
+            a1 = self.buf(f"{tag}:a1", (B * Q, D))
+            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, tgt, B, Q, a1, site=ds)
             t1 = self.buf(f"{tag}:t1", (B * Q, D))
-            self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1")
             q2 = self.buf(f"{tag}:q2", (B * Q, D))
-            self._add_bcast(t1, qpos, q2)
+            self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1", add=qpos, y2=q2)          # q2 = t1 + query_pos (:219)
+            # cross attention: Q from this layer, K / V column blocks of the shared projection buffer
+            cp = f"{pfx}/multihead_attn"
+            Wc, bc = self._w(f"{cp}/in_proj_kernel"), V[f"{cp}/in_proj_bias"]
+            Qc = self.buf(f"{tag}:ca:Q", (B * Q, D))
+            hip.linear_fwd(q2, Wc[0:D], bc[0:D], Qc)
+            Oc = self.buf(f"{tag}:ca:O", (B * Q, D))
+            lse = self.buf(f"{tag}:ca:lse", (B * HEADS, Q))
+            hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, lse, B, HEADS, Q, L,
+                          scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev)
             a2 = self.buf(f"{tag}:a2", (B * Q, D))
-            self._mha_fwd(f"{tag}:ca", f"{pfx}/multihead_attn", q2, mem_pos, memory, B, Q, L, a2, residual=t1, seed=ds + 2)
+            hip.linear_fwd(Oc, self._w(f"{cp}/out_proj_kernel"), V[f"{cp}/out_proj_bias"], a2, residual=t1, dropout_p=dp,
+                           dropout_seed=ds + 3, dropout_step=self._seed_dev)              # :226
             t2 = self.buf(f"{tag}:t2", (B * Q, D))
             self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2")
             f = self.buf(f"{tag}:f", (B * Q, D))
             self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4)
             t3 = self.buf(f"{tag}:t3", (B * Q, D))
-            self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
+            if i + 1 < nd:
+                qin = self.buf(f"dec{i + 1}:qin", (B * Q, D))
+                self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3", add=qpos, y2=qin)
+            else:
+                self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
             self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
             tgt = t3
         # ---------------- heads (detr.py:181-204 / :94-114) ----------------
@@ -532,48 +582,66 @@ class DetrEngine:
         hip.COMPUTE_BF16 = self.compute
         # ---------------- decoder ----------------
         feat, Hf, Wf, L = self._feat_meta
+        nd = self.num_dec
         memory = self._bufs[f"enc{self.num_enc - 1}:x2"] if self.num_enc > 0 else self._bufs["enc:src0"]
-        mem_pos = self._bufs["dec:mem_pos"]
+        mem_pos = self._bufs["dec:mem_pos"] if self.num_enc > 0 else self._bufs["enc0:qk"]
+        KV = self._bufs["dec:KV"]
+        ct = self._cross_tables()
         qpos, g_qpos = V["query_embed/kernel"], G["query_embed/kernel"]
-        d_mem = self.buf("scratch:d_mem", (B * L, D))
-        hip.zero_(d_mem)
-        d_next = None                       # gradient flowing into t3 of layer i from layer i+1
         BQ = B * Q
-        for i in reversed(range(self.num_dec)):
+        dp, _ = self._drop
+        dKV = self.buf("scratch:dKV", (B * L, 2 * nd * D))           # every column block is written by its layer's attention backward
+        acc_qpos = self.buf("scratch:acc_qpos", (BQ, D))             # sum over layers / sites of d(tgt + query_pos): query_pos gradient
+        hip.zero_(acc_qpos)
+        d_next = None                       # gradient flowing into t3 of layer i from layer i+1
+        for i in reversed(range(nd)):
             pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
+            cp = f"{pfx}/multihead_attn"
             t1, t2, t3 = self._bufs[f"{tag}:t1"], self._bufs[f"{tag}:t2"], self._bufs[f"{tag}:t3"]
             a1, a2, f = self._bufs[f"{tag}:a1"], self._bufs[f"{tag}:a2"], self._bufs[f"{tag}:f"]
             qin, q2 = self._bufs[f"{tag}:qin"], self._bufs[f"{tag}:q2"]
             tgt = self._bufs[f"dec{i - 1}:t3"] if i > 0 else self._bufs["dec:tgt0"]
-            d_t3 = self.buf("scratch:d_t3", (BQ, D))
-            self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf")
-            if d_next is not None:
-                self._add(d_t3, d_next, d_t3)
-            d_f = self.buf("scratch:d_f", (BQ, D))
-            self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3")
             ds = 16 * (32 + i)
+            d_t3 = self.buf("scratch:d_t3", (BQ, D))
+            self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf", dx_add=d_next)
+            d_f = self.buf("scratch:d_f", (BQ, D))
+            d_y = self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5)
             d_t2 = self.buf("scratch:d_t2", (BQ, D))
-            self._ffn_bwd(tag, pfx, d_f, t2, d_t2, seed=ds + 4)
+            self._ffn_bwd(tag, pfx, d_y, d_f, t2, d_t2)
             d_a2 = self.buf("scratch:d_a2", (BQ, D))
-            self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2")
-            d_q2 = self.buf("scratch:d_q2", (BQ, D))
-            self._mha_bwd(f"{tag}:ca", f"{pfx}/multihead_attn", d_a2, q2, mem_pos, memory, B, Q, L, d_q2, d_mem, d_mem,
-                          dk_accum=True, dv_accum=True, seed=ds + 2)
-            self._colsum(d_q2.view(B, Q * D), g_qpos.view(Q * D))          # d query_pos (sum over the batch)
+            d_out = self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2", drop_site=ds + 3)
+            # ---- cross attention
+            Wc = self._w(f"{cp}/in_proj_kernel")
+            Qc, Oc = self._bufs[f"{tag}:ca:Q"], self._bufs[f"{tag}:ca:O"]
+            dO = self.buf(f"scratch:dO:{BQ}", (BQ, D))
+            hip.linear_dgrad(d_out, self._w(f"{cp}/out_proj_kernel"), dO)
+            dQc = self.buf("scratch:dQc", (BQ, D))
+            delta = self.buf(f"scratch:delta:{BQ}", (B * HEADS, Q))
+            hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, self._bufs[f"{tag}:ca:lse"],
+                          B, HEADS, Q, L, scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev,
+                          d_o=dO, dq=dQc, dk=dKV[:, i * D:(i + 1) * D], dv=dKV[:, (nd + i) * D:(nd + i + 1) * D], delta=delta)
+            hip.gemm_group([hip.linear_wgrad_call(d_out, Oc, G[f"{cp}/out_proj_kernel"], bias_grad=G[f"{cp}/out_proj_bias"]),
+                            hip.linear_wgrad_call(dQc, q2, G[f"{cp}/in_proj_kernel"][0:D], bias_grad=G[f"{cp}/in_proj_bias"][0:D])])
             d_t1 = self.buf("scratch:d_t1", (BQ, D))
-            self._add(d_q2, d_a2, d_t1)                                    # q2 = t1 + qpos ; a2 = ... + t1
+            # q2 = t1 + query_pos ; a2 = attn + t1: the q gradient goes to t1 (with the residual path) and to the query_pos sum
+            hip.gemm_group([hip.linear_dgrad_call(dQc, Wc[0:D], acc_qpos, residual=acc_qpos),
+                            hip.linear_dgrad_call(dQc, Wc[0:D], d_t1, residual=d_a2)])
             d_a1 = self.buf("scratch:d_a1", (BQ, D))
-            self._ln_bwd(d_t1, a1, f"{pfx}/norm1", d_a1, f"{tag}:ln1")
-            d_qin = self.buf("scratch:d_qin", (BQ, D))
-            d_kin = self.buf("scratch:d_kin", (BQ, D))
-            d_vin = self.buf("scratch:d_vin", (BQ, D))
-            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a1, qin, qin, tgt, B, Q, Q, d_qin, d_kin, d_vin, seed=ds)
-            self._add(d_qin, d_kin, d_qin)                                 # q and k share qin = tgt + qpos
-            self._colsum(d_qin.view(B, Q * D), g_qpos.view(Q * D))
-            d_tgt = self.buf(f"scratch:d_tgt{i & 1}", (BQ, D))
-            self._add(d_qin, d_vin, d_tgt)
-            self._add(d_tgt, d_a1, d_tgt)                                  # residual a1 = attn + tgt
+            d_out = self._ln_bwd(d_t1, a1, f"{pfx}/norm1", d_a1, f"{tag}:ln1", drop_site=ds + 1)
+            # ---- self attention: qin = tgt + query_pos feeds q and k, tgt feeds v and the residual
+            d_tgt = self.buf(f"scratch:d_tgt{i & 1}", (BQ, D)) if i > 0 else None      # layer 0: tgt is the constant zero target
+            self._self_attn_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_out, d_a1, qin, tgt, B, Q, d_tgt, site=ds, acc_qk=acc_qpos)
             d_next = d_tgt
+        self._colsum(acc_qpos.view(B, Q * D), g_qpos.view(Q * D))      # d query_pos (sum over the batch)
+        # ---- K / V projections of all layers: weight gradient of the gathered copy (scattered back into the per-layer
+        #      in_proj gradients by one launch) and ONE data gradient GEMM with K = 2*nd*256
+        hip.zero_(ct["gW"])
+        hip.zero_(ct["gb"])
+        hip.gemm_group([hip.linear_wgrad_call(dKV[:, 0:nd * D], mem_pos, ct["gW"][0:nd * D], bias_grad=ct["gb"][0:nd * D]),
+                        hip.linear_wgrad_call(dKV[:, nd * D:], memory, ct["gW"][nd * D:], bias_grad=ct["gb"][nd * D:])])
+        hip.multi_copy(ct["scatter"])
+        d_mem = self.buf("scratch:d_mem", (B * L, D))
+        hip.linear_dgrad(dKV, ct["Wkv"], d_mem)        # d(memory + pos) through K and d(memory) through V land on the same tensor
         # ---------------- encoder ----------------
         d_x = d_mem
         for i in reversed(range(self.num_enc)):
@@ -581,19 +649,13 @@ class DetrEngine:
             x_in = self._bufs[f"enc{i - 1}:x2"] if i > 0 else self._bufs["enc:src0"]
             qk, a, x1, f = (self._bufs[f"{tag}:{n}"] for n in ("qk", "a", "x1", "f"))
             d_f = self.buf("scratch:e_d_f", (B * L, D))
-            self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2")
+            d_y = self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2", drop_site=16 * i + 3)
             d_x1 = self.buf("scratch:e_d_x1", (B * L, D))
-            self._ffn_bwd(tag, pfx, d_f, x1, d_x1, seed=16 * i + 2)
+            self._ffn_bwd(tag, pfx, d_y, d_f, x1, d_x1)
             d_a = self.buf("scratch:e_d_a", (B * L, D))
-            self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1")
-            d_q = self.buf("scratch:e_d_q", (B * L, D))
-            d_k = self.buf("scratch:e_d_k", (B * L, D))
-            d_v = self.buf("scratch:e_d_v", (B * L, D))
-            self._mha_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_a, qk, qk, x_in, B, L, L, d_q, d_k, d_v, seed=16 * i)
+            d_out = self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1", drop_site=16 * i + 1)
             d_xn = self.buf(f"scratch:e_d_x{i & 1}", (B * L, D))
-            self._add(d_q, d_k, d_xn)
-            self._add(d_xn, d_v, d_xn)
-            self._add(d_xn, d_a, d_xn)
+            self._self_attn_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_out, d_a, qk, x_in, B, L, d_xn, site=16 * i)
             d_x = d_xn
         if on_bucket:
             on_bucket(0)

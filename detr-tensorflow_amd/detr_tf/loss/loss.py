@@ -101,6 +101,11 @@ def get_losses(m_outputs, t_bbox, t_class, config):
     hook = getattr(m_outputs, "reduce_sums", None)
     sl.reduce_sums = hook
     total, losses = sl.forward(lg, bx, tb, tc, config.background_class)
+    if getattr(config, "check_matching", False):
+        # opt-in (it synchronises): the reference's SciPy call raises ValueError on NaN / inf / infeasible cost matrices
+        # (hungarian_matching.py:29); the device matcher records a status per problem instead of stopping the step
+        if bool((sl.matcher.status != 0).any()):
+            raise ValueError("cost matrix is infeasible or contains invalid numeric entries")
     vals = losses.clone()
     log = {}
     order = [Lv - 1] + list(range(Lv - 1))                   # main first, then aux 0..n-1 (loss.py:23-30)

@@ -74,13 +74,17 @@ class DetrModel:
         for l in self.layers:
             print(f"  {l.name:28s} {sum(v.numel() for v in l.trainable_variables):>12,}")
 
+    @staticmethod
+    def _npz(path):
+        return path if path.endswith(".npz") else path + ".npz"      # np.savez appends the suffix: keep save / load symmetric
+
     def load_weights(self, path_or_dict):
-        missing = self.engine.P.load(path_or_dict) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
+        missing = self.engine.P.load(self._npz(path_or_dict)) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
         self.engine.fold_bn()
         return missing
 
     def save_weights(self, path):
-        self.engine.P.save(path)
+        self.engine.P.save(self._npz(path))
 
     # ---- forward ----------------------------------------------------------------------------
     def __call__(self, images, training=False):
@@ -89,7 +93,13 @@ class DetrModel:
         images = images.to(device=self.device, dtype=torch.float32)
         logits, boxes = self.engine.forward(images, training=training)
         if self.headless:
-            return self.engine._bufs["dec:hs"].view(self.engine.num_dec, images.shape[0], self.engine.Q, 256)
+            hs = self.engine._bufs["dec:hs"].view(self.engine.num_dec, images.shape[0], self.engine.Q, 256)
+            return hs if training else hs.clone()
+        if not training:
+            # inference outputs are often kept across calls (predictions accumulated for mAP, train vs val outputs): hand out
+            # fresh tensors like Keras does.  Training outputs stay views of the engine's buffers (consumed by get_losses
+            # before the next forward; no allocation in the step).
+            logits, boxes = logits.clone(), boxes.clone()
         out = DetrOutputs()
         out["pred_logits"], out["pred_boxes"] = logits[-1], boxes[-1]
         out["aux"] = [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(logits.shape[0] - 1)]
@@ -112,9 +122,10 @@ def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_ba
                       num_encoder_layers=num_encoder_layers, num_queries=num_queries, backbone=backbone, device=device,
                       seed=seed, dropout=dropout, precision=precision)
     if weights is not None:
-        if isinstance(weights, str) and not weights.endswith(".npz"):
-            raise NotImplementedError(f'weights="{weights}": the reference downloads a TF checkpoint (weights.py:5-11); '
-                                      "pass the path of an .npz keyed by the reference layer names instead")
+        if isinstance(weights, str) and weights == "detr":
+            raise NotImplementedError('weights="detr": the reference downloads a TF checkpoint from GCS (weights.py:5-11); convert the '
+                                      "original PyTorch detr-r50 state-dict with detr_tf.networks.weights.convert_state_dict() (or "
+                                      "`python -m detr_tf.networks.weights in.pth out.npz`) and pass the .npz path instead")
         model.load_weights(weights)
     if include_top is False and nb_class is not None:
         config.add_nlayers([_Layer("cls_layer", None), _Layer("pos_layer", None)])      # detr.py:103

@@ -19,8 +19,9 @@ class GroupAdam:
     """tf.keras.optimizers.Adam(learning_rate=<callable>, clipnorm=...) for one variable group
     (optimizers.py:86-88): beta1 .9, beta2 .999, epsilon 1e-7, bias-corrected step size."""
 
-    def __init__(self, store, group_id, lr_getter, clipnorm, nlayers):
+    def __init__(self, store, group_id, lr_getter, clipnorm, nlayers, engine=None):
         self.store, self.group_id, self.lr_getter, self.clipnorm = store, group_id, lr_getter, clipnorm
+        self.engine = engine          # its derived weight copies (BN-folded kernels, bf16 shadow) go stale with every apply
         self.iterations = 0
         self.beta_1, self.beta_2, self.epsilon = 0.9, 0.999, 1e-7
         dev = store.device
@@ -44,16 +45,25 @@ class GroupAdam:
     def learning_rate(self):
         return float(self.lr_getter())
 
-    def apply_gradients(self, grad_flat):
-        """One Keras Adam step on this group's tensors using the flat gradient buffer."""
+    def set_step_hyper(self):
+        """Advances the Adam step counter and writes this step's hyper-parameters (bias-corrected step size, clipnorm,
+        betas, epsilon) to DEVICE memory.  Separate from the kernels that consume them, so that a captured training
+        step (training.GraphedTrainStep) can be replayed with fresh values."""
         self.iterations += 1
-        if self.n_chunks == 0:
-            return
         t = self.iterations
         lr_t = self.learning_rate() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         clip = self.clipnorm if self.clipnorm is not None else 0.0
         hip.call("detr_hip_set_floats8_f32", self.hyper.data_ptr(), lr_t, lr_t, lr_t, clip, self.beta_1, self.beta_2,
                  self.epsilon, 0.0)
+
+    def apply_gradients(self, grad_flat, hyper_ready=False):
+        """One Keras Adam step on this group's tensors using the flat gradient buffer."""
+        if not hyper_ready:
+            self.set_step_hyper()
+        if self.engine is not None:
+            self.engine.weights_dirty = True
+        if self.n_chunks == 0:
+            return
         hip.zero_(self.sumsq)
         hip.call("detr_hip_sumsq_segments_f32", grad_flat.data_ptr(), self.chunk_tensor.data_ptr(),
                  self.chunk_start.data_ptr(), self.seg_end.data_ptr(), self.n_chunks, CHUNK, self.sumsq.data_ptr())
@@ -67,12 +77,13 @@ def setup_optimizers(model, config):
     store = model.engine.P
     out = {}
     for gid, name in enumerate(GROUPS):
-        lr_cell = getattr(config, f"{name}_lr")
-        getter = (lambda c=lr_cell: float(c))
-        opt = GroupAdam(store, gid, getter, config.gradient_norm_clipping, config.nlayers)
+        # resolved at every step: `config.backbone_lr = 1e-4` (rebinding) works like `.assign(1e-4)` on the cell
+        getter = (lambda n=name: float(getattr(config, f"{n}_lr")))
+        opt = GroupAdam(store, gid, getter, config.gradient_norm_clipping, config.nlayers, engine=model.engine)
         out[f"{name}_optimizer"] = opt
         out[f"{name}_variables"] = [store.views[n] for n in opt.names]
     out["_store"] = store
+    out["_engine"] = model.engine
     return out
 
 

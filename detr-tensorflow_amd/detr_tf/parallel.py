@@ -43,7 +43,9 @@ def shard_batch(global_batch, rank, world):
 
 
 class DataParallel:
-    def __init__(self, grad_flat, bucket_bounds, group=None):
+    def __init__(self, grad_flat, bucket_bounds, group=None, engine=None):
+        if engine is not None and dist.is_initialized():
+            engine.dp_rank = dist.get_rank(group)      # every rank draws its own dropout masks (whole-batch semantics)
         self.grad = grad_flat
         self.bounds = list(bucket_bounds)
         self.group = group

@@ -10,7 +10,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch.Tensor storage); nothing is
  *     allocated, freed or synchronised inside; every call only enqueues work on `stream`
- *     (a hipStream_t passed as void*) and is safe to capture in a hipGraph;
+ *     (a hipStream_t passed as void*) and is safe to capture in a hipGraph; whatever changes from one
+ *     training step to the next (dropout step seed, Adam step sizes) is read from DEVICE memory, so a
+ *     captured step can be replayed;
  *   - all arithmetic is fp32 ("f32" in the names); indices are int32 on the device;
  *   - return value: 0 = ok, negative = rejected (bad shape / alignment / launch failure); the
  *     reason is retrievable with detr_hip_last_error() (thread-local);
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 1
+#define DETR_HIP_ABI_VERSION 2
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -68,9 +70,11 @@ typedef struct {
      * 16-byte stores and a second launch reduces them onto C (C += alpha*scale*sum); otherwise
      * the partials are accumulated with fp32 atomics. */
     float *workspace; int64_t workspace_bytes;
-    /* fused dropout (training mode, transformer.py:169,174-176): keep-mask = counter hash of
-     * (dropout_seed, row*N + col), kept values scaled by 1/(1-p); applied before the residual add when a
-     * residual is given, otherwise after the activation.  0 = off. */
+    /* fused dropout (training mode, transformer.py:169,174-176): keep-mask = keyed counter hash of
+     * (site = dropout_seed, step seed = *dropout_step, element row*N + col), kept values scaled by 1/(1-p); applied
+     * before the residual add when a residual is given, otherwise after the activation.  0 = off.
+     * dropout_step (last field of this struct) is a DEVICE pointer to the uint32 seed of the current training step
+     * (NULL = 0): a hipGraph replay of a captured step reads a fresh seed. */
     float dropout_p; uint32_t dropout_seed;
     /* 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA with fp32 storage / accumulation (BASELINE config C3:
      * operands are rounded to bf16 on their way into LDS) */
@@ -88,6 +92,7 @@ typedef struct {
      * tensor is bf16 in memory (uint16, RNE; leading dimensions in elements), 0 = fp32.  The epilogue arithmetic stays
      * fp32 and the result is rounded once.  Not with split_k / batch (partial slabs and gradients of parameters stay fp32). */
     int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask */
+    const uint32_t *dropout_step;                   /* see dropout_p */
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 /* n independent GEMMs in one call.  Consecutive members (up to 4) that share one kernel variant -- 64x64 tiles, same operand
@@ -200,13 +205,28 @@ int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H
  *   column sums (bias gradients), broadcast add (src + pos :161-163, tgt + query_pos :209),
  *   sigmoid backward (detr.py:188).
  * ------------------------------------------------------------------------------------------- */
-int detr_hip_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, float *y,
-                               float *mean, float *rstd, int32_t rows, int32_t C, float eps, void *stream);
-/* dgamma/dbeta are ACCUMULATED: deterministically (per-block partials in `workspace` + a finish launch) when the
- * workspace holds at least 512*2*C floats, with fp32 atomics otherwise (workspace may be NULL) */
-int detr_hip_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
-                               const float *rstd, float *dx, float *dgamma, float *dbeta,
-                               int32_t rows, int32_t C, float *workspace, int64_t workspace_bytes, void *stream);
+typedef struct {
+    int32_t rows, C; float eps;
+    const float *x;                 /* fwd: input rows; bwd: the forward INPUT (xhat is recomputed from mean / rstd) */
+    const float *gamma, *beta;
+    float *y;                       /* fwd output */
+    float *mean, *rstd;             /* [rows]: written by fwd, read by bwd */
+    /* fwd, optional fused second output  y2[r] = y[r] + add[r % add_rows]  -- the `src + pos` / `tgt + query_pos`
+     * operand of the NEXT attention block (transformer.py:161-163,209,219), written while y is still in registers */
+    const float *add; int32_t add_rows; float *y2;
+    /* bwd */
+    const float *dy; float *dx; float *dgamma, *dbeta;     /* dgamma / dbeta are ACCUMULATED */
+    /* dgamma/dbeta reduction: deterministic (per-block partials in `workspace` + a finish launch) when the workspace
+     * holds at least 512*2*C floats, fp32 atomics otherwise (workspace may be NULL) */
+    float *workspace; int64_t workspace_bytes;
+    const float *dx_add;            /* optional: dx += dx_add (a second gradient branch into the same tensor) */
+    /* optional fused second output dx_drop[i] = keep(site, step, i) ? dx[i] / (1-p) : 0 -- the gradient through the
+     * Dropout that precedes the residual add in front of this LayerNorm (transformer.py:169,176,215,226,232), i.e. the
+     * mask of the forward GEMM epilogue regenerated on the gradient (element index row*C + col) */
+    float *dx_drop; float dropout_p; uint32_t dropout_site; const uint32_t *dropout_step;
+} detr_layernorm_desc;
+int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream);
+int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);
 int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream);
 /* ds = p * (dp - sum(dp*p)), written over dp */
 int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,
@@ -221,8 +241,22 @@ int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n
 int detr_hip_add_f32(const float *a, const float *b, float *out, int64_t n, void *stream);
 /* dz[i] = dy[i] * y[i] * (1 - y[i]) */
 int detr_hip_sigmoid_bwd_f32(const float *dy, const float *y, float *dz, int64_t n, void *stream);
-/* out[i] = keep(seed, i) ? x[i] / (1-p) : 0   -- the dropout mask of detr_gemm_desc regenerated on a gradient */
-int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t seed, void *stream);
+/* out[i] = keep(site, *step, i) ? x[i] / (1-p) : 0   -- the dropout mask of detr_gemm_desc regenerated on a gradient */
+int detr_hip_dropout_f32(const float *x, float *out, int64_t n, float p, uint32_t site, const uint32_t *step, void *stream);
+/* n independent flat copies (mode 0: 16-byte units, any element type) or fp32 accumulations dst += src (mode 1) in ONE launch;
+ * `table` is DEVICE memory.  Gathers the per-layer decoder cross-attention K / V projection weights (transformer.py:221-223,
+ * the memory operand is layer-invariant) into one [layers*256, 256] GEMM operand and scatters its gradient back. */
+typedef struct detr_copy_entry {
+    const void *src;
+    void *dst;
+    int64_t n16;        /* number of 16-byte units */
+    int32_t mode;       /* 0 copy, 1 fp32 accumulate */
+    int32_t reserved;
+} detr_copy_entry;
+int detr_hip_multi_copy(const detr_copy_entry *table, int32_t n, int32_t blocks_per_entry, void *stream);
+/* dst[0..7] = v0..v7 (uint32; the values travel as kernel arguments): the per-step dropout seed */
+int detr_hip_set_u32x8(uint32_t *dst, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5,
+                       uint32_t v6, uint32_t v7, void *stream);
 /* out[i] = (ref[i] > 0) ? g[i] : 0 */
 int detr_hip_relu_mask_f32(const float *g, const float *ref, float *out, int64_t n, void *stream);
 /* w_out[k, co] = w[k, co] * scale[co]   (frozen-BN scale folded into conv kernels, HWIO flat) */
@@ -237,29 +271,38 @@ int detr_hip_bn_fold_f32(const float *weight, const float *bias, const float *me
 
 /* ---------------------------------------------------------------------------------------------
  * Fused multi-head attention core, head_dim 32 (detr_tf/networks/transformer.py:308-345):
- *   o[b,t,h*32:+32] = softmax_s( q[b,t,h] . k[b,s,h] ) v[b,s,h]      (q already scaled, :307)
- * on batch-first token matrices with row stride `ld` floats; the [T,S] probability tensor is never
+ *   o[b,t,h*32:+32] = softmax_s( q[b,t,h] . k[b,s,h] ) v[b,s,h]      (scale = head_dim**-0.5, :307)
+ * on batch-first token matrices; the [T,S] probability tensor is never
  * written to memory.  lse [B*H, T] (log-sum-exp per score row) is saved for the backward, which
  * recomputes the probabilities; delta [B*H, T] is scratch (rowsum(dO*O)).
  * ------------------------------------------------------------------------------------------- */
-int detr_hip_attention_fwd_f32(const float *q, const float *k, const float *v, float *o, float *lse,
-                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
-                               float dropout_p, uint32_t dropout_seed, void *stream);
-int detr_hip_attention_bwd_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
-                               const float *d_o, float *dq, float *dk, float *dv, float *delta,
-                               int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
-                               float dropout_p, uint32_t dropout_seed, void *stream);
-/* attention-probability dropout (transformer.py:341): element index ((b*H + h)*T + t)*Sp + s of `dropout_seed`,
- * Sp = S rounded up to even (one counter hash per pair of adjacent keys, common.h) */
-/* The same two entry points with bf16 MFMA operands (precision="bf16", BASELINE config C3): Q, K, V, P, dO and dS are
- * rounded to bf16, accumulation / softmax statistics / LSE / delta / outputs stay fp32 (csrc/attention_bf16.hip). */
-int detr_hip_attention_fwd_bf16c(const float *q, const float *k, const float *v, float *o, float *lse,
-                                 int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
-                                 float dropout_p, uint32_t dropout_seed, void *stream);
-int detr_hip_attention_bwd_bf16c(const float *q, const float *k, const float *v, const float *o, const float *lse,
-                                 const float *d_o, float *dq, float *dk, float *dv, float *delta,
-                                 int32_t B, int32_t H, int32_t T, int32_t S, int64_t ld,
-                                 float dropout_p, uint32_t dropout_seed, void *stream);
+typedef struct {
+    int32_t B, H, T, S;
+    /* batch-first token matrices; every tensor has its OWN row stride (floats), so q / k / v (and their gradients) may
+     * be column blocks of one packed projection buffer: [rows, 768] for self-attention, [rows, layers*256] for the
+     * layer-invariant decoder cross-attention K / V of all layers */
+    const float *q; int64_t ldq;
+    const float *k; int64_t ldk;
+    const float *v; int64_t ldv;
+    float *o; int64_t ldo;          /* fwd: output; bwd: the forward output */
+    float *lse;                     /* [B*H, T] */
+    const float *d_o; int64_t ldd_o;
+    float *dq; int64_t lddq;
+    float *dk; int64_t lddk;
+    float *dv; int64_t lddv;
+    float *delta;                   /* [B*H, T] scratch */
+    /* softmax(scale * q.k): the reference scales the projected query (WQ *= head_dim**-0.5, transformer.py:307); here
+     * the factor is folded into the constant q is loaded with, and dq is the gradient w.r.t. the UNSCALED q */
+    float scale;
+    /* attention-probability dropout (transformer.py:341): element index ((b*H + h)*T + t)*Sp + s, Sp = S rounded up to
+     * even (one keyed counter hash per pair of adjacent keys, csrc/common.h); site / step as in detr_gemm_desc */
+    float dropout_p; uint32_t dropout_site; const uint32_t *dropout_step;
+    /* 0 = exact fp32 MFMA; 1 = bf16 MFMA operands (Q, K, V, P, dO, dS rounded to bf16; accumulation, softmax
+     * statistics, LSE, delta and outputs fp32; csrc/attention_bf16.hip) */
+    int32_t compute;
+} detr_attn_desc;
+int detr_hip_attention_fwd(const detr_attn_desc *d, void *stream);
+int detr_hip_attention_bwd(const detr_attn_desc *d, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,

@@ -204,17 +204,16 @@ def test_fused_attention_fwd_bwd(hip, B, T, S):
     do = torch.randn(B, T, D, dtype=torch.float64)
     o.backward(do)
     lse_ref = torch.logsumexp(qh @ kh.transpose(-1, -2), dim=-1)
-    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
-    od = torch.full((B, T, D), 7.0, device=DEV)
+    qd, kd, vd, dod = (t.view(-1, D) for t in (g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())))
+    od = torch.full((B * T, D), 7.0, device=DEV)
     lse = torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
-             T, S, D, ctypes.c_float(0.0), 0)
-    close(od, o, rtol=2e-5, what="attention fwd")
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=0)
+    close(od.view(B, T, D), o, rtol=2e-5, what="attention fwd")
     close(lse.view(B, H, T), lse_ref, rtol=1e-5, what="attention lse")
-    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    dq, dk, dv = (torch.zeros_like(t).view(B, -1, D) for t in (qd, kd, vd))
     delta = torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
-             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(0.0), 0)
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=0, d_o=dod, dq=dq.view(-1, D), dk=dk.view(-1, D), dv=dv.view(-1, D),
+                  delta=delta)
     close(dq, q.grad, rtol=5e-5, what="attention dq")
     close(dk, k.grad, rtol=5e-5, what="attention dk")
     close(dv, v.grad, rtol=5e-5, what="attention dv")
@@ -237,21 +236,20 @@ def test_fused_attention_bf16_mfma(hip, B, T, S, p):
     sc = qh @ kh.transpose(-1, -2)
     w = torch.softmax(sc, dim=-1)
     if p > 0.0:
-        keep = torch.from_numpy(DR.keep_mask(seed, DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
+        keep = torch.from_numpy(DR.keep_mask(DR.drop_key(seed, 0), DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
         w = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
     o = (w @ vh).transpose(1, 2).reshape(B, T, D)
     do = torch.randn(B, T, D, dtype=torch.float64)
     o.backward(do)
-    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
-    od, lse = torch.full((B, T, D), 7.0, device=DEV), torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_fwd_bf16c", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
-             T, S, D, ctypes.c_float(p), seed)
-    close(od, o, rtol=1.5e-2, what="bf16 attention fwd")
+    qd, kd, vd, dod = (t.view(-1, D) for t in (g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())))
+    od, lse = torch.full((B * T, D), 7.0, device=DEV), torch.zeros(B * H, T, device=DEV)
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=1, dropout_p=p, dropout_site=seed)
+    close(od.view(B, T, D), o, rtol=1.5e-2, what="bf16 attention fwd")
     close(lse.view(B, H, T), torch.logsumexp(sc, dim=-1), rtol=3e-3, what="bf16 attention lse")
-    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    dq, dk, dv = (torch.zeros_like(t).view(B, -1, D) for t in (qd, kd, vd))
     delta = torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_bwd_bf16c", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
-             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(p), seed)
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=1, dropout_p=p, dropout_site=seed, d_o=dod, dq=dq.view(-1, D),
+                  dk=dk.view(-1, D), dv=dv.view(-1, D), delta=delta)
     close(dq, q.grad, rtol=2e-2, what="bf16 attention dq")
     close(dk, k.grad, rtol=2e-2, what="bf16 attention dk")
     close(dv, v.grad, rtol=2e-2, what="bf16 attention dv")
@@ -408,23 +406,24 @@ def test_layernorm_fwd_bwd(hip, rows, C):
     xd, gd, bd = g(x.detach().float()), g(gam.detach().float()), g(bet.detach().float())
     yd = torch.zeros(rows, C, device=DEV)
     mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
-    hip.call("detr_hip_layernorm_fwd_f32", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mean.data_ptr(),
-             rstd.data_ptr(), rows, C, ctypes.c_float(1e-5))
+    hip.layernorm_fwd(xd, gd, bd, yd, mean, rstd, 1e-5)
     close(yd, y, rtol=1e-5, what="layernorm fwd")
     dxd = torch.zeros(rows, C, device=DEV)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dyd = g(dy.float())
-    hip.call("detr_hip_layernorm_bwd_f32", dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
-             rstd.data_ptr(), dxd.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, None, 0)      # atomic fallback
+    ws_keep, hip.WORKSPACE = hip.WORKSPACE, None
+    try:
+        hip.layernorm_bwd(dyd, xd, gd, mean, rstd, dxd, dg, db)                     # no workspace: atomic fallback
+    finally:
+        hip.WORKSPACE = ws_keep
     close(dxd, x.grad, rtol=2e-5, what="layernorm dx")
     close(dg, gam.grad, rtol=5e-5, what="layernorm dgamma")
     close(db, bet.grad, rtol=5e-5, what="layernorm dbeta")
-    ws = torch.empty(512 * 2 * C, device=DEV)                                     # deterministic workspace path
+    hip.ensure_workspace(DEV)                                                     # deterministic workspace path
     res = []
     for rep in range(2):
         dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-        hip.call("detr_hip_layernorm_bwd_f32", dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), mean.data_ptr(),
-                 rstd.data_ptr(), dxd.data_ptr(), dg2.data_ptr(), db2.data_ptr(), rows, C, ws.data_ptr(), ws.numel() * 4)
+        hip.layernorm_bwd(dyd, xd, gd, mean, rstd, dxd, dg2, db2)
         res.append((dg2, db2))
     close(res[0][0], gam.grad, rtol=5e-5, what="layernorm dgamma (workspace)")
     close(res[0][1], bet.grad, rtol=5e-5, what="layernorm dbeta (workspace)")
@@ -677,51 +676,110 @@ def test_dropout_gemm_epilogue_and_elementwise(hip):
     M, N, K, p, seed = 333, 256, 64, 0.1, 0xABCDE
     x, W, b, R = torch.randn(M, K), torch.randn(N, K), torch.randn(N), torch.randn(M, N)
     xd, Wd, bd, Rd = g(x), g(W), g(b), g(R)
-    keep = torch.from_numpy(DR.keep_mask(seed, np.arange(M * N).reshape(M, N), p))
+    step = 0x1234567
+    stepd = torch.tensor([step] + [0] * 7, dtype=torch.int32, device=DEV)         # the per-step seed lives in device memory
+    keep = torch.from_numpy(DR.keep_mask(DR.drop_key(seed, step), np.arange(M * N).reshape(M, N), p))
     assert 0.88 < float(keep.float().mean()) < 0.92
+    keep0 = torch.from_numpy(DR.keep_mask(DR.drop_key(seed, 0), np.arange(M * N).reshape(M, N), p))
+    assert abs(float((keep ^ keep0).float().mean()) - 0.18) < 0.02                 # another step: an unrelated mask
     scale = 1.0 / (1.0 - p)
     lin = x.double() @ W.double().t() + b.double()
     # with a residual: x + drop(f(x))
     y = torch.zeros(M, N, device=DEV)
-    hip.linear_fwd(xd, Wd, bd, y, residual=Rd, dropout_p=p, dropout_seed=seed)
+    hip.linear_fwd(xd, Wd, bd, y, residual=Rd, dropout_p=p, dropout_seed=seed, dropout_step=stepd)
     close(y, torch.where(keep, lin * scale, torch.zeros_like(lin)) + R.double(), what="gemm dropout before residual")
     # without: drop(relu(f(x)))
-    hip.linear_fwd(xd, Wd, bd, y, act=1, dropout_p=p, dropout_seed=seed)
+    hip.linear_fwd(xd, Wd, bd, y, act=1, dropout_p=p, dropout_seed=seed, dropout_step=stepd)
     close(y, torch.where(keep, lin.clamp_min(0) * scale, torch.zeros_like(lin)), what="gemm dropout after relu")
     gsrc = torch.randn(M, N)
     gd, out = g(gsrc), torch.zeros(M, N, device=DEV)
-    hip.call("detr_hip_dropout_f32", gd.data_ptr(), out.data_ptr(), M * N, ctypes.c_float(p), seed)
+    hip.call("detr_hip_dropout_f32", gd.data_ptr(), out.data_ptr(), M * N, ctypes.c_float(p), seed, stepd.data_ptr())
     close(out, torch.where(keep, gsrc.double() * scale, torch.zeros(M, N, dtype=torch.float64)), rtol=1e-6, what="dropout_f32")
 
 
-@pytest.mark.parametrize("B,T,S", [(2, 100, 333), (1, 70, 1050)])
-def test_fused_attention_dropout(hip, B, T, S):
+@pytest.mark.parametrize("B,T,S,compute", [(2, 100, 333, 0), (1, 70, 1050, 0), (2, 100, 333, 1)])
+def test_fused_attention_dropout(hip, B, T, S, compute):
+    """Dropout on the probabilities with the keyed counter-hash masks (site id as kernel argument, step seed in DEVICE
+    memory), softmax scale folded into the kernel (transformer.py:307), and q / k / v / gradients addressed as column
+    blocks of PACKED buffers with their own row strides (the engine's [rows, 768] / [rows, layers*256] layouts)."""
     from oracle import dropout_ref as DR
     torch.manual_seed(T + S)
-    H, hd, p, seed = 8, 32, 0.1, 77
+    H, hd, p, site, step, scale = 8, 32, 0.1, 77, 0xBEEF1234, 32 ** -0.5
     D = H * hd
-    q = (torch.randn(B, T, D, dtype=torch.float64) * 0.5).requires_grad_(True)
+    q = (torch.randn(B, T, D, dtype=torch.float64) * 1.5).requires_grad_(True)
     k = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
     v = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
     qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
-    w = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)                       # [B,H,T,S]
-    keep = torch.from_numpy(DR.keep_mask(seed, DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
+    w = torch.softmax((qh * scale) @ kh.transpose(-1, -2), dim=-1)             # [B,H,T,S]
+    keep = torch.from_numpy(DR.keep_mask(DR.drop_key(site, step), DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
     wd = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
     o = (wd @ vh).transpose(1, 2).reshape(B, T, D)
     do = torch.randn(B, T, D, dtype=torch.float64)
     o.backward(do)
-    qd, kd, vd, dod = g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())
-    od, lse = torch.zeros(B, T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_fwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(), B, H,
-             T, S, D, ctypes.c_float(p), seed)
-    close(od, o, rtol=3e-5, what="attention+dropout fwd")
-    dq, dk, dv = torch.zeros_like(qd), torch.zeros_like(kd), torch.zeros_like(vd)
+    stepd = torch.tensor([step - (1 << 32)] + [0] * 7, dtype=torch.int32, device=DEV)
+    qbuf = torch.full((B * T, 3 * D), 3.0, device=DEV)                         # q in columns 256..511 of a [rows, 768] buffer
+    kvbuf = torch.full((B * S, 5 * D), -2.0, device=DEV)                       # k in block 1, v in block 3 of a [rows, 1280] buffer
+    qbuf[:, D:2 * D] = q.detach().float().view(-1, D).to(DEV)
+    kvbuf[:, D:2 * D] = k.detach().float().view(-1, D).to(DEV)
+    kvbuf[:, 3 * D:4 * D] = v.detach().float().view(-1, D).to(DEV)
+    qd, kd, vd = qbuf[:, D:2 * D], kvbuf[:, D:2 * D], kvbuf[:, 3 * D:4 * D]
+    dod = g(do.float()).view(-1, D)
+    od, lse = torch.zeros(B * T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, scale=scale, dropout_p=p, dropout_site=site, dropout_step=stepd, compute=compute)
+    tol = 3e-5 if compute == 0 else 1.5e-2
+    close(od.view(B, T, D), o, rtol=tol, what="attention+dropout fwd")
+    dqb, dkvb = torch.full_like(qbuf, 5.0), torch.full_like(kvbuf, 5.0)
     delta = torch.zeros(B * H, T, device=DEV)
-    hip.call("detr_hip_attention_bwd_f32", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lse.data_ptr(),
-             dod.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, T, S, D, ctypes.c_float(p), seed)
-    close(dq, q.grad, rtol=5e-5, what="attention+dropout dq")
-    close(dk, k.grad, rtol=5e-5, what="attention+dropout dk")
-    close(dv, v.grad, rtol=5e-5, what="attention+dropout dv")
+    hip.attention(qd, kd, vd, od, lse, B, H, T, S, scale=scale, dropout_p=p, dropout_site=site, dropout_step=stepd, compute=compute,
+                  d_o=dod, dq=dqb[:, 0:D], dk=dkvb[:, 2 * D:3 * D], dv=dkvb[:, 4 * D:], delta=delta)
+    gt = 5e-5 if compute == 0 else 2e-2
+    close(dqb[:, 0:D].reshape(B, T, D), q.grad, rtol=gt, what="attention+dropout dq (w.r.t. the unscaled q)")
+    close(dkvb[:, 2 * D:3 * D].reshape(B, S, D), k.grad, rtol=gt, what="attention+dropout dk")
+    close(dkvb[:, 4 * D:].reshape(B, S, D), v.grad, rtol=gt, what="attention+dropout dv")
+    # nothing outside the addressed column blocks was touched
+    assert bool((dqb[:, D:] == 5.0).all()) and bool((dkvb[:, :2 * D] == 5.0).all()) and bool((dkvb[:, 3 * D:4 * D] == 5.0).all())
+
+
+@pytest.mark.parametrize("rows,C,period", [(8400, 256, 1050), (800, 256, 100), (37, 64, 37)])
+def test_layernorm_fused_outputs(hip, rows, C, period):
+    """Fused side outputs of the LayerNorm launches: forward y2 = y + add[r % period] (the `+ pos` operand of the next
+    attention block); backward dx += dx_add and dx_drop = dropout_bwd(dx) with the GEMM-epilogue mask of (site, step)."""
+    from oracle import dropout_ref as DR
+    torch.manual_seed(rows)
+    x, gam, bet = torch.randn(rows, C) * 2 + 0.3, torch.rand(C) + 0.5, torch.randn(C)
+    add = torch.randn(period, C)
+    xd, gd, bd, addd = g(x), g(gam), g(bet), g(add)
+    yd, y2d = torch.zeros(rows, C, device=DEV), torch.zeros(rows, C, device=DEV)
+    mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+    hip.layernorm_fwd(xd, gd, bd, yd, mean, rstd, 1e-5, add=addd, y2=y2d)
+    yref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    close(yd, yref, rtol=1e-5, what="layernorm fwd")
+    assert torch.equal(y2d, yd + addd.repeat(rows // period, 1))
+    dy, extra = torch.randn(rows, C), torch.randn(rows, C)
+    p, site, step = 0.1, 1234, 0x0BADF00D
+    stepd = torch.tensor([step] + [0] * 7, dtype=torch.int32, device=DEV)
+    dx0, dx1, dxdrop = (torch.zeros(rows, C, device=DEV) for _ in range(3))
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    hip.layernorm_bwd(g(dy), xd, gd, mean, rstd, dx0, dg, db)
+    hip.layernorm_bwd(g(dy), xd, gd, mean, rstd, dx1, dg, db, dx_add=g(extra), dx_drop=dxdrop, dropout_p=p, dropout_site=site,
+                      dropout_step=stepd)
+    close(dx1, dx0.cpu().double() + extra.double(), rtol=1e-6, what="layernorm dx + dx_add")
+    keep = torch.from_numpy(DR.keep_mask(DR.drop_key(site, step), np.arange(rows * C).reshape(rows, C), p)).to(DEV)
+    assert bool((dxdrop[~keep] == 0).all())
+    close(dxdrop, torch.where(keep, dx1 / (1.0 - p), torch.zeros_like(dx1)).cpu().double(), rtol=1e-6, what="layernorm dx_drop")
+
+
+def test_multi_copy_and_set_u32(hip):
+    torch.manual_seed(3)
+    a, b = torch.randn(256, 256, device=DEV), torch.randn(512, device=DEV)
+    a16 = torch.randn(64, 256, device=DEV).to(torch.bfloat16)
+    da, db, da16 = torch.zeros_like(a), torch.ones_like(b), torch.zeros_like(a16)
+    table = hip.copy_table([(a, da, 0), (b, db, 1), (a16, da16, 0)], DEV)
+    hip.multi_copy(table)
+    assert torch.equal(da, a) and torch.equal(db, b + 1.0) and torch.equal(da16, a16)
+    w = torch.zeros(8, dtype=torch.int32, device=DEV)
+    hip.call("detr_hip_set_u32x8", w.data_ptr(), 0xDEADBEEF, 1, 2, 3, 4, 5, 6, 7)
+    assert [int(v) & 0xFFFFFFFF for v in w.cpu()] == [0xDEADBEEF, 1, 2, 3, 4, 5, 6, 7]
 
 
 # ------------------------------------------------------------------------------------------
