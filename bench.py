@@ -107,11 +107,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the 3 extra fp32-parity-mode steps of a bf16 run")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (default: the step is recorded once as a "
+                                                           "hipGraph and replayed, exactly as training.fit does)")
     ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps (the last ones) whose launches carry HIP events")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves and relay rank 0's line
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     from detr_tf import _hip, parallel, training
     from detr_tf.loss.loss import get_losses
@@ -125,7 +135,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != max(1, args.gpus) and not (world == 1 and os.environ.get("DETR_DP_FORCE") == "1"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s); launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                         "(or plain `python bench.py --gpus N`, which spawns the ranks itself)")
+    if world > torch.cuda.device_count() and (args.dist_backend or "nccl") == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
 
     cfg = TrainingConfig()
     cfg.background_class = 91
@@ -140,18 +155,25 @@ def main():
         for raw in model.engine.P.bn_raw.values():
             dist.broadcast(raw, src=0)
         model.engine.fold_bn()
-        model.dp = parallel.DataParallel(model.engine.P.grad, model.engine.P.bucket_bounds())
+        model.dp = parallel.DataParallel(model.engine.P.grad, model.engine.P.bucket_bounds(), engine=model.engine)
 
     rng = np.random.default_rng(1234 + rank)
     images = torch.from_numpy(rng.normal(size=(args.batch, args.height, args.width, 3)).astype(np.float32)).to(dev)
     tb, tc = make_targets(args.batch, np.random.default_rng(1235 + rank))
     tb, tc = torch.from_numpy(tb).to(dev), torch.from_numpy(tc).to(dev)
 
+    use_graph = not args.no_graph
+    stepper = {}
+
     def step(i):
         if args.mode == "train":
-            out, total, log, steps = training.run_train_step(model, images, tb, tc, opt, cfg)
-            for name in steps:
-                training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], i, cfg)
+            if use_graph and _hip.PROFILER is None:      # (HIP events around single launches need the eager step)
+                if id(model) not in stepper:
+                    stepper.clear()
+                    stepper[id(model)] = training.GraphedTrainStep(model, opt, cfg)
+                out, total, log = stepper[id(model)](images, tb, tc, i)
+            else:
+                out, total, log = training.train_step(model, images, tb, tc, opt, cfg, i)
             return total
         out = model(images, training=False)
         total, log = get_losses(out, tb, tc, cfg)

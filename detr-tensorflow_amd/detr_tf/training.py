@@ -1,10 +1,21 @@
-"""Training / evaluation loop of the drop-in API (reference detr_tf/training.py:9-87)."""
+"""Training / evaluation loop of the drop-in API (reference detr_tf/training.py:9-87).
+
+`run_train_step`, `run_val_step`, `fit` and `eval` keep the reference's signatures, return values, console lines and
+side effects (`config.global_step`).  Underneath, a step is a fixed sequence of HIP kernel launches with no host
+synchronisation and no allocation, so `fit` can record it ONCE as a hipGraph (`GraphedTrainStep`) and replay it for
+every further batch of the same shape: whatever changes between steps -- the batch, the dropout step seed, the Adam step
+sizes -- lives in device memory that is refreshed before each replay.
+"""
+import os
 import time
 
 import torch
 
 from .loss.loss import get_losses
-from .optimizers import aggregate_grad_and_apply, gather_gradient
+from .optimizers import GROUPS, aggregate_grad_and_apply, gather_gradient
+
+PRINT_EVERY_TRAIN = 100         # training.py:57
+PRINT_EVERY_VAL = 10            # training.py:80
 
 
 def _gradient_aggregate(config):
@@ -32,31 +43,210 @@ def run_val_step(model, images, t_bbox, t_class, config):
     return m_outputs, total_loss, log
 
 
+def train_step(model, images, t_bbox, t_class, optimizers, config, epoch_step):
+    """What `fit` does for one batch (training.py:46-54): gradients, then accumulate / apply per group."""
+    m_outputs, total_loss, log, gradient_steps = run_train_step(model, images, t_bbox, t_class, optimizers, config)
+    for name in gradient_steps:
+        aggregate_grad_and_apply(name, optimizers, gradient_steps[name]["gradients"], epoch_step, config)
+    return m_outputs, total_loss, log
+
+
+class _Segments:
+    """A step recorded as consecutive hipGraphs with an EAGER action between them (the data-parallel collectives stay
+    outside the graphs: RCCL launches on its own stream as soon as the segment that finalises a gradient bucket is queued)."""
+
+    def __init__(self):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs, self.actions = [], []
+        self._cur = None
+
+    def begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self.pool)
+
+    def cut(self, action):
+        self._cur.capture_end()
+        self.graphs.append(self._cur)
+        self.actions.append(action)
+        self.begin()
+
+    def end(self):
+        self._cur.capture_end()
+        self.graphs.append(self._cur)
+        self.actions.append(None)
+        self._cur = None
+
+    def replay(self):
+        for g, act in zip(self.graphs, self.actions):
+            g.replay()
+            if act is not None:
+                act()
+
+
+class GraphedTrainStep:
+    """train_step() for a fixed batch shape, recorded once as hipGraph(s) and replayed.
+
+    The first `eager_steps` calls run eagerly (they also allocate every buffer of the static memory plan); the next call
+    records the launch sequence -- forward, set loss, backward into one graph (cut at the data-parallel exchange points
+    when training on several GPUs), clip + Adam of the three groups into another -- and from then on a step is: copy the
+    batch into the static input buffers, write the new dropout seed / Adam step sizes to device memory, replay.
+    A new batch shape (or set of trained groups) is recorded afresh after one eager step; gradient accumulation runs eagerly."""
+
+    def __init__(self, model, optimizers, config, eager_steps=1):
+        self.model, self.optimizers, self.config = model, optimizers, config
+        self.eager_steps = max(1, int(eager_steps))
+        self.calls = 0
+        self.key = None
+        self.step_graph = self.apply_graph = None
+        self.static = None
+        self.result = None
+
+    def _signature(self, images, t_bbox, t_class):
+        c = self.config
+        return (tuple(images.shape), tuple(t_bbox.shape), bool(c.train_backbone), bool(c.train_transformers),
+                bool(c.train_nlayers), int(c.background_class), self.model.engine.compute, float(self.model.engine.dropout_p))
+
+    def _capture(self, images, t_bbox, t_class):
+        model, opts, cfg = self.model, self.optimizers, self.config
+        eng, dev = model.engine, model.device
+        st_img = torch.empty(tuple(images.shape), dtype=torch.float32, device=dev)
+        st_tb = torch.empty(tuple(t_bbox.shape), dtype=torch.float32, device=dev)
+        st_tc = torch.empty((t_bbox.shape[0], t_bbox.shape[1]), dtype=torch.int64, device=dev)
+        self.static = (st_img, st_tb, st_tc)
+        self._load_inputs(images, t_bbox, t_class)
+        dp = model.dp
+        seg = _Segments()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        eng._graph_replay = True
+        eng.weights_dirty = True            # the derived weight copies are rebuilt inside the recorded step, as in every eager step
+        prev_hooks = None
+        try:
+            with torch.cuda.stream(side):
+                if dp is not None and dp.active:      # collectives run eagerly between graph segments
+                    prev_hooks = (dp.on_bucket, dp.reduce_sums, dp.finish)
+                    dp.on_bucket = lambda i, f=prev_hooks[0]: seg.cut(lambda: f(i))
+                    dp.reduce_sums = lambda sums, f=prev_hooks[1]: seg.cut(lambda: f(sums))
+                    dp.finish = lambda: None
+                seg.begin()
+                m_outputs, total_loss, log, gradient_steps = run_train_step(model, st_img, st_tb, st_tc, opts, cfg)
+                seg.end()
+                if prev_hooks is not None:
+                    dp.on_bucket, dp.reduce_sums, dp.finish = prev_hooks
+                    prev_hooks = None
+                app = _Segments()
+                app.pool = seg.pool
+                app.begin()
+                store = opts["_store"]
+                for name in GROUPS:
+                    if getattr(cfg, f"train_{name}"):
+                        opts[f"{name}_gradients"] = store.grad
+                        opts[f"{name}_optimizer"].apply_gradients(store.grad, hyper_ready=True)
+                app.end()
+        finally:
+            if prev_hooks is not None:
+                dp.on_bucket, dp.reduce_sums, dp.finish = prev_hooks
+            eng._graph_replay = False
+        torch.cuda.current_stream().wait_stream(side)
+        self.step_graph, self.apply_graph = seg, app
+        self.result = (m_outputs, total_loss, log)
+
+    def _load_inputs(self, images, t_bbox, t_class):
+        st_img, st_tb, st_tc = self.static
+        if not (torch.is_tensor(images) and images.data_ptr() == st_img.data_ptr()):
+            st_img.copy_(torch.as_tensor(images), non_blocking=True)
+        if not (torch.is_tensor(t_bbox) and t_bbox.data_ptr() == st_tb.data_ptr()):
+            st_tb.copy_(torch.as_tensor(t_bbox), non_blocking=True)
+        tc = torch.as_tensor(t_class)
+        if not (tc.is_cuda and tc.data_ptr() == st_tc.data_ptr()):
+            st_tc.copy_(tc.reshape(st_tc.shape), non_blocking=True)
+
+    def __call__(self, images, t_bbox, t_class, epoch_step):
+        cfg, model = self.config, self.model
+        key = self._signature(images, t_bbox, t_class)
+        if key != self.key:                 # new batch shape / trained groups / precision: eager warm-up, then record again
+            self.key, self.calls = key, 0
+            self.step_graph = self.apply_graph = self.result = None
+        self.calls += 1
+        if _gradient_aggregate(cfg) > 1 or self.calls <= self.eager_steps:
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
+        if self.step_graph is None:
+            self._capture(images, t_bbox, t_class)
+        else:
+            self._load_inputs(images, t_bbox, t_class)
+        eng = model.engine
+        eng._graph_replay = True
+        try:
+            if eng.dropout_p > 0.0:
+                eng.advance_dropout_step()                         # new masks: the kernels read the seed from device memory
+            for name in GROUPS:
+                if getattr(cfg, f"train_{name}"):
+                    self.optimizers[f"{name}_optimizer"].set_step_hyper()
+            self.step_graph.replay()
+            if model.dp is not None:
+                model.dp.finish()
+            self.apply_graph.replay()
+        finally:
+            eng._graph_replay = False
+        eng.weights_dirty = True                                   # the parameters moved: derived copies are stale for eager passes
+        m_outputs, total_loss, log = self.result
+        for name in GROUPS:
+            log[f"{name}_lr"] = self.optimizers[f"{name}_optimizer"].learning_rate()
+        return m_outputs, total_loss, log
+
+
+def _use_graph(config):
+    flag = getattr(config, "use_graph", None)
+    if flag is None:
+        flag = os.environ.get("DETR_HIP_GRAPH", "1") != "0"
+    return bool(flag)
+
+
+def _console(prefix, log, elapsed):
+    return (f"{prefix}, \t ce: [{float(log['label_cost']):.2f}] \t giou : [{float(log['giou_loss']):.2f}] \t "
+            f"l1 : [{float(log['l1_loss']):.2f}] \t time : [{elapsed:.2f}]")
+
+
+class _Stopwatch:
+    """The reference's `t` bookkeeping: 0.00 at the first report; `fit` then measures since the PREVIOUS report
+    (training.py:58-63 resets t), `eval` since the FIRST one (training.py:81-83 never resets it)."""
+
+    def __init__(self, reset):
+        self.t, self.reset = None, reset
+
+    def lap(self):
+        if self.t is None:
+            self.t = time.time()
+        elapsed = time.time() - self.t
+        if self.reset:
+            self.t = time.time()
+        return elapsed
+
+
 def fit(model, train_dt, optimizers, config, epoch_nb, class_names):
-    """Train the model for one epoch (training.py:35-65); same console line every 100 steps."""
-    t = None
+    """Train the model for one epoch (training.py:35-65); same console line every 100 steps, `config.global_step`
+    advanced once per batch.  `config.use_graph` (default on, env DETR_HIP_GRAPH=0 disables) replays the step as a hipGraph."""
+    stepper = optimizers.get("_graphed_step") if _use_graph(config) else None
+    if _use_graph(config) and stepper is None:
+        stepper = optimizers["_graphed_step"] = GraphedTrainStep(model, optimizers, config)
+    watch = _Stopwatch(reset=True)
     for epoch_step, (images, t_bbox, t_class) in enumerate(train_dt):
-        m_outputs, total_loss, log, gradient_steps = run_train_step(model, images, t_bbox, t_class, optimizers, config)
-        for name in gradient_steps:
-            aggregate_grad_and_apply(name, optimizers, gradient_steps[name]["gradients"], epoch_step, config)
-        if epoch_step % 100 == 0:
-            t = t if t is not None else time.time()
-            elapsed = time.time() - t
-            print(f"Epoch: [{epoch_nb}], \t Step: [{epoch_step}], \t ce: [{float(log['label_cost']):.2f}] \t "
-                  f"giou : [{float(log['giou_loss']):.2f}] \t l1 : [{float(log['l1_loss']):.2f}] \t time : [{elapsed:.2f}]")
-            t = time.time()
+        if stepper is not None:
+            m_outputs, total_loss, log = stepper(images, t_bbox, t_class, epoch_step)
+        else:
+            m_outputs, total_loss, log = train_step(model, images, t_bbox, t_class, optimizers, config, epoch_step)
+        if epoch_step % PRINT_EVERY_TRAIN == 0:
+            print(_console(f"Epoch: [{epoch_nb}], \t Step: [{epoch_step}]", log, watch.lap()))
         config.global_step += 1
 
 
 def eval(model, valid_dt, config, class_name, evaluation_step=200):
-    """Evaluate on the validation set (training.py:68-87)."""
-    t = None
+    """Evaluate on the validation set (training.py:68-87): forward with training=False + set loss for at most
+    `evaluation_step` batches, console line every 10."""
+    watch = _Stopwatch(reset=False)
     for val_step, (images, t_bbox, t_class) in enumerate(valid_dt):
         m_outputs, total_loss, log = run_val_step(model, images, t_bbox, t_class, config)
-        if val_step % 10 == 0:
-            t = t if t is not None else time.time()
-            elapsed = time.time() - t
-            print(f"Validation step: [{val_step}], \t ce: [{float(log['label_cost']):.2f}] \t "
-                  f"giou : [{float(log['giou_loss']):.2f}] \t l1 : [{float(log['l1_loss']):.2f}] \t time : [{elapsed:.2f}]")
+        if val_step % PRINT_EVERY_VAL == 0:
+            print(_console(f"Validation step: [{val_step}]", log, watch.lap()))
         if val_step + 1 >= evaluation_step:
             break

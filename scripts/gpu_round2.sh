@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-2 GPU runner (via gpurun): scripts/gpu_round2.sh <tag> <what...>
+TAG=${1:-run}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export PYTHONUNBUFFERED=1
+cd /root/repo
+for w in "$@"; do
+  case $w in
+    tests) timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; tail -40 $OUT/tests.log ;;
+    tests_all) timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; tail -60 $OUT/tests.log ;;
+    kernels) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider > $OUT/kernels.log 2>&1; echo "kernels rc=$?" >> $OUT/summary.txt; tail -40 $OUT/kernels.log ;;
+    model) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_training.py tests/test_golden.py tests/test_gpu_dp.py -m gpu -q --no-header -p no:cacheprovider > $OUT/model.log 2>&1; echo "model rc=$?" >> $OUT/summary.txt; tail -60 $OUT/model.log ;;
+    smoke) timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt; tail -3 $OUT/smoke.log ;;
+    bench) timeout 900 python bench.py --steps 10 --warmup 3 --dump-shapes $OUT/shapes.json > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench.log | cut -c1-1500 ;;
+    bench_quick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --dump-shapes $OUT/shapes.json > $OUT/bench_quick.log 2>&1; echo "bench_quick rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_quick.log | cut -c1-2500 ;;
+    bench_eager) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-graph --no-kernel-events > $OUT/bench_eager.log 2>&1; echo "bench_eager rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_eager.log | cut -c1-600 ;;
+    bench_f32) timeout 600 python bench.py --steps 5 --warmup 2 --precision fp32 --no-cpu-baseline --dump-shapes $OUT/shapes_f32.json > $OUT/bench_f32.log 2>&1; echo "bench_f32 rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_f32.log | cut -c1-800 ;;
+    prof16) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt
+          python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 > $OUT/prof16_summary.txt 2>&1; head -70 $OUT/prof16_summary.txt ;;
+    *) echo "unknown $w" ;;
+  esac
+done
+cat $OUT/summary.txt
+exit 0

@@ -545,6 +545,46 @@ def test_assign_matches_scipy(hip, Q, n_list):
         assert np.array_equal(tfp[p], inv)
 
 
+@pytest.mark.parametrize("Q,n,seed", [(100, 7, 0), (100, 99, 1), (100, 1, 2), (64, 20, 3)])
+def test_hungarian_matching_six_tuple_vs_scipy(hip, Q, n, seed):
+    """The single-image wrapper with the reference's signature and SIX-tuple return convention
+    (hungarian_matching.py:163-203).  The reference's names are swapped twice (np_tf_linear_sum_assignment calls SciPy's
+    ROW = prediction indices `target_indices`, :29-31, and hungarian_matching returns `pred_indices` first, :203), so the
+    caller's `t_indices, p_indices, t_selector, p_selector` (loss.py:118) receive: SciPy's column (= target) indices,
+    SciPy's row (= prediction) indices ascending, a bool[n] over targets, a bool[Q] over predictions."""
+    from scipy.optimize import linear_sum_assignment
+    from detr_tf.loss.hungarian_matching import hungarian_matching
+    from oracle import set_loss_ref as L
+    rng = np.random.default_rng(seed)
+    C = 92
+    t_bbox = np.zeros((100, 4), np.float32)
+    t_class = np.zeros((100, 1), np.int64)
+    t_bbox[0, 0] = n
+    t_bbox[1:1 + n, :2] = rng.uniform(0.2, 0.8, (n, 2))
+    t_bbox[1:1 + n, 2:] = rng.uniform(0.05, 0.4, (n, 2))
+    t_class[1:1 + n, 0] = rng.integers(1, 91, n)
+    p_bbox = np.concatenate([rng.uniform(0.1, 0.9, (Q, 2)), rng.uniform(0.05, 0.5, (Q, 2))], 1).astype(np.float32)
+    p_class = rng.normal(size=(Q, C)).astype(np.float32)
+    got = hungarian_matching(g(torch.from_numpy(t_bbox)), g(torch.from_numpy(t_class)), g(torch.from_numpy(p_bbox)),
+                             g(torch.from_numpy(p_class)), slice_preds=True)
+    assert len(got) == 6
+    t_idx, p_idx, t_sel, p_sel, tb, tc = got
+    cost = L.cost_matrix(torch.from_numpy(t_bbox[1:1 + n]), torch.from_numpy(t_class[1:1 + n, 0]), torch.from_numpy(p_bbox),
+                         torch.from_numpy(p_class)).numpy()
+    rows, cols = linear_sum_assignment(cost)                       # rows = predictions (ascending), cols = targets
+    assert t_idx.dtype == torch.int64 and p_idx.dtype == torch.int64
+    assert np.array_equal(p_idx.cpu().numpy(), rows) and np.array_equal(t_idx.cpu().numpy(), cols)
+    assert t_sel.dtype == torch.bool and tuple(t_sel.shape) == (n,) and bool(t_sel.all())
+    want_psel = np.zeros(Q, bool)
+    want_psel[rows] = True
+    assert p_sel.dtype == torch.bool and np.array_equal(p_sel.cpu().numpy(), want_psel)
+    assert np.array_equal(tb.cpu().numpy(), t_bbox[1:1 + n]) and np.array_equal(tc.cpu().numpy(), t_class[1:1 + n, 0])
+    # the oracle's own wrapper agrees (it returns the five used entries in the caller's order)
+    oti, opi, osel, _, _ = L.hungarian_matching(torch.from_numpy(t_bbox), torch.from_numpy(t_class), torch.from_numpy(p_bbox),
+                                                torch.from_numpy(p_class))
+    assert np.array_equal(oti.numpy(), cols) and np.array_equal(opi.numpy(), rows) and np.array_equal(osel.numpy(), want_psel)
+
+
 def test_assign_ties_and_invalid(hip):
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(5)

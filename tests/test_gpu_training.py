@@ -1,0 +1,207 @@
+"""GPU tests of the training / evaluation LOOP of the drop-in API (reference detr_tf/training.py:35-87): console
+format, `config.global_step`, the `evaluation_step` break, gradient accumulation through `fit`, and the hipGraph replay
+of the step (`training.GraphedTrainStep`) against the eager step."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TRAIN_LINE = re.compile(r"^Epoch: \[(\d+)\], \t Step: \[(\d+)\], \t ce: \[(-?\d+\.\d\d)\] \t giou : \[(-?\d+\.\d\d)\] \t "
+                        r"l1 : \[(-?\d+\.\d\d)\] \t time : \[(\d+\.\d\d)\]$")
+VAL_LINE = re.compile(r"^Validation step: \[(\d+)\], \t ce: \[(-?\d+\.\d\d)\] \t giou : \[(-?\d+\.\d\d)\] \t "
+                      r"l1 : \[(-?\d+\.\d\d)\] \t time : \[(\d+\.\d\d)\]$")
+
+
+def _cfg():
+    from detr_tf.training_config import TrainingConfig
+    cfg = TrainingConfig()
+    cfg.background_class = 91
+    cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
+    cfg.target_batch = None
+    cfg.batch_size = 2
+    return cfg
+
+
+def _model(cfg, dropout=0.1, precision="fp32", seed=5):
+    from detr_tf.networks.detr import get_detr_model
+    from oracle import detr_ref as R
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=dropout, precision=precision)
+    model.load_weights(R.make_params(seed, num_enc=1, num_dec=2))
+    return model
+
+
+def _batches(n, seed=0, B=2, H=96, W=128):
+    from oracle import set_loss_ref as L
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        tb, tc = L.make_targets(B, seed=100 + seed + i, force_full=False)
+        out.append((rng.normal(size=(B, H, W, 3)).astype(np.float32), tb, tc))
+    return out
+
+
+def test_fit_console_global_step_and_oracle_loss(hip, capsys):
+    """training.fit on a 3-batch iterable: one console line (step 0; the next would be step 100) in the reference's
+    format (training.py:60), global_step advanced per batch, and the printed numbers are the oracle's first-step losses
+    (dropout masks shared with the oracle)."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, dropout_ref as DR, set_loss_ref as L
+    cfg = _cfg()
+    cfg.use_graph = False
+    model = _model(cfg)
+    opt = setup_optimizers(model, cfg)
+    data = _batches(3)
+    cfg.global_step = 7
+    training.fit(model, data, opt, cfg, epoch_nb=4, class_names=[])
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    m = TRAIN_LINE.match(lines[0])
+    assert m, repr(lines[0])
+    assert (int(m.group(1)), int(m.group(2))) == (4, 0)
+    assert cfg.global_step == 10
+    assert all(o.iterations == 3 for o in (opt["backbone_optimizer"], opt["transformers_optimizer"], opt["nlayers_optimizer"]))
+    # the oracle on the first batch with the same weights and the same dropout masks (step 1 of this engine)
+    params = R.make_params(5, num_enc=1, num_dec=2)
+    seed1 = DR.step_seed(model.engine.dropout_seed, 1, 0)
+    ref_out = R.detr_forward(torch.from_numpy(data[0][0]), R.to_torch(params), num_enc=1, num_dec=2, drop=DR.Dropper(0.1, seed1))
+    _, ref_log = L.get_losses(ref_out, torch.from_numpy(data[0][1]), torch.from_numpy(data[0][2]), 91)
+    for grp, key in ((3, "label_cost"), (4, "giou_loss"), (5, "l1_loss")):
+        assert abs(float(m.group(grp)) - float(ref_log[key])) <= 0.011, (key, m.group(grp), float(ref_log[key]))
+
+
+def test_eval_console_and_evaluation_step_break(hip, capsys):
+    """training.eval (training.py:68-87): a line at validation steps 0, 10, 20..., stops after `evaluation_step` batches,
+    never touches the parameters or global_step."""
+    from detr_tf import training
+    cfg = _cfg()
+    model = _model(cfg)
+    before = model.engine.P.flat.clone()
+    one = _batches(1)[0]
+    consumed = []
+
+    def stream():
+        for i in range(40):
+            consumed.append(i)
+            yield one
+
+    training.eval(model, stream(), cfg, class_name=[], evaluation_step=12)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert [int(VAL_LINE.match(l).group(1)) for l in lines] == [0, 10], lines
+    assert len(consumed) == 12 and cfg.global_step == 0
+    assert torch.equal(before, model.engine.P.flat)
+    assert lines[0].split("time")[0] == lines[1].split("time")[0]          # same batch, eval mode: identical numbers
+
+
+def test_fit_gradient_accumulation_applies_every_target_batch(hip):
+    """target_batch / batch_size = 2 (optimizers.py:137-163 through training.fit): parameters move after batches 1 and 3 only."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    cfg = _cfg()
+    cfg.target_batch = 4
+    cfg.use_graph = True               # accumulation falls back to the eager step
+    model = _model(cfg, dropout=0.0)
+    opt = setup_optimizers(model, cfg)
+    snaps = []
+
+    class Data:
+        def __iter__(self):
+            for b in _batches(4):
+                snaps.append(model.engine.P.flat.clone())
+                yield b
+
+    training.fit(model, Data(), opt, cfg, epoch_nb=0, class_names=[])
+    snaps.append(model.engine.P.flat.clone())
+    moved = [not torch.equal(snaps[i], snaps[i + 1]) for i in range(4)]
+    assert moved == [False, True, False, True], moved
+    assert opt["backbone_optimizer"].iterations == 2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replay_equals_eager_steps(hip, precision):
+    """The hipGraph replay of the training step (dropout 0.1: new masks every step from the device-resident seed; Adam
+    step sizes from device memory; derived weight copies rebuilt inside the graph) reproduces the eager steps bit for bit:
+    same parameters after 5 steps, same losses at every step."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    data = _batches(5, seed=3)
+    results = {}
+    for mode in ("eager", "graph"):
+        cfg = _cfg()
+        model = _model(cfg, precision=precision)
+        opt = setup_optimizers(model, cfg)
+        losses = []
+        if mode == "eager":
+            for i, (im, tb, tc) in enumerate(data):
+                _, total, log = training.train_step(model, im, tb, tc, opt, cfg, i)
+                losses.append((float(total), float(log["giou_loss_0"])))
+        else:
+            stepper = training.GraphedTrainStep(model, opt, cfg, eager_steps=1)
+            for i, (im, tb, tc) in enumerate(data):
+                _, total, log = stepper(im, tb, tc, i)
+                losses.append((float(total), float(log["giou_loss_0"])))
+            assert stepper.step_graph is not None and len(stepper.step_graph.graphs) == 1
+        torch.cuda.synchronize()
+        results[mode] = (losses, model.engine.P.flat.clone(), model.engine.P.adam_v.clone())
+    assert results["eager"][0] == results["graph"][0], (results["eager"][0], results["graph"][0])
+    assert torch.equal(results["eager"][1], results["graph"][1])
+    assert torch.equal(results["eager"][2], results["graph"][2])
+    l = [x[0] for x in results["graph"][0]]
+    assert len(set(l)) == 5                                     # five different batches / masks: nothing was replayed stale
+
+
+def test_graph_falls_back_on_new_shape_and_eval_sees_new_weights(hip):
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    cfg = _cfg()
+    model = _model(cfg, dropout=0.0)
+    opt = setup_optimizers(model, cfg)
+    stepper = training.GraphedTrainStep(model, opt, cfg)
+    a = _batches(3, seed=1)
+    for i, (im, tb, tc) in enumerate(a):
+        stepper(im, tb, tc, i)
+    # eval after graph replays must use the updated parameters (derived copies are version-stamped)
+    out_graph = model(a[0][0], training=False)["pred_logits"].clone()
+    cfg2 = _cfg()
+    m2 = _model(cfg2, dropout=0.0)
+    o2 = setup_optimizers(m2, cfg2)
+    for i, (im, tb, tc) in enumerate(a):
+        training.train_step(m2, im, tb, tc, o2, cfg2, i)
+    assert torch.equal(out_graph, m2(a[0][0], training=False)["pred_logits"])
+    # another image size: eager fallback, still a valid step
+    b = _batches(1, seed=9, H=64, W=96)[0]
+    before = model.engine.P.flat.clone()
+    _, total, _ = stepper(b[0], b[1], b[2], 3)
+    assert np.isfinite(float(total)) and not torch.equal(before, model.engine.P.flat)
+
+
+def test_setup_optimizers_alone_keeps_derived_weights_fresh(hip):
+    """a loop that calls gather_gradient / GroupAdam.apply_gradients directly (never run_train_step's
+    bookkeeping) must still see the BN-folded / bf16 weight copies rebuilt after an apply."""
+    from detr_tf.loss.loss import get_losses
+    from detr_tf.optimizers import gather_gradient, setup_optimizers
+    cfg = _cfg()
+    model = _model(cfg, dropout=0.0, precision="bf16")
+    opt = setup_optimizers(model, cfg)
+    im, tb, tc = _batches(1)[0]
+    out = model(im, training=True)
+    total, log = get_losses(out, tb, tc, cfg)
+    steps = gather_gradient(model, opt, total, out, cfg, log)
+    l0 = float(total)
+    cfg.backbone_lr = 1e-2          # rebinding the attribute (not .assign): must be picked up
+    cfg.transformers_lr = 1e-2
+    for name in ("backbone", "transformers", "nlayers"):
+        opt[f"{name}_optimizer"].apply_gradients(model.engine.P.grad)
+    assert opt["backbone_optimizer"].learning_rate() == pytest.approx(1e-2)
+    out2 = model(im, training=True)
+    total2, _ = get_losses(out2, tb, tc, cfg)
+    # the big step changed every weight: with stale folded backbone kernels / bf16 shadow the loss would not move
+    eng = model.engine
+    w = eng.P.views["backbone/layer1/0/conv1/kernel"]
+    ws16 = eng._bufs["ws16:backbone/layer1/0/conv1/kernel"].float()
+    want = (w * eng.bn_scale["backbone/layer1/0/bn1"]).to(torch.bfloat16).float()
+    assert torch.equal(ws16, want)
+    assert abs(float(total2) - l0) > 1e-3 * abs(l0)
