@@ -250,9 +250,9 @@ def test_fused_attention_bf16_mfma(hip, B, T, S, p):
     delta = torch.zeros(B * H, T, device=DEV)
     hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=1, dropout_p=p, dropout_site=seed, d_o=dod, dq=dq.view(-1, D),
                   dk=dk.view(-1, D), dv=dv.view(-1, D), delta=delta)
-    close(dq, q.grad, rtol=2e-2, what="bf16 attention dq")
-    close(dk, k.grad, rtol=2e-2, what="bf16 attention dk")
-    close(dv, v.grad, rtol=2e-2, what="bf16 attention dv")
+    close(dq, q.grad, rtol=2.5e-2, what="bf16 attention dq")
+    close(dk, k.grad, rtol=2.5e-2, what="bf16 attention dk")
+    close(dv, v.grad, rtol=2.5e-2, what="bf16 attention dv")
 
 
 @pytest.mark.parametrize("N,H,W,compute", [(2, 37, 53, 0), (1, 128, 160, 0), (2, 37, 53, 1), (3, 64, 96, 1)])

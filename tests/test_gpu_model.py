@@ -436,14 +436,19 @@ def test_c1_single_480x640_image_forward_and_inference(hip):
     from oracle import detr_ref as R, set_loss_ref as L
     cfg = _cfg(train=False)
     params = R.make_params(12)
-    params["class_embed/bias"] = params["class_embed/bias"].copy()
-    params["class_embed/bias"][91] -= 0.05          # random-init logits are near-uniform: let some queries be foreground
-    model = get_detr_model(cfg, include_top=True)
-    assert not model.load_weights(params)
     image = np.random.default_rng(13).normal(size=(1, 480, 640, 3)).astype(np.float32)
-    out = model(image, training=False)
     with torch.no_grad():
         ref = R.detr_forward(torch.from_numpy(image), R.to_torch(params))
+        # random-init logits never pick the background class: shift its bias so that about half of the queries are
+        # background (the bias is additive, so the oracle's logits shift by the same amount)
+        lg = ref["pred_logits"][0]
+        delta = float(torch.median(lg[:, :91].max(-1).values - lg[:, 91]))
+        params["class_embed/bias"] = params["class_embed/bias"].copy()
+        params["class_embed/bias"][91] += np.float32(delta)
+        ref = R.detr_forward(torch.from_numpy(image), R.to_torch(params))
+    model = get_detr_model(cfg, include_top=True)
+    assert not model.load_weights(params)
+    out = model(image, training=False)
     assert tuple(out["pred_logits"].shape) == (1, 100, 92) and len(out["aux"]) == 5
     assert model.engine._feat_meta[1:] == (15, 20, 300)
     assert _rel(out["pred_logits"], ref["pred_logits"]) < 2e-4
