@@ -1,18 +1,27 @@
 #!/usr/bin/env python
-"""bench.py -- images/sec of one DETR-R50 training step (forward with training=True, Hungarian
-set loss with 5 aux levels, backward, per-tensor clipnorm, 3x Adam) at 800x1333, batch 8 per GPU,
-synthetic data, random-init weights (BASELINE.json metric / SURVEY.md 8d).  Default --precision bf16
-(BASELINE.json config C3: bf16 MFMA, bf16 weight shadow and backbone activation storage, fp32 master
-weights / accumulation / loss); --precision fp32 is the exact-f32 parity mode, whose rate the bf16 line
-also reports (`images_per_sec_fp32_parity_mode`).
+"""bench.py -- images/sec of one DETR-R50 training step (forward with training=True, Hungarian set loss with 5 aux
+levels, backward, per-tensor clipnorm, 3x Adam) at 800x1333, batch 8 per GPU, synthetic data, random-init weights
+(BASELINE.json metric / SURVEY.md 8d).  Default --precision bf16 = BASELINE.json config C3 (bf16 MFMA, bf16 weight shadow
+and backbone activation storage, fp32 master weights / accumulation / LayerNorm / softmax statistics / heads / loss);
+--precision fp32 is the exact-f32 parity mode -- the reference's own precision -- whose numbers every bf16 line carries
+as first-class fields (`fp32`).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+      N > 1: the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+      RCCL); plain `python bench.py --gpus N` spawns the N ranks itself.  A rank count that differs from --gpus is an error.
 
-Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel (template instantiation of the GEMM
-tile engine) timed live with HIP events on the launch stream; `cpu_baseline` = the CPU oracle
-(restatement of the TF reference; TF is not installable here) timed on a bounded sample on this box's
-host cores.
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   K timed steps (barrier + synchronize on both sides, max over ranks).  The step is what training.fit
+                        runs: recorded once as a hipGraph and replayed (--no-graph: eager launches); the last
+                        --event-steps timed steps run eagerly with HIP events around every GEMM / conv / attention launch.
+  roofline              the dominant kernel family by total time, from those events (on the launch stream).
+  step_roofline         SURVEY 8d's mixed roofline: sum over the instrumented launches of max(FLOPs / MFMA peak, bytes / HBM peak)
+                        against the measured step.
+  fp32                  the parity mode (3 steps) with its own roofline.
+  configs               the other single-GPU BASELINE.json configs measured in the same process: C1 (one 480x640 image,
+                        eval forward + get_model_inference), C2 (fp32 forward + set loss, batch 8, 800x1333), and C2's bf16 twin.
+  cpu_baseline          the CPU restatement of the TF reference (oracle/, kind "port": TF is not installable) on this box's
+                        host cores, bounded samples: a batch-1 train step (same unit as `value`), the C1 forward, the C2 forward+loss.
 """
 import argparse
 import json
@@ -31,8 +40,9 @@ import torch.distributed as dist
 
 FWD_GFLOP_PER_IMAGE = 203.3          # SURVEY.md 8d (R50, 800x1333, Q=100)
 STEP_GFLOP_PER_IMAGE = 610.0         # fwd + dgrad + wgrad
-PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md
-PEAK_HBM_GBS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, exact f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0                # spec; ~6300 GB/s achievable by a copy kernel
 
 
 def make_targets(B, rng, rows=100):
@@ -60,52 +70,127 @@ def _pick_threads(requested):
     return max(1, min(avail, 32))        # torch-CPU convs stop scaling (and thrash) far below 256 threads
 
 
-def cpu_baseline(height, width, budget_s=25.0, threads=0):
-    """The oracle (kind "port": CPU restatement of the reference, torch-CPU fp32 + SciPy matcher)
-    timed on the host cores on a bounded sample: train steps at batch 1 of the same shape."""
+def cpu_baseline(height, width, threads=0, budget_s=28.0):
+    """The oracle (kind "port": CPU restatement of the reference, torch-CPU fp32 + SciPy matcher) timed on the host cores on
+    bounded samples.  `value` = batch-1 train steps of the metric's shape (images/s); `c1_forward_480x640` and
+    `c2_forward_loss` are the two CPU-runnable BASELINE.json configs."""
     from oracle import detr_ref as R, optim_ref as O, set_loss_ref as L
     cores = _pick_threads(threads)
     torch.set_num_threads(cores)
     params = R.make_params(0)
     rng = np.random.default_rng(1234)
+    t_start = time.perf_counter()
+
+    def best_of(fn, n):
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+            if time.perf_counter() - t_start > budget_s and len(ts) >= 2:
+                break
+        return min(ts[1:]) if len(ts) > 1 else ts[0], len(ts)
+
     img = torch.from_numpy(rng.normal(size=(1, height, width, 3)).astype(np.float32))
     tb, tc = L.make_targets(1, seed=1235, force_full=False)
+    tb_t, tc_t = torch.from_numpy(tb), torch.from_numpy(tc)
+    Pn = R.to_torch(params)
+    # C1: single 480x640 image, eval forward + post-processing (eval.py:41-45)
+    img1 = torch.from_numpy(rng.normal(size=(1, 480, 640, 3)).astype(np.float32))
+
+    def c1():
+        with torch.no_grad():
+            L.get_model_inference(R.detr_forward(img1, Pn), 91)
+    t_c1, n_c1 = best_of(c1, 4)
+
+    # C2: forward + set loss at the metric's shape, batch 1 (batch 8 = 8 x this: images are independent)
+    def c2():
+        with torch.no_grad():
+            L.get_losses(R.detr_forward(img, Pn), tb_t, tc_t, 91)
+    t_c2, n_c2 = best_of(c2, 3)
     opts = {g: O.Adam(lr, clipnorm=0.1) for g, lr in (("backbone", 1e-5), ("transformers", 1e-4), ("nlayers", 1e-4))}
-    n, t0 = 0, time.perf_counter()
-    times = []
-    while True:
-        t1 = time.perf_counter()
+
+    def train():
         P = R.to_torch(params, requires_grad=True)
-        out = R.detr_forward(img, P)
-        total, _ = L.get_losses(out, torch.from_numpy(tb), torch.from_numpy(tc), 91)
+        total, _ = L.get_losses(R.detr_forward(img, P), tb_t, tc_t, 91)
         total.backward()
         grads = {k: P[k].grad.numpy() for k in P if R.trainable(k)}
         for g in opts:
             opts[g].apply({k: v for k, v in grads.items() if O.variable_group(k) == g}, params)
-        times.append(time.perf_counter() - t1)
-        n += 1
-        if n >= 4 or time.perf_counter() - t0 > budget_s:
-            break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps (fwd+set loss+bwd+clip+Adam) at batch 1, {height}x{width}, torch-CPU fp32 "
-                      f"restatement of the TF reference (TF not installable) + SciPy matcher; best step {best:.2f}s"}
+    t_tr, n_tr = best_of(train, 4)
+    return {"value": round(1.0 / t_tr, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_tr} train steps (fwd+set loss+bwd+clip+Adam) at batch 1, {height}x{width}, torch-CPU fp32 restatement of the "
+                      f"TF reference (TF not installable) + SciPy matcher; best step {t_tr:.2f}s",
+            "c1_forward_480x640": {"value": round(1.0 / t_c1, 3), "unit": "images/sec", "latency_ms": round(t_c1 * 1e3, 1),
+                                   "sample": f"best of {n_c1} eval forwards + get_model_inference of one 480x640 image"},
+            "c2_forward_loss": {"value": round(1.0 / t_c2, 4), "unit": "images/sec",
+                                "sample": f"best of {n_c2} forward + set-loss passes at batch 1, {height}x{width} (no backward)"}}
+
+
+def family_tables(prof, ev_steps, precision):
+    """Per-family totals of the HIP-event records + the dominant family + SURVEY 8d's mixed roofline over the instrumented launches."""
+    fam = prof.summary()
+    if not fam:
+        return None, None
+    rows = {}
+    mixed_ms = cov_ms = 0.0
+    for k, v in fam.items():
+        f32 = precision == "fp32" or k.startswith("gemm_f32")
+        peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
+        t_mfma = v["flops"] / (peak * 1e12) * 1e3
+        t_hbm = v["bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3
+        mixed_ms += max(t_mfma, t_hbm)
+        cov_ms += v["ms"]
+        rows[k] = {"ms_per_step": round(v["ms"] / ev_steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "launches_per_step": v["launches"] // ev_steps,
+                   "roofline_ms": round(max(t_mfma, t_hbm) / ev_steps, 3), "bound": "mfma" if t_mfma >= t_hbm else "hbm"}
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    return (fam, dom, rows), {"mixed_ms": mixed_ms / ev_steps, "covered_ms": cov_ms / ev_steps}
+
+
+def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
+    d = fam[dom]
+    tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    f32 = precision == "fp32" or dom.startswith("gemm_f32")
+    peak_tf = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
+    bound = "mfma" if tflops / peak_tf >= gbs / PEAK_HBM_GBS else "hbm"
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", traffic_file)
+    if os.path.exists(tpath):
+        with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
+            tj = json.load(f)
+        if dom in tj.get("per_symbol", {}):
+            traffic = round(tj["per_symbol"][dom]["traffic_bytes_per_launch"])
+            traffic_src = f"profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
+    note = " (all K / layout / epilogue instantiations pooled)" if dom.startswith("gemm_stream") else " (tile sizes pooled)"
+    r = {"bound": bound, "kernel": "detr::" + dom + note,
+         "achieved": round(gbs, 1) if bound == "hbm" else round(tflops, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak_tf,
+         "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+         "frac": round(gbs / PEAK_HBM_GBS if bound == "hbm" else tflops / peak_tf, 4),
+         "traffic": traffic, "traffic_source": traffic_src,
+         "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
+         "tflops": round(tflops, 2), "gbs": round(gbs, 1), "launches_per_step": d["launches"] // ev_steps,
+         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+         "events": f"HIP events on the launch stream around every launch of {ev_steps} eager step(s)", "families": rows}
+    return r
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
     ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
-                    help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 storage/accumulation (config C3)")
+                    help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 accumulation (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the 3 extra fp32-parity-mode steps of a bf16 run")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-parity-mode steps of a bf16 run")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 measurements")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (default: the step is recorded once as a "
                                                            "hipGraph and replayed, exactly as training.fit does)")
@@ -124,6 +209,7 @@ def main():
         raise SystemExit(subprocess.call(cmd))
 
     from detr_tf import _hip, parallel, training
+    from detr_tf.inference import get_model_inference
     from detr_tf.loss.loss import get_losses
     from detr_tf.networks.detr import get_detr_model
     from detr_tf.optimizers import setup_optimizers
@@ -147,54 +233,58 @@ def main():
     cfg.batch_size = args.batch
     cfg.target_batch = None
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
-    model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=args.precision)
-    opt = setup_optimizers(model, cfg)
-    if world > 1 or dist.is_initialized():
-        # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
-        dist.broadcast(model.engine.P.flat, src=0)
-        for raw in model.engine.P.bn_raw.values():
-            dist.broadcast(raw, src=0)
-        model.engine.fold_bn()
-        model.dp = parallel.DataParallel(model.engine.P.grad, model.engine.P.bucket_bounds(), engine=model.engine)
+    use_graph = not args.no_graph
+
+    def build(precision):
+        m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=precision)
+        o = setup_optimizers(m, cfg)
+        if world > 1 or dist.is_initialized():
+            # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
+            dist.broadcast(m.engine.P.flat, src=0)
+            for raw in m.engine.P.bn_raw.values():
+                dist.broadcast(raw, src=0)
+            m.engine.fold_bn()
+            m.dp = parallel.DataParallel(m.engine.P.grad, m.engine.P.bucket_bounds(), engine=m.engine)
+        return m, o, (training.GraphedTrainStep(m, o, cfg) if use_graph else None)
 
     rng = np.random.default_rng(1234 + rank)
     images = torch.from_numpy(rng.normal(size=(args.batch, args.height, args.width, 3)).astype(np.float32)).to(dev)
     tb, tc = make_targets(args.batch, np.random.default_rng(1235 + rank))
     tb, tc = torch.from_numpy(tb).to(dev), torch.from_numpy(tc).to(dev)
-
-    use_graph = not args.no_graph
-    stepper = {}
+    model, opt, stepper = build(args.precision)
 
     def step(i):
         if args.mode == "train":
-            if use_graph and _hip.PROFILER is None:      # (HIP events around single launches need the eager step)
-                if id(model) not in stepper:
-                    stepper.clear()
-                    stepper[id(model)] = training.GraphedTrainStep(model, opt, cfg)
-                out, total, log = stepper[id(model)](images, tb, tc, i)
-            else:
-                out, total, log = training.train_step(model, images, tb, tc, opt, cfg, i)
-            return total
+            if stepper is not None and _hip.PROFILER is None:      # (HIP events around single launches need the eager step)
+                return stepper(images, tb, tc, i)[1]
+            return training.train_step(model, images, tb, tc, opt, cfg, i)[1]
         out = model(images, training=False)
-        total, log = get_losses(out, tb, tc, cfg)
-        return total
+        return get_losses(out, tb, tc, cfg)[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, first=0):
+        barrier()
+        t = time.perf_counter()
+        for i in range(n):
+            last = step(first + i)
+        barrier()
+        return time.perf_counter() - t, last
+
     loss_first = None
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 2 if use_graph else 1)):     # graph mode: one eager step, then the recording pass
         last = step(i)
         if i == 0:
-            loss_first = last          # device scalar: read after the timed region
-    # HIP events around every GEMM / conv launch (roofline leg) cost ~4 us of host time per event (~3.5 ms per step),
-    # so they are recorded in the LAST `event_steps` timed steps only; the other timed steps run uninstrumented.
+            loss_first = last.clone()      # device scalar: read after the timed region
+    # HIP events around every GEMM / conv / attention launch (roofline leg) cost ~4 us of host time per event, so they are
+    # recorded in the LAST `event_steps` timed steps only (which run eagerly); the other timed steps run uninstrumented.
     prof = None
-    ev_steps = 0 if (args.no_kernel_events or rank != 0) else max(1, min(args.event_steps, args.steps))
+    ev_steps = 0 if (args.no_kernel_events or rank != 0 or args.mode != "train") else max(1, min(args.event_steps, args.steps))
     if ev_steps:
-        prof = _hip.KernelProfiler(prealloc=1200 * ev_steps)     # event objects exist before the timed region
+        prof = _hip.KernelProfiler(prealloc=1400 * ev_steps)     # event objects exist before the timed region
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -205,99 +295,102 @@ def main():
     dt = time.perf_counter() - t0
     _hip.PROFILER = None
     loss_val = float(last)
-    # the same step with dropout disabled (SURVEY.md 8d asks for both numbers)
-    value_nodrop = None
-    if args.mode == "train" and args.dropout > 0.0:
-        model.engine.dropout_p = 0.0
-        step(0)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(3):
-            step(i)
-        barrier()
-        value_nodrop = args.batch * world * 3 / (time.perf_counter() - t1)
-        model.engine.dropout_p = args.dropout
-    # fp32 parity mode (exact-f32 MFMA everywhere: the mode the oracle parity tests run in), reported beside the headline
-    value_fp32 = None
-    bf16_loss_dev = None
-    if args.mode == "train" and args.precision == "bf16" and world == 1 and not args.no_fp32_leg:
-        model = opt = None
-        torch.cuda.empty_cache()
-        model = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision="fp32")
-        opt = setup_optimizers(model, cfg)
-        loss_first_fp32 = float(step(0))          # same weights, batch and dropout masks as the first bf16 step
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(3):
-            step(1 + i)
-        barrier()
-        value_fp32 = args.batch * 3 / (time.perf_counter() - t1)
-        if loss_first is not None:
-            bf16_loss_dev = abs(float(loss_first) - loss_first_fp32) / abs(loss_first_fp32)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
+    solo = world == 1 and not dist.is_initialized()
+
+    # ---- the same step with dropout disabled (SURVEY.md 8d asks for both numbers)
+    value_nodrop = None
+    if args.mode == "train" and args.dropout > 0.0 and solo:
+        model.engine.dropout_p = 0.0
+        for i in range(2):
+            step(i)
+        d, _ = timed(3)
+        value_nodrop = args.batch * 3 / d
+        model.engine.dropout_p = args.dropout
+    main_tables = family_tables(prof, ev_steps, args.precision) if prof is not None else (None, None)
+    if prof is not None and args.dump_shapes and rank == 0:
+        with open(args.dump_shapes, "w") as f:
+            json.dump({"steps": ev_steps, "rows": prof.by_shape(80)}, f, indent=1)
+
+    # ---- fp32 parity mode (exact-f32 MFMA everywhere: the reference's precision, the mode of the oracle parity tests)
+    fp32 = None
+    bf16_loss_dev = None
+    if args.mode == "train" and args.precision == "bf16" and solo and not args.no_fp32_leg:
+        model = opt = stepper = None
+        torch.cuda.empty_cache()
+        model, opt, stepper = build("fp32")
+        loss_first_fp32 = float(step(0))          # same weights, batch and dropout masks as the first bf16 step
+        step(1)
+        d, _ = timed(3, first=2)
+        fp32 = {"value": round(args.batch * 3 / d, 3), "unit": "images/sec", "ms_per_step": round(d / 3 * 1e3, 3), "steps": 3,
+                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)"}
+        if not args.no_kernel_events:
+            p32 = _hip.KernelProfiler(prealloc=1400)
+            _hip.PROFILER = p32
+            step(5)
+            torch.cuda.synchronize()
+            _hip.PROFILER = None
+            (fam32, dom32, rows32), mix32 = family_tables(p32, 1, "fp32")
+            fp32["roofline"] = roofline_entry(fam32, dom32, rows32, 1, "fp32", "r02_traffic.json")
+            fp32["step_roofline"] = {"mixed_ms": round(mix32["mixed_ms"], 3), "frac": round(mix32["mixed_ms"] / (d / 3 * 1e3), 4)}
+        if loss_first is not None:
+            bf16_loss_dev = abs(float(loss_first) - loss_first_fp32) / abs(loss_first_fp32)
+
+    # ---- the other single-GPU configs of BASELINE.json
+    configs = None
+    if solo and not args.no_configs and args.mode == "train":
+        configs = {}
+        model = opt = stepper = None
+        torch.cuda.empty_cache()
+        for prec in ("fp32", "bf16"):
+            m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=prec)
+            for _ in range(2):
+                get_losses(m(images, training=False), tb, tc, cfg)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                tot = get_losses(m(images, training=False), tb, tc, cfg)[0]
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t) / 3
+            key = "c2_forward_loss_fp32" if prec == "fp32" else "c2_forward_loss_bf16"
+            configs[key] = {"value": round(args.batch / d, 2), "unit": "images/sec", "ms": round(d * 1e3, 3), "loss": round(float(tot), 5),
+                            "workload": f"DETR-R50 {prec} forward (eval) + set loss 6 levels, batch {args.batch}, {args.height}x{args.width}",
+                            "frac_of_mfma_peak": round(args.batch / d * FWD_GFLOP_PER_IMAGE / 1e3 /
+                                                       (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS), 4)}
+            if prec == "fp32":       # C1: one 480x640 image, eval forward + post-processing (eval.py:41-45)
+                img1 = torch.from_numpy(np.random.default_rng(7).normal(size=(1, 480, 640, 3)).astype(np.float32)).to(dev)
+                for _ in range(2):
+                    get_model_inference(m(img1, training=False), 91)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(5):
+                    get_model_inference(m(img1, training=False), 91)
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t) / 5
+                configs["c1_forward_480x640_fp32"] = {"value": round(1.0 / d1, 1), "unit": "images/sec", "latency_ms": round(d1 * 1e3, 3),
+                                                      "workload": "DETR-R50 fp32 eval forward + get_model_inference, ONE 480x640 image (58.3 GFLOP)"}
+            m = None
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        gflop = STEP_GFLOP_PER_IMAGE if args.mode == "train" else FWD_GFLOP_PER_IMAGE
-        scale = (args.height * args.width) / (800.0 * 1333.0)
-        roofline = None
-        if prof is not None:
-            fam = prof.summary()
-            if args.dump_shapes:
-                with open(args.dump_shapes, "w") as f:
-                    json.dump({"steps": ev_steps, "rows": prof.by_shape(60)}, f, indent=1)
-            if fam:
-                # dominant kernel = the template instantiation (as rocprofv3 names it, tile sizes pooled) with the largest
-                # total time; its average launch duration is directly comparable with profiles/r01_rocprofv3_kernel_stats*.txt
-                dom = max(fam, key=lambda k: fam[k]["ms"])
-                d = fam[dom]
-                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                traffic, traffic_src = None, None
-                tpath = os.path.join(ROOT, "profiles", "r01_traffic_bf16.json" if args.precision == "bf16" else "r01_traffic.json")
-                if os.path.exists(tpath):
-                    with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
-                        tj = json.load(f)
-                    if dom in tj.get("per_symbol", {}):
-                        traffic = round(tj["per_symbol"][dom]["traffic_bytes_per_launch"])
-                        traffic_src = f"profiles/{os.path.basename(tpath)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                gemm_all = {"ms": sum(v["ms"] for k, v in fam.items() if k.startswith("gemm_")),
-                            "launches": sum(v["launches"] for k, v in fam.items() if k.startswith("gemm_")),
-                            "flops": sum(v["flops"] for k, v in fam.items() if k.startswith("gemm_")),
-                            "bytes": sum(v["bytes"] for k, v in fam.items() if k.startswith("gemm_"))}
-                gemm_all_out = {"ms_per_step": round(gemm_all["ms"] / ev_steps, 3), "launches_per_step": gemm_all["launches"] // ev_steps,
-                                "tflops": round(gemm_all["flops"] / (gemm_all["ms"] * 1e-3) / 1e12, 2),
-                                "gbs": round(gemm_all["bytes"] / (gemm_all["ms"] * 1e-3) / 1e9, 1)}
-                if args.precision == "bf16":
-                    # fp32 storage + bf16 MFMA: the GEMM-class kernels are HBM bound -> algorithmic bytes / time
-                    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                    roofline = {"bound": "hbm", "kernel": "detr::" + dom + (" (all K / layout / epilogue instantiations pooled)" if dom.startswith("gemm_stream")
-                                                                  else " (64x64 / 128x128 tiles pooled)"), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                                "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                                "tflops": round(ach, 2), "launches_per_step": d["launches"] // ev_steps,
-                                "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                                "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
-                                "all_gemm_kernels": gemm_all_out,
-                                "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
-                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                                 "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}
-                else:
-                  roofline = {"bound": "mfma", "kernel": "detr::" + dom + " (tile sizes pooled)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                            "traffic_source": traffic_src,
-                            "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
-                            "launches_per_step": d["launches"] // ev_steps,
-                            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                            "events": f"HIP events on the launch stream around every launch of the last {ev_steps} timed step(s)",
-                            "all_gemm_kernels": gemm_all_out,
-                            "families": {k: {"ms_per_step": round(v["ms"] / ev_steps, 3),
-                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                             "launches_per_step": v["launches"] // ev_steps} for k, v in fam.items()}}
+        roofline = step_roofline = None
+        if main_tables[0] is not None:
+            (fam, dom, rows), mix = main_tables
+            roofline = roofline_entry(fam, dom, rows, ev_steps, args.precision,
+                                      "r02_traffic_bf16.json" if args.precision == "bf16" else "r02_traffic.json")
+            step_roofline = {"what": "SURVEY 8d mixed roofline: sum over the instrumented GEMM / conv / attention launches of "
+                                     "max(FLOPs / MFMA peak of the launch's dtype, algorithmic bytes / 8 TB/s)",
+                             "mixed_ms": round(mix["mixed_ms"], 3), "instrumented_kernel_ms": round(mix["covered_ms"], 3),
+                             "ms_per_step": round(ms_per_step, 3), "frac": round(mix["mixed_ms"] / ms_per_step, 4),
+                             "frac_of_bf16_mfma_peak": round(value / world * STEP_GFLOP_PER_IMAGE / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4)
+                             if args.precision == "bf16" else None,
+                             "frac_of_f32_mfma_peak": round(value / world * STEP_GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
+                             if args.precision == "fp32" else None}
         res = {
             "metric": "images/sec training step, DETR-R50 800x1333 bs=8/GPU" if args.mode == "train"
                       else "images/sec forward+set-loss, DETR-R50 800x1333 bs=8/GPU",
@@ -306,15 +399,16 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"DETR-R50 {'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout {args.dropout}",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)",
+                       "launch": "hipGraph replay" if (use_graph and args.mode == "train") else "eager"},
             "loss": round(loss_val, 5),
             "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
-            "images_per_sec_fp32_parity_mode": round(value_fp32, 3) if value_fp32 else None,
+            "fp32": fp32,
+            "images_per_sec_fp32_parity_mode": fp32["value"] if fp32 else None,
             "bf16_vs_fp32_loss_rel_dev_first_step": (float(f"{bf16_loss_dev:.3e}") if bf16_loss_dev is not None else None),
-            "whole_step_fraction_of_f32_mfma_peak": round(value / world * gflop * scale / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
-            "roofline": roofline,
+            "roofline": roofline, "step_roofline": step_roofline, "configs": configs,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and solo:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.height, args.width, threads=args.cpu_threads)
             except Exception as e:          # the baseline is a report, never the product path
@@ -322,7 +416,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -457,8 +457,13 @@ def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_
     d.lse = lse.data_ptr()
     d.scale, d.dropout_p, d.dropout_site, d.dropout_step = scale, dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    prods = 2.0 * B * H * T * S * 32                   # FLOPs of one [T,S,32] product over all (batch, head) problems
+    io = 4.0 * 256 * (2 * B * T + 2 * B * S)           # q, o + k, v rows (fp32), once each
     if d_o is None:
         _check(load().detr_hip_attention_fwd(byref(d), _stream()), "detr_hip_attention_fwd")
+        if ev0 is not None:
+            PROFILER.end("attention_fwd", 2 * prods, ev0, f"B{B} H{H} T{T} S{S}", io)
         return
     for name, ldn, t in (("d_o", "ldd_o", d_o), ("dq", "lddq", dq), ("dk", "lddk", dk), ("dv", "lddv", dv)):
         if t.stride(1) != 1 or t.dtype != torch.float32:
@@ -467,6 +472,8 @@ def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_
         setattr(d, ldn, t.stride(0))
     d.delta = delta.data_ptr()
     _check(load().detr_hip_attention_bwd(byref(d), _stream()), "detr_hip_attention_bwd")
+    if ev0 is not None:      # dQ kernel: S, dP, dQ; dK/dV kernel: S, dP, dV, dK (the probabilities are recomputed twice)
+        PROFILER.end("attention_bwd", 7 * prods, ev0, f"B{B} H{H} T{T} S{S}", 2.5 * io)
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None):

@@ -11,6 +11,7 @@ import time
 
 import torch
 
+from . import _hip as hip
 from .loss.loss import get_losses
 from .optimizers import GROUPS, aggregate_grad_and_apply, gather_gradient
 
@@ -59,10 +60,12 @@ class _Segments:
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs, self.actions = [], []
         self._cur = None
+        self._pad = torch.zeros(4, dtype=torch.int32, device="cuda")
 
     def begin(self):
         self._cur = torch.cuda.CUDAGraph()
         self._cur.capture_begin(pool=self.pool)
+        hip.zero_(self._pad)               # a segment may record nothing else (after the last gradient bucket): never an empty graph
 
     def cut(self, action):
         self._cur.capture_end()

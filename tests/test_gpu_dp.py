@@ -79,3 +79,95 @@ def test_two_rank_dp_equals_single_process_batch(hip):
         assert abs(l0[k] - float(log[k])) < 1e-4 * max(1.0, abs(float(log[k]))), k
     num = np.linalg.norm(g0 - ref)
     assert num < 2e-3 * np.linalg.norm(ref), num / np.linalg.norm(ref)
+
+
+def _rank_job_graph(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    cfg, model, images, t_bbox, t_class = _make()
+    import torch.distributed as dist
+    from detr_tf import parallel, training
+    from detr_tf.optimizers import setup_optimizers
+    parallel.init_distributed(backend="gloo")
+    model.dp = parallel.DataParallel(model.engine.P.grad, model.engine.P.bucket_bounds(), engine=model.engine)
+    assert model.engine.dp_rank == rank
+    opt = setup_optimizers(model, cfg)
+    lo, hi = parallel.shard_batch(2, rank, world)
+    stepper = training.GraphedTrainStep(model, opt, cfg)
+    totals = []
+    for i in range(4):
+        _, total, _ = stepper(images[lo:hi], t_bbox[lo:hi], t_class[lo:hi], i)
+        totals.append(float(total))
+    torch.cuda.synchronize()
+    ret[rank] = (model.engine.P.flat.cpu().numpy(), totals, len(stepper.step_graph.graphs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_graph_replay_equals_single_process_steps(hip):
+    """The recorded step under data parallelism: the graph is cut at the exchange points (loss normalisers, 4 gradient
+    buckets) and the collectives run eagerly between the segments.  4 steps (1 eager + 3 replays) on 2 ranks x 1 image
+    == 4 eager single-process steps on the batch of 2."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_job_graph, args=(2, _free_port(), ret), nprocs=2, join=True)
+    cfg, model, images, t_bbox, t_class = _make()
+    opt = setup_optimizers(model, cfg)
+    p0 = model.engine.P.flat.cpu().numpy().copy()
+    totals = []
+    for i in range(4):
+        _, total, _ = training.train_step(model, images, t_bbox, t_class, opt, cfg, i)
+        totals.append(float(total))
+    torch.cuda.synchronize()
+    ref = model.engine.P.flat.cpu().numpy()
+    f0, t0, nseg0 = ret[0]
+    f1, t1, nseg1 = ret[1]
+    assert nseg0 == nseg1 == 6, (nseg0, nseg1)                 # 1 normaliser cut + 4 bucket cuts -> 6 segments
+    assert np.array_equal(f0, f1), "replicas diverged"
+    assert np.allclose(t0, totals, rtol=1e-4), (t0, totals)
+    d_ref, d_got = ref - p0, f0 - p0
+    assert np.linalg.norm(d_got - d_ref) < 2e-2 * np.linalg.norm(d_ref), np.linalg.norm(d_got - d_ref) / np.linalg.norm(d_ref)
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_forced_single_rank_rccl_path(hip):
+    """bench.py through torch.distributed.run with ONE rank and DETR_DP_FORCE=1: the RCCL (backend "nccl") process group, the
+    parameter broadcast, the normaliser all-reduce and the bucketed gradient all-reduce on the side stream all execute for
+    real (world size 1), inside the segmented hipGraph replay."""
+    import json
+    import sys
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+                    str(_free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--height", "128",
+                    "--width", "160", "--no-cpu-baseline", "--no-fp32-leg", "--no-configs", "--no-kernel-events"],
+                   env_extra={"DETR_DP_FORCE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and np.isfinite(j["loss"]) and j["value"] > 0
+    assert j["config"]["launch"] == "hipGraph replay" and j["config"]["parallelism"] == "dp1"
+
+
+def test_bench_refuses_rank_count_mismatch(hip):
+    """`python bench.py --gpus 2` spawns two ranks itself; on a 1-GPU box that must fail loudly, never print a 1-GPU number
+    labelled n_gpus = 2."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a 1-GPU box")
+    r = _run_bench(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1", "--height", "64", "--width", "96",
+                    "--no-cpu-baseline", "--no-fp32-leg", "--no-configs"], timeout=300)
+    assert r.returncode != 0
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+    assert "only 1 GPU(s) visible" in (r.stderr + r.stdout)
+    # and a launcher world size that contradicts --gpus is refused as well
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+                    str(_free_port()), "bench.py", "--gpus", "4", "--steps", "1", "--warmup", "1"], timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but the process group has 1 rank" in (r.stderr + r.stdout)
