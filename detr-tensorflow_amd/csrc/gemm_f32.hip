@@ -200,12 +200,18 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int bid
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool do_rs = !AK && !A16 && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
+    const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
     float4 rs[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
-    auto rs_add = [&](const typename LA::Reg (&r)[NRA]) {     // every float4 of a thread belongs to the column group 4*ib + c of its tid
+    auto rs_add = [&](const typename LA::Reg (&r)[NRA]) {     // every register of a thread belongs to the column group 4*ib + c of its tid
         if constexpr (!AK && !A16) {
 #pragma unroll
             for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
+        } else if constexpr (!AK && A16) {      // bf16 storage (LoaderMNth: the same unit map as LoaderMNt, 4 bf16 = 4 consecutive rows m)
+#pragma unroll
+            for (int i = 0; i < NRA; ++i) {
+                rs[0].x += bf16_bits_to_f32(r[i].x & 0xFFFFu); rs[0].y += __builtin_bit_cast(float, r[i].x & 0xFFFF0000u);
+                rs[0].z += bf16_bits_to_f32(r[i].y & 0xFFFFu); rs[0].w += __builtin_bit_cast(float, r[i].y & 0xFFFF0000u);
+            }
         }
     };
     // Operand pipeline, two K tiles deep: while tile kt is multiplied out of LDS, tile kt+1 sits in one register set
@@ -458,9 +464,9 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
                                          (d->b_kcontig ? d->K % 8 == 0 : d->N % 4 == 0)),
                      "gemm: a bf16 B operand needs compute = bf16, batch 1, 16-byte alignment, ldb %% 8 == 0 and K %% 8 (N %% 4) == 0");
         DETR_REQUIRE(ea * 4 <= BUF_MAX_BYTES && eb * 4 <= BUF_MAX_BYTES, "gemm: an operand spans more than 4 GB");
-        DETR_REQUIRE(d->a_dtype == 0 || (d->a_dtype == 1 && bf16c && batch == 1 && !d->rowsum_a && ((uintptr_t)d->A % 16 == 0) &&
+        DETR_REQUIRE(d->a_dtype == 0 || (d->a_dtype == 1 && bf16c && batch == 1 && ((uintptr_t)d->A % 16 == 0) &&
                                          (d->a_kcontig ? (d->lda % 8 == 0 && d->K % 8 == 0) : (d->lda % 4 == 0 && d->M % 4 == 0))),
-                     "gemm: a bf16 A operand needs compute = bf16, batch 1, no rowsum_a, 16-byte alignment and K %% 8 (M %% 4) == 0");
+                     "gemm: a bf16 A operand needs compute = bf16, batch 1, 16-byte alignment and K %% 8 (M %% 4) == 0");
         DETR_REQUIRE((d->c_dtype == 0 && d->r_dtype == 0 && d->m_dtype == 0) || (batch == 1 && split == 1),
                      "gemm: bf16 C / residual / mask need batch 1 and no split-K");
     }

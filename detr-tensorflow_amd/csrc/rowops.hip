@@ -12,11 +12,19 @@ namespace detr {
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;
 
+__device__ __forceinline__ unsigned ln_pk_bf16(float a, float b) {      // two RNE roundings (v_cvt_pk_bf16_f32)
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float *__restrict__ y,
                                                             float *__restrict__ mean, float *__restrict__ rstd,
                                                             int rows, int C, float eps, const float *__restrict__ add,
-                                                            int add_rows, float *__restrict__ y2) {
+                                                            int add_rows, float *__restrict__ y2, unsigned short *__restrict__ y16) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int nv = C >> 2;  // float4 per row
@@ -55,6 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
                 o.z = (v[i].z - mu) * rs * g.z + b.z;
                 o.w = (v[i].w - mu) * rs * g.w + b.w;
                 yr[j] = o;
+                if (y16)         // bf16 twin of y: the A operand of the next bf16-compute GEMM (the loader would round it anyway)
+                    reinterpret_cast<uint2 *>(y16 + (long long)row * C)[j] = make_uint2(ln_pk_bf16(o.x, o.y), ln_pk_bf16(o.z, o.w));
                 if (y2) {        // the `+ pos` / `+ query_pos` operand of the next attention block, written while y is in registers
                     const float4 p = reinterpret_cast<const float4 *>(add + (long long)(row % add_rows) * C)[j];
                     reinterpret_cast<float4 *>(y2 + (long long)row * C)[j] = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
@@ -77,7 +87,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             int rows, int C, float *__restrict__ partial,
                                                             const float *__restrict__ dx_add, float *__restrict__ dx_drop,
                                                             float drop_scale, uint32_t drop_thresh, uint32_t drop_site,
-                                                            const uint32_t *__restrict__ drop_step) {
+                                                            const uint32_t *__restrict__ drop_step,
+                                                            unsigned short *__restrict__ dx_drop16) {
     __shared__ float red[2][4][64 * LN_MAXV * 4 / 4];  // [gamma|beta][wave][C] ; C <= 1024 -> see below
     // (partial sums are kept per lane in registers and reduced through LDS at the end)
     const int lane = threadIdx.x & 63;
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         pg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const uint32_t dkey = dx_drop ? drop_key(drop_site, drop_step) : 0u;
+    const bool want_drop = dx_drop != nullptr || dx_drop16 != nullptr;
+    const uint32_t dkey = (want_drop && drop_scale != 0.0f) ? drop_key(drop_site, drop_step) : 0u;
     for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
         const float4 *xr = reinterpret_cast<const float4 *>(x + (long long)row * C);
         const float4 *dr = reinterpret_cast<const float4 *>(dy + (long long)row * C);
@@ -131,15 +143,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                     o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
                 }
                 oxr[j] = o;
-                if (dx_drop) {   // gradient through the dropout that precedes the residual add (same mask as the forward GEMM epilogue)
-                    const unsigned long long di = (unsigned long long)row * C + 4 * j;      // even: two hashes serve the four elements
-                    const uint32_t h0 = drop_hash(dkey, di >> 1), h1 = drop_hash(dkey, (di >> 1) + 1);
-                    float4 d;
-                    d.x = (h0 & 0xFFFFu) >= drop_thresh ? o.x * drop_scale : 0.0f;
-                    d.y = (h0 >> 16) >= drop_thresh ? o.y * drop_scale : 0.0f;
-                    d.z = (h1 & 0xFFFFu) >= drop_thresh ? o.z * drop_scale : 0.0f;
-                    d.w = (h1 >> 16) >= drop_thresh ? o.w * drop_scale : 0.0f;
-                    reinterpret_cast<float4 *>(dx_drop + (long long)row * C)[j] = d;
+                if (want_drop) { // gradient through the dropout that precedes the residual add (same mask as the forward GEMM epilogue)
+                    float4 d = o;
+                    if (drop_scale != 0.0f) {
+                        const unsigned long long di = (unsigned long long)row * C + 4 * j;      // even: two hashes serve the four elements
+                        const uint32_t h0 = drop_hash(dkey, di >> 1), h1 = drop_hash(dkey, (di >> 1) + 1);
+                        d.x = (h0 & 0xFFFFu) >= drop_thresh ? o.x * drop_scale : 0.0f;
+                        d.y = (h0 >> 16) >= drop_thresh ? o.y * drop_scale : 0.0f;
+                        d.z = (h1 & 0xFFFFu) >= drop_thresh ? o.z * drop_scale : 0.0f;
+                        d.w = (h1 >> 16) >= drop_thresh ? o.w * drop_scale : 0.0f;
+                    }
+                    if (dx_drop) reinterpret_cast<float4 *>(dx_drop + (long long)row * C)[j] = d;
+                    if (dx_drop16)   // bf16 twin (the gradient only feeds bf16-compute GEMM operands)
+                        reinterpret_cast<uint2 *>(dx_drop16 + (long long)row * C)[j] = make_uint2(ln_pk_bf16(d.x, d.y), ln_pk_bf16(d.z, d.w));
                 }
             }
         }
@@ -405,9 +421,10 @@ extern "C" int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream
     DETR_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV && rows > 0, "layernorm fwd: C=%d rows=%d unsupported", C, rows);
     DETR_REQUIRE(aligned16(d->x) && aligned16(d->y) && aligned16(d->gamma) && aligned16(d->beta), "layernorm fwd: alignment");
     if (d->y2) DETR_REQUIRE(d->add && d->add_rows > 0 && aligned16(d->add) && aligned16(d->y2), "layernorm fwd: y2 needs add / add_rows (16-byte aligned)");
+    if (d->y16) DETR_REQUIRE((reinterpret_cast<uintptr_t>(d->y16) & 7) == 0, "layernorm fwd: y16 must be 8-byte aligned");
     const int grid = min(cdiv(rows, 4), 4096);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->x, d->gamma, d->beta, d->y, d->mean,
-                       d->rstd, rows, C, d->eps, d->add, d->add_rows, d->y2);
+                       d->rstd, rows, C, d->eps, d->add, d->add_rows, d->y2, d->y16);
     DETR_LAUNCH_CHECK("layernorm fwd");
     return 0;
 }
@@ -419,9 +436,10 @@ extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream
     DETR_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma), "layernorm bwd: alignment");
     if (d->dx_add) DETR_REQUIRE(aligned16(d->dx_add), "layernorm bwd: dx_add alignment");
     float drop_scale = 0.0f;
-    if (d->dx_drop) {
-        DETR_REQUIRE(aligned16(d->dx_drop) && d->dropout_p > 0.0f && d->dropout_p < 1.0f, "layernorm bwd: dx_drop needs 0 < p < 1 (16-byte aligned)");
-        drop_scale = 1.0f / (1.0f - d->dropout_p);
+    if (d->dx_drop || d->dx_drop16) {
+        DETR_REQUIRE((!d->dx_drop || aligned16(d->dx_drop)) && (reinterpret_cast<uintptr_t>(d->dx_drop16) & 7) == 0 &&
+                     d->dropout_p >= 0.0f && d->dropout_p < 1.0f, "layernorm bwd: dx_drop needs 0 <= p < 1 and aligned outputs");
+        drop_scale = d->dropout_p > 0.0f ? 1.0f / (1.0f - d->dropout_p) : 0.0f;      // p = 0: plain copies of dx
     }
     const int grid = min(cdiv(rows, 8), 512);
     // with a workspace of grid*2*C floats the gamma / beta gradients are reduced deterministically (per-block partials +
@@ -429,7 +447,7 @@ extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream
     float *partial = (d->workspace && d->workspace_bytes >= (long long)grid * 2 * C * 4) ? d->workspace : nullptr;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->gamma, d->mean, d->rstd,
                        d->dx, d->dgamma, d->dbeta, rows, C, partial, d->dx_add, d->dx_drop, drop_scale, drop_thresh16(d->dropout_p),
-                       d->dropout_site, d->dropout_step);
+                       d->dropout_site, d->dropout_step, d->dx_drop16);
     DETR_LAUNCH_CHECK("layernorm bwd");
     if (partial) {
         hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, grid,

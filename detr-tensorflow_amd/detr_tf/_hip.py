@@ -49,11 +49,12 @@ class AttnDesc(Structure):
 class LayerNormDesc(Structure):
     _fields_ = [("rows", c_int32), ("C", c_int32), ("eps", c_float),
                 ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("y", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
-                ("add", c_void_p), ("add_rows", c_int32), ("y2", c_void_p),
+                ("add", c_void_p), ("add_rows", c_int32), ("y2", c_void_p), ("y16", c_void_p),
                 ("dy", c_void_p), ("dx", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dx_add", c_void_p),
-                ("dx_drop", c_void_p), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p)]
+                ("dx_drop", c_void_p), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p),
+                ("dx_drop16", c_void_p)]
 
 
 class StemDesc(Structure):
@@ -476,17 +477,18 @@ def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_
         PROFILER.end("attention_bwd", 7 * prods, ev0, f"B{B} H{H} T{T} S{S}", 2.5 * io)
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None, y16=None):
     d = LayerNormDesc()
     d.rows, d.C, d.eps = x.shape[0], x.shape[1], eps
     d.x, d.gamma, d.beta, d.y, d.mean, d.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     if y2 is not None:
         d.add, d.add_rows, d.y2 = add.data_ptr(), add.shape[0], y2.data_ptr()
+    d.y16 = ptr(y16)
     _check(load().detr_hip_layernorm_fwd(byref(d), _stream()), "detr_hip_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, dx_drop=None, dropout_p=0.0, dropout_site=0,
-                  dropout_step=None):
+                  dropout_step=None, dx_drop16=None):
     d = LayerNormDesc()
     d.rows, d.C = x.shape[0], x.shape[1]
     d.dy, d.x, d.gamma, d.mean, d.rstd = dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
@@ -494,8 +496,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, d
     if WORKSPACE is not None:                                       # deterministic gamma / beta reduction
         d.workspace, d.workspace_bytes = WORKSPACE.data_ptr(), WORKSPACE.numel() * 4
     d.dx_add = ptr(dx_add)
-    if dx_drop is not None:
-        d.dx_drop, d.dropout_p, d.dropout_site, d.dropout_step = dx_drop.data_ptr(), dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
+    if dx_drop is not None or dx_drop16 is not None:
+        d.dx_drop, d.dx_drop16 = ptr(dx_drop), ptr(dx_drop16)
+        d.dropout_p, d.dropout_site, d.dropout_step = dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
     _check(load().detr_hip_layernorm_bwd(byref(d), _stream()), "detr_hip_layernorm_bwd")
 
 

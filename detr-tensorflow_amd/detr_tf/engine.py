@@ -220,24 +220,31 @@ class DetrEngine:
         hip.call("detr_hip_colsum_f32", x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], x2d.stride(0),
                  c_float(alpha))
 
-    def _ln_fwd(self, x, pfx, y, tag, add=None, y2=None):
+    def _ln_fwd(self, x, pfx, y, tag, add=None, y2=None, y16=None):
         """LayerNormalization(eps 1e-5) transformer.py:151-152; optional fused y2 = y + add[r % rows(add)] -- the
-        `+ pos` / `+ query_pos` operand of the next attention block (transformer.py:161-163,209,219)."""
+        `+ pos` / `+ query_pos` operand of the next attention block (transformer.py:161-163,209,219); optional bf16 twin."""
         rows = x.shape[0]
         mean = self.buf(f"{tag}:mean", (rows,))
         rstd = self.buf(f"{tag}:rstd", (rows,))
-        hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2)
+        hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2,
+                          y16=y16)
 
-    def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None):
+    def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None, want16=False):
         """Backward of _ln_fwd w.r.t. x (+ dx_add).  drop_site: also return dropout_bwd(dx) -- the gradient through the
-        Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the same launch."""
+        Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the same launch.
+        want16: that second output as bf16 (it only feeds GEMM operands of the bf16-compute FFN backward)."""
         dp, _ = self._drop
-        dx_drop = None
-        if drop_site is not None and dp > 0.0:
-            dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}", dx.shape)
+        dx_drop = dx_drop16 = None
+        if drop_site is not None:
+            if want16:
+                dx_drop16 = self.buf(f"scratch:drop16:{dx.shape[0]}", dx.shape, torch.bfloat16)
+            elif dp > 0.0:
+                dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}", dx.shape)
         hip.layernorm_bwd(dy, x, self.P.views[f"{pfx}/gamma"], self._bufs[f"{tag}:mean"], self._bufs[f"{tag}:rstd"], dx,
                           self.P.gviews[f"{pfx}/gamma"], self.P.gviews[f"{pfx}/beta"], dx_add=dx_add, dx_drop=dx_drop,
-                          dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev)
+                          dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev, dx_drop16=dx_drop16)
+        if dx_drop16 is not None:
+            return dx_drop16
         return dx if dx_drop is None else dx_drop
 
     def _add_bcast(self, x, p, out):
@@ -292,28 +299,35 @@ class DetrEngine:
         elif calls:
             hip.gemm_group(calls)
 
-    def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0):
+    # bf16 compute mode: the tensors that ONLY feed GEMM operands of the FFN -- its input twin x16 (written by the LayerNorm
+    # that produces x), the hidden activation h, its gradient dh and the incoming gradient twin d_y16 (written by the
+    # LayerNorm backward) -- are STORED in bf16: the loaders would round them anyway (bit-identical products), the two
+    # [rows, 2048] tensors move half the bytes, and both weight gradients become one grouped launch of the all-bf16 variant.
+    @property
+    def ffn16(self):
+        return self.compute == 1 and H16
+
+    def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0, x16=None):
         V = self.P.views
         dp, _ = self._drop
-        # the hidden activation feeds only GEMM operands (rounded to bf16 there anyway): bf16 STORAGE in bf16 compute
-        # mode is bit-identical and halves the traffic of the four GEMMs that touch it
-        h = self.buf(f"{tag}:h", (x.shape[0], FF), torch.bfloat16 if (self.compute == 1 and H16) else torch.float32)
-        hip.linear_fwd(x, self._w(f"{pfx}/linear1/kernel"), V[f"{pfx}/linear1/bias"], h, act=1, dropout_p=dp,
-                       dropout_seed=seed, dropout_step=self._seed_dev)                 # :172-174
+        h = self.buf(f"{tag}:h", (x.shape[0], FF), torch.bfloat16 if self.ffn16 else torch.float32)
+        hip.linear_fwd(x16 if x16 is not None else x, self._w(f"{pfx}/linear1/kernel"), V[f"{pfx}/linear1/bias"], h, act=1,
+                       dropout_p=dp, dropout_seed=seed, dropout_step=self._seed_dev)    # :172-174
         hip.linear_fwd(h, self._w(f"{pfx}/linear2/kernel"), V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
                        dropout_seed=seed + 1, dropout_step=self._seed_dev)             # :175-176
 
-    def _ffn_bwd(self, tag, pfx, d_y, d_f, x, dx):
+    def _ffn_bwd(self, tag, pfx, d_y, d_f, x, dx, x16=None):
         """d_f: grad of (drop(linear2(drop(relu(linear1(x))))) + x); d_y = dropout_bwd(d_f) (from the LayerNorm backward
-        launch); dx = full gradient w.r.t. x."""
+        launch; bf16 in bf16 compute mode); dx = full gradient w.r.t. x."""
         G = self.P.gviews
         h = self._bufs[f"{tag}:h"]                 # post-ReLU, post-dropout hidden activation
         dp, _ = self._drop
-        dh = self.buf(f"scratch:dh:{h.shape[0]}", h.shape)
+        dh = self.buf(f"scratch:dh:{h.shape[0]}:{int(self.ffn16)}", h.shape, torch.bfloat16 if self.ffn16 else torch.float32)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
         hip.linear_dgrad(d_y, self._w(f"{pfx}/linear2/kernel"), dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
         hip.gemm_group([hip.linear_wgrad_call(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"]),
-                        hip.linear_wgrad_call(dh, x, G[f"{pfx}/linear1/kernel"], bias_grad=G[f"{pfx}/linear1/bias"])])
+                        hip.linear_wgrad_call(dh, x16 if x16 is not None else x, G[f"{pfx}/linear1/kernel"],
+                                              bias_grad=G[f"{pfx}/linear1/bias"])])
         hip.linear_dgrad(dh, self._w(f"{pfx}/linear1/kernel"), dx, residual=d_f)
 
     # ---- layer-invariant decoder cross-attention K / V (transformer.py:221-223: memory is the same for every layer) ------
@@ -450,9 +464,10 @@ class DetrEngine:
             a = self.buf(f"{tag}:a", (B * L, D))
             self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, x, B, L, a, site=16 * i)
             x1 = self.buf(f"{tag}:x1", (B * L, D))
-            self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1")
+            x1h = self.buf(f"{tag}:x1h", (B * L, D), torch.bfloat16) if self.ffn16 else None
+            self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1", y16=x1h)
             f = self.buf(f"{tag}:f", (B * L, D))
-            self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2)
+            self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2, x16=x1h)
             x2 = self.buf(f"{tag}:x2", (B * L, D))
             # x2 + pos = the q / k input of the next layer, or `memory + pos` of the decoder (:219), in the same launch
             qk = self.buf(f"enc{i + 1}:qk" if i + 1 < self.num_enc else "dec:mem_pos", (B * L, D))
@@ -498,9 +513,10 @@ class DetrEngine:
             hip.linear_fwd(Oc, self._w(f"{cp}/out_proj_kernel"), V[f"{cp}/out_proj_bias"], a2, residual=t1, dropout_p=dp,
                            dropout_seed=ds + 3, dropout_step=self._seed_dev)              # :226
             t2 = self.buf(f"{tag}:t2", (B * Q, D))
-            self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2")
+            t2h = self.buf(f"{tag}:t2h", (B * Q, D), torch.bfloat16) if self.ffn16 else None
+            self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2", y16=t2h)
             f = self.buf(f"{tag}:f", (B * Q, D))
-            self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4)
+            self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4, x16=t2h)
             t3 = self.buf(f"{tag}:t3", (B * Q, D))
             if i + 1 < nd:
                 qin = self.buf(f"dec{i + 1}:qin", (B * Q, D))
@@ -605,9 +621,9 @@ class DetrEngine:
             d_t3 = self.buf("scratch:d_t3", (BQ, D))
             self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf", dx_add=d_next)
             d_f = self.buf("scratch:d_f", (BQ, D))
-            d_y = self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5)
+            d_y = self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5, want16=self.ffn16)
             d_t2 = self.buf("scratch:d_t2", (BQ, D))
-            self._ffn_bwd(tag, pfx, d_y, d_f, t2, d_t2)
+            self._ffn_bwd(tag, pfx, d_y, d_f, t2, d_t2, x16=self._bufs.get(f"{tag}:t2h") if self.ffn16 else None)
             d_a2 = self.buf("scratch:d_a2", (BQ, D))
             d_out = self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2", drop_site=ds + 3)
             # ---- cross attention
@@ -649,9 +665,9 @@ class DetrEngine:
             x_in = self._bufs[f"enc{i - 1}:x2"] if i > 0 else self._bufs["enc:src0"]
             qk, a, x1, f = (self._bufs[f"{tag}:{n}"] for n in ("qk", "a", "x1", "f"))
             d_f = self.buf("scratch:e_d_f", (B * L, D))
-            d_y = self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2", drop_site=16 * i + 3)
+            d_y = self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2", drop_site=16 * i + 3, want16=self.ffn16)
             d_x1 = self.buf("scratch:e_d_x1", (B * L, D))
-            self._ffn_bwd(tag, pfx, d_y, d_f, x1, d_x1)
+            self._ffn_bwd(tag, pfx, d_y, d_f, x1, d_x1, x16=self._bufs.get(f"{tag}:x1h") if self.ffn16 else None)
             d_a = self.buf("scratch:e_d_a", (B * L, D))
             d_out = self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1", drop_site=16 * i + 1)
             d_xn = self.buf(f"scratch:e_d_x{i & 1}", (B * L, D))

@@ -214,6 +214,7 @@ typedef struct {
     /* fwd, optional fused second output  y2[r] = y[r] + add[r % add_rows]  -- the `src + pos` / `tgt + query_pos`
      * operand of the NEXT attention block (transformer.py:161-163,209,219), written while y is still in registers */
     const float *add; int32_t add_rows; float *y2;
+    uint16_t *y16;                  /* fwd, optional: bf16 (RNE) twin of y -- the A operand of the next bf16-compute GEMM */
     /* bwd */
     const float *dy; float *dx; float *dgamma, *dbeta;     /* dgamma / dbeta are ACCUMULATED */
     /* dgamma/dbeta reduction: deterministic (per-block partials in `workspace` + a finish launch) when the workspace
@@ -224,6 +225,7 @@ typedef struct {
      * Dropout that precedes the residual add in front of this LayerNorm (transformer.py:169,176,215,226,232), i.e. the
      * mask of the forward GEMM epilogue regenerated on the gradient (element index row*C + col) */
     float *dx_drop; float dropout_p; uint32_t dropout_site; const uint32_t *dropout_step;
+    uint16_t *dx_drop16;            /* optional bf16 twin of dx_drop (dropout_p = 0: of dx) */
 } detr_layernorm_desc;
 int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream);
 int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);

@@ -16,7 +16,7 @@ for w in "$@"; do
     bench_quick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --dump-shapes $OUT/shapes.json > $OUT/bench_quick.log 2>&1; echo "bench_quick rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_quick.log | cut -c1-2500 ;;
     bench_eager) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-graph --no-kernel-events > $OUT/bench_eager.log 2>&1; echo "bench_eager rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_eager.log | cut -c1-600 ;;
     bench_f32) timeout 600 python bench.py --steps 5 --warmup 2 --precision fp32 --no-cpu-baseline --dump-shapes $OUT/shapes_f32.json > $OUT/bench_f32.log 2>&1; echo "bench_f32 rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_f32.log | cut -c1-800 ;;
-    prof16) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt
+    prof16) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt
           python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 > $OUT/prof16_summary.txt 2>&1; head -70 $OUT/prof16_summary.txt ;;
     *) echo "unknown $w" ;;
   esac

@@ -163,6 +163,44 @@ def test_gemm_fused_rowsum_bias_gradient(hip, M, N, K, sk, compute):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "must be deterministic"
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(256, 2048, 8400, 8), (2048, 256, 8400, 8), (256, 256, 800, 6), (512, 256, 801, 1)])
+def test_gemm_fused_rowsum_with_bf16_stored_operands(hip, M, N, K, sk):
+    """The same fused bias gradient when the A operand (dy) and / or the B operand (x) are STORED in bf16 (the FFN tensors
+    of the bf16 transformer: LoaderMNth shares LoaderMNt's unit map): dW from the bf16 values, db = fp32 sum of them."""
+    torch.manual_seed(M + N + K)
+    dy16, x16 = torch.randn(K, M).to(torch.bfloat16), torch.randn(K, N).to(torch.bfloat16)
+    ws = torch.empty(16 * 1024 * 1024, device=DEV)
+    ref_w = dy16.double().t() @ x16.double()
+    ref_b = dy16.double().sum(0)
+    for a16, b16 in ((True, True), (True, False), (False, True)):
+        A = g(dy16 if a16 else dy16.float())
+        Bm = g(x16 if b16 else x16.float())
+        outs = []
+        for rep in range(2):
+            dw, db = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
+            kw = dict(split_k=sk) if sk > 1 else dict(residual=dw, ldr=N)
+            hip.gemm(M, N, K, A, M, 0, Bm, N, 0, dw, N, workspace=ws, compute=1, rowsum_a=db, **kw)
+            outs.append((dw.clone(), db.clone()))
+        close(outs[0][0], ref_w, rtol=5e-5, what=f"bf16-stored wgrad a16={a16} b16={b16}")
+        close(outs[0][1], ref_b, rtol=2e-5, what=f"bf16-stored bias gradient a16={a16} b16={b16}")
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and through the grouped launch the engine uses for the two FFN weight gradients
+    dws = [torch.zeros(M, N, device=DEV), torch.zeros(N, M, device=DEV)]
+    dbs = [torch.zeros(M, device=DEV), torch.zeros(N, device=DEV)]
+    hip.ensure_workspace(DEV)
+    old = hip.COMPUTE_BF16
+    hip.COMPUTE_BF16 = 1
+    try:
+        hip.gemm_group([hip.linear_wgrad_call(g(dy16), g(x16), dws[0], bias_grad=dbs[0]),
+                        hip.linear_wgrad_call(g(x16), g(dy16), dws[1], bias_grad=dbs[1])])
+    finally:
+        hip.COMPUTE_BF16 = old
+    close(dws[0], ref_w, rtol=5e-5, what="grouped bf16-stored wgrad 0")
+    close(dws[1], ref_w.t(), rtol=5e-5, what="grouped bf16-stored wgrad 1")
+    close(dbs[0], ref_b, rtol=2e-5, what="grouped bf16-stored bias gradient 0")
+    close(dbs[1], x16.double().sum(0), rtol=2e-5, what="grouped bf16-stored bias gradient 1")
+
+
 def test_gemm_batched_attention_layout(hip):
     """scores[b,h] = Q_h K_h^T and O = P V_h on the [B, L, heads*32] layout used by the transformer."""
     torch.manual_seed(4)
@@ -791,10 +829,12 @@ def test_layernorm_fused_outputs(hip, rows, C, period):
     xd, gd, bd, addd = g(x), g(gam), g(bet), g(add)
     yd, y2d = torch.zeros(rows, C, device=DEV), torch.zeros(rows, C, device=DEV)
     mean, rstd = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
-    hip.layernorm_fwd(xd, gd, bd, yd, mean, rstd, 1e-5, add=addd, y2=y2d)
+    y16 = torch.zeros(rows, C, device=DEV, dtype=torch.bfloat16)
+    hip.layernorm_fwd(xd, gd, bd, yd, mean, rstd, 1e-5, add=addd, y2=y2d, y16=y16)
     yref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
     close(yd, yref, rtol=1e-5, what="layernorm fwd")
     assert torch.equal(y2d, yd + addd.repeat(rows // period, 1))
+    assert torch.equal(y16, yd.to(torch.bfloat16))                      # RNE twin of y
     dy, extra = torch.randn(rows, C), torch.randn(rows, C)
     p, site, step = 0.1, 1234, 0x0BADF00D
     stepd = torch.tensor([step] + [0] * 7, dtype=torch.int32, device=DEV)
@@ -806,6 +846,12 @@ def test_layernorm_fused_outputs(hip, rows, C, period):
     close(dx1, dx0.cpu().double() + extra.double(), rtol=1e-6, what="layernorm dx + dx_add")
     keep = torch.from_numpy(DR.keep_mask(DR.drop_key(site, step), np.arange(rows * C).reshape(rows, C), p)).to(DEV)
     assert bool((dxdrop[~keep] == 0).all())
+    d16, dx2 = torch.zeros(rows, C, device=DEV, dtype=torch.bfloat16), torch.zeros(rows, C, device=DEV)
+    hip.layernorm_bwd(g(dy), xd, gd, mean, rstd, dx2, dg, db, dx_add=g(extra), dx_drop16=d16, dropout_p=p, dropout_site=site,
+                      dropout_step=stepd)
+    assert torch.equal(dx2, dx1) and torch.equal(d16, dxdrop.to(torch.bfloat16))
+    hip.layernorm_bwd(g(dy), xd, gd, mean, rstd, dx2, dg, db, dx_drop16=d16, dropout_p=0.0)     # p = 0: a plain bf16 copy of dx
+    assert torch.equal(d16, dx0.to(torch.bfloat16))
     close(dxdrop, torch.where(keep, dx1 / (1.0 - p), torch.zeros_like(dx1)).cpu().double(), rtol=1e-6, what="layernorm dx_drop")
 
 

@@ -442,7 +442,11 @@ def test_c1_single_480x640_image_forward_and_inference(hip):
         # random-init logits never pick the background class: shift its bias so that about half of the queries are
         # background (the bias is additive, so the oracle's logits shift by the same amount)
         lg = ref["pred_logits"][0]
-        delta = float(torch.median(lg[:, :91].max(-1).values - lg[:, 91]))
+        gaps = torch.sort(lg[:, :91].max(-1).values - lg[:, 91]).values          # shift needed per query to turn it into background
+        mid = gaps[40:61]
+        k = int(torch.argmax(mid[1:] - mid[:-1]))                                 # the widest gap near the median: no query sits on the fence
+        delta = float((mid[k] + mid[k + 1]) / 2)
+        assert float(mid[k + 1] - mid[k]) > 1e-4 * float(lg.abs().max())
         params["class_embed/bias"] = params["class_embed/bias"].copy()
         params["class_embed/bias"][91] += np.float32(delta)
         ref = R.detr_forward(torch.from_numpy(image), R.to_torch(params))

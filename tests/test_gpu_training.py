@@ -122,40 +122,39 @@ def test_fit_gradient_accumulation_applies_every_target_batch(hip):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_graph_replay_equals_eager_steps(hip, precision):
-    """The hipGraph replay of the training step (dropout 0.1: new masks every step from the device-resident seed; Adam
-    step sizes from device memory; derived weight copies rebuilt inside the graph) reproduces the eager steps: same
-    losses at every step and the same parameters / Adam moments after 5 steps, to rounding."""
+    """The hipGraph replay of the training step reproduces the eager step: with dropout 0.1 (new masks every step from the
+    device-resident seed), Adam step sizes from device memory and the derived weight copies rebuilt inside the graph.
+    Both models start every step from the SAME state (the eager model's parameters and Adam moments are copied over:
+    the set-loss sums use fp32 atomics, and Hungarian matching of a near-degenerate random-init cost matrix amplifies that
+    rounding noise into different assignments within a few steps), then the logits must agree to rounding, the loss to
+    1e-5 and the parameter update in relative L2."""
     from detr_tf import training
     from detr_tf.optimizers import setup_optimizers
     data = _batches(5, seed=3)
-    results = {}
-    for mode in ("eager", "graph"):
-        cfg = _cfg()
-        model = _model(cfg, precision=precision)
-        opt = setup_optimizers(model, cfg)
-        losses = []
-        if mode == "eager":
-            for i, (im, tb, tc) in enumerate(data):
-                _, total, log = training.train_step(model, im, tb, tc, opt, cfg, i)
-                losses.append((float(total), float(log["giou_loss_0"])))
-        else:
-            stepper = training.GraphedTrainStep(model, opt, cfg, eager_steps=1)
-            for i, (im, tb, tc) in enumerate(data):
-                _, total, log = stepper(im, tb, tc, i)
-                losses.append((float(total), float(log["giou_loss_0"])))
-            assert stepper.step_graph is not None and len(stepper.step_graph.graphs) == 1
-        torch.cuda.synchronize()
-        results[mode] = (losses, model.engine.P.flat.clone(), model.engine.P.adam_v.clone())
-    # (not bit for bit: the set-loss sums are accumulated with fp32 atomics, so two runs of the SAME mode differ in the
-    #  last bits as well)
-    for (te, ge), (tg, gg) in zip(results["eager"][0], results["graph"][0]):
-        assert abs(te - tg) <= 1e-5 * abs(te) and abs(ge - gg) <= 1e-5 * abs(ge), (results["eager"][0], results["graph"][0])
-    p0 = _model(_cfg(), precision=precision).engine.P.flat
-    de, dg = results["eager"][1] - p0, results["graph"][1] - p0
-    assert float((de - dg).abs().max()) <= 2e-3 * float(de.abs().max()), (float((de - dg).abs().max()), float(de.abs().max()))
-    assert float((results["eager"][2] - results["graph"][2]).abs().max()) <= 1e-3 * float(results["eager"][2].abs().max())
-    l = [x[0] for x in results["graph"][0]]
-    assert len(set(l)) == 5                                     # five different batches / masks: nothing was replayed stale
+    cfg_e, cfg_g = _cfg(), _cfg()
+    m_e, m_g = _model(cfg_e, precision=precision), _model(cfg_g, precision=precision)
+    o_e, o_g = setup_optimizers(m_e, cfg_e), setup_optimizers(m_g, cfg_g)
+    stepper = training.GraphedTrainStep(m_g, o_g, cfg_g, eager_steps=1)
+    losses = []
+    for i, (im, tb, tc) in enumerate(data):
+        for src, dst in ((m_e.engine.P.flat, m_g.engine.P.flat), (m_e.engine.P.adam_m, m_g.engine.P.adam_m),
+                         (m_e.engine.P.adam_v, m_g.engine.P.adam_v)):
+            dst.copy_(src)
+        m_g.engine.weights_dirty = True
+        before = m_e.engine.P.flat.clone()
+        out_e, tot_e, log_e = training.train_step(m_e, im, tb, tc, o_e, cfg_e, i)
+        lg_e = out_e["pred_logits"].clone()
+        out_g, tot_g, log_g = stepper(im, tb, tc, i)
+        lg_g = out_g["pred_logits"].clone()
+        assert m_e.engine._drop == m_g.engine._drop and m_e.engine._drop[0] == pytest.approx(0.1)
+        assert float((lg_e - lg_g).abs().max()) <= 1e-5 * float(lg_e.abs().max()), (i, float((lg_e - lg_g).abs().max()))
+        assert abs(float(tot_e) - float(tot_g)) <= 1e-5 * abs(float(tot_e)), (i, float(tot_e), float(tot_g))
+        assert abs(float(log_e["giou_loss_0"]) - float(log_g["giou_loss_0"])) <= 1e-5
+        de, dg = m_e.engine.P.flat - before, m_g.engine.P.flat - before
+        assert float((de - dg).norm()) <= 2e-2 * float(de.norm()), (i, float((de - dg).norm()) / float(de.norm()))
+        losses.append(float(tot_g))
+    assert stepper.step_graph is not None and len(stepper.step_graph.graphs) == 1 and stepper.calls == 5
+    assert len(set(losses)) == 5 and losses[-1] < losses[0]      # five different batches / masks, and it trains
 
 
 def test_graph_falls_back_on_new_shape_and_eval_sees_new_weights(hip):
