@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void sumsq_segments_kernel(const float *__rest
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(sumsq + t, (red[0] + red[1]) + (red[2] + red[3]));
+    // one partial per chunk, plain store: the per-tensor sum is formed in a FIXED order by clip_adam_kernel, so that every
+    // data-parallel replica (and every replay) clips with bit-identical norms -- fp32 atomics here made replicas drift by ulps
+    if (threadIdx.x == 0) sumsq[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ param, const float *__restrict__ g,
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ para
                                                         const long long *__restrict__ seg_end,
                                                         const int *__restrict__ tensor_group,
                                                         const float *__restrict__ sumsq,
-                                                        const float *__restrict__ hyper, int chunk) {
+                                                        const float *__restrict__ hyper, int chunk, int n_chunks) {
     const int c = blockIdx.x;
     const int t = chunk_tensor[c];
     const long long s0 = chunk_start[c];
@@ -48,7 +50,24 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float *__restrict__ para
     // tf.clip_by_norm: g * clip / max(||g||, clip)   (clip <= 0 disables)
     float cs = 1.0f;
     if (clip > 0.f) {
-        const float nrm = sqrtf(sumsq[t]);
+        // the chunks of tensor t are consecutive: [lo, hi) by binary search, partials summed in a fixed order
+        __shared__ int s_lo, s_hi;
+        __shared__ float s_red[4];
+        if (threadIdx.x == 0) {
+            int a = 0, b = c;                      // first index with chunk_tensor >= t  (chunk_tensor[c] == t)
+            while (a < b) { const int mid = (a + b) >> 1; if (chunk_tensor[mid] < t) a = mid + 1; else b = mid; }
+            s_lo = a;
+            a = c; b = n_chunks;                   // first index with chunk_tensor > t
+            while (a < b) { const int mid = (a + b) >> 1; if (chunk_tensor[mid] <= t) a = mid + 1; else b = mid; }
+            s_hi = a;
+        }
+        __syncthreads();
+        float acc = 0.f;
+        for (int k = s_lo + (int)threadIdx.x; k < s_hi; k += blockDim.x) acc += sumsq[k];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        const float nrm = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
         cs = clip / fmaxf(nrm, clip);
     }
     for (long long i = s0 + threadIdx.x; i < s1; i += blockDim.x) {
@@ -100,7 +119,7 @@ extern "C" int detr_hip_clip_adam_f32(float *param, const float *g, float *m, fl
     DETR_REQUIRE(n_chunks > 0 && chunk > 0, "clip_adam: bad chunking");
     hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, param, g, m, v, chunk_tensor,
                        reinterpret_cast<const long long *>(chunk_start), reinterpret_cast<const long long *>(seg_end),
-                       tensor_group, sumsq, hyper, chunk);
+                       tensor_group, sumsq, hyper, chunk, n_chunks);
     DETR_LAUNCH_CHECK("clip_adam");
     return 0;
 }

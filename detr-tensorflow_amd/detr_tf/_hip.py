@@ -77,6 +77,14 @@ class Conv3x3Desc(Structure):
                 ("x_dtype", c_int32), ("y_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
 
 
+class PostprocessDesc(Structure):
+    _fields_ = [("B", c_int32), ("Q", c_int32), ("C", c_int32),
+                ("logits", c_void_p), ("sL_b", c_int64), ("sL_q", c_int64),
+                ("boxes", c_void_p), ("sB_b", c_int64), ("sB_q", c_int64),
+                ("background_class", c_int32), ("bbox_format", c_int32),
+                ("out_boxes", c_void_p), ("out_labels", c_void_p), ("out_scores", c_void_p), ("counts", c_void_p)]
+
+
 class SetLossDesc(Structure):
     _fields_ = [("levels", c_int32), ("B", c_int32), ("Q", c_int32), ("C", c_int32), ("R", c_int32),
                 ("logits", c_void_p), ("sL_l", c_int64), ("sL_b", c_int64), ("sL_q", c_int64),
@@ -121,6 +129,7 @@ _SIGNATURES = {
     "detr_hip_scale_cols_f32": [f32p, f32p, f32p, c_int64, c_int32, c_void_p],
     "detr_hip_scale_cols_t_f32": [f32p, f32p, f32p, c_int32, c_int32, c_void_p],
     "detr_hip_bn_fold_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_float, c_void_p],
+    "detr_hip_postprocess": [POINTER(PostprocessDesc), c_void_p],
     "detr_hip_match_cost_f32": [POINTER(SetLossDesc), f32p, c_void_p],
     "detr_hip_assign_f32": [f32p, c_int32, c_int32, c_int32, f32p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     "detr_hip_set_loss_sums_f32": [POINTER(SetLossDesc), c_void_p, f32p, c_void_p],

@@ -125,6 +125,7 @@ class DetrEngine:
         self._step_no += 1
         self._step_seed = step_seed(self.dropout_seed, self._step_no, self.dp_rank)
         hip.call("detr_hip_set_u32x8", self._seed_dev.data_ptr(), self._step_seed, 0, 0, 0, 0, 0, 0, 0)
+        self._drop = (float(self.dropout_p), self._step_seed)
         return self._step_seed
 
     # ---- buffers ------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ class GroupAdam:
         self.chunk_start = tables["chunk_start"][idx].contiguous() if keep else None
         self.seg_end = tables["seg_end"]
         self.tensor_group = torch.tensor(grp, dtype=torch.int32, device=dev)
-        self.sumsq = torch.zeros(len(grp), dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(max(1, self.n_chunks), dtype=torch.float32, device=dev)     # one partial sum of squares per chunk
         if not hasattr(store, "adam_m"):            # the groups own disjoint slices of shared moment buffers
             store.adam_m = torch.zeros_like(store.flat)
             store.adam_v = torch.zeros_like(store.flat)
@@ -64,7 +64,6 @@ class GroupAdam:
             self.engine.weights_dirty = True
         if self.n_chunks == 0:
             return
-        hip.zero_(self.sumsq)
         hip.call("detr_hip_sumsq_segments_f32", grad_flat.data_ptr(), self.chunk_tensor.data_ptr(),
                  self.chunk_start.data_ptr(), self.seg_end.data_ptr(), self.n_chunks, CHUNK, self.sumsq.data_ptr())
         hip.call("detr_hip_clip_adam_f32", self.store.flat.data_ptr(), grad_flat.data_ptr(), self.m.data_ptr(),

@@ -346,11 +346,33 @@ int detr_hip_set_loss_grad_f32(const detr_setloss_desc *d, const int32_t *tgt_fo
                                float loss_scale, float *d_logits, float *d_boxes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched post-processing (detr_tf/inference.py:68-95, which handles batch element 0 only; the validation loops call it
+ * once per image, logger/training_logging.py:61-88, eval.py:41-55).  One launch for the whole batch: per query
+ * score = max softmax probability, label = first arg-max of the probabilities; queries whose label is `background_class`
+ * are dropped (order preserved); boxes converted (bbox.py:171-196: xyxy / yxyx are clipped to [0, 1]); the kept detections
+ * of image b are written compacted to out_*[b][0 .. counts[b]).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, Q, C;
+    const float *logits; int64_t sL_b, sL_q;     /* [B, Q, C], unit class stride */
+    const float *boxes;  int64_t sB_b, sB_q;     /* [B, Q, 4] cx, cy, w, h */
+    int32_t background_class;
+    int32_t bbox_format;                         /* 0 "xy_center", 1 "xyxy", 2 "yxyx" */
+    float *out_boxes;                            /* [B, Q, 4] */
+    int64_t *out_labels;                         /* [B, Q] */
+    float *out_scores;                           /* [B, Q] */
+    int32_t *counts;                             /* [B] */
+} detr_postprocess_desc;
+int detr_hip_postprocess(const detr_postprocess_desc *d, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimiser (detr_tf/optimizers.py:86-88,137-163): per-tensor clip-by-norm then Keras Adam on
  * a flat fp32 parameter buffer.  Tensor t occupies [seg_off[t], seg_off[t+1]) ; chunk c of
  * `chunk` elements belongs to tensor chunk_tensor[c] and starts at chunk_start[c].
  *   hyper (device, float[8]) = {lr_t group0, lr_t group1, lr_t group2, clipnorm, beta1, beta2, eps, -}
  *   with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host each step.
+ *   sumsq [n_chunks]: sumsq_segments stores one partial per chunk; clip_adam sums the partials of a tensor (its chunks are
+ *   consecutive) in a fixed order -- no atomics, so data-parallel replicas apply bit-identical updates.
  * ------------------------------------------------------------------------------------------- */
 int detr_hip_sumsq_segments_f32(const float *g, const int32_t *chunk_tensor, const int64_t *chunk_start,
                                 const int64_t *seg_end, int32_t n_chunks, int32_t chunk, float *sumsq,

@@ -34,6 +34,7 @@ from detr_tf import bbox as ref_bbox                              # noqa: E402  
 from detr_tf import inference as ref_inference                    # noqa: E402
 from detr_tf import optimizers as ref_optimizers                  # noqa: E402
 from detr_tf import training as ref_training                      # noqa: E402
+from detr_tf.loss import compute_map as ref_map                    # noqa: E402
 from detr_tf.loss import loss as ref_loss                         # noqa: E402
 from detr_tf.loss.hungarian_matching import hungarian_matching as ref_hungarian      # noqa: E402
 from detr_tf.networks import detr as ref_detr                     # noqa: E402
@@ -432,7 +433,68 @@ def check_training():
     print("    wrote refpy_training.npz")
 
 
+# =====================================================================================================
+# D. mAP accumulation (eval.py:30-61 / compute_map.py) -- fixture for the vectorised accumulator of the package
+# =====================================================================================================
+def make_map_case(seed, n_images, nb_class):
+    rng = np.random.default_rng(seed)
+    images = []
+    for _ in range(n_images):
+        n_gt = int(rng.integers(0, 9))
+        yx = rng.uniform(0.0, 0.7, (n_gt, 2))
+        hw = rng.uniform(0.05, 0.3, (n_gt, 2))
+        t_bbox = np.concatenate([yx, np.minimum(yx + hw, 1.0)], 1).astype(np.float32)
+        t_cls = rng.integers(0, nb_class, n_gt).astype(np.int64)
+        preds, pcls, pscore = [], [], []
+        for j in range(n_gt):                       # perturbed copies of the ground truths (some duplicated, some mislabelled)
+            for _ in range(int(rng.integers(0, 3))):
+                jit = rng.normal(0, 0.03, 4)
+                preds.append(np.clip(t_bbox[j] + jit, 0, 1))
+                pcls.append(t_cls[j] if rng.uniform() < 0.8 else rng.integers(0, nb_class))
+                pscore.append(round(float(rng.uniform(0.05, 1.0)), 2))      # two decimals: score ties do occur
+        for _ in range(int(rng.integers(0, 6))):    # false positives
+            a = rng.uniform(0, 0.8, 2)
+            preds.append(np.concatenate([a, np.minimum(a + rng.uniform(0.05, 0.2, 2), 1.0)]))
+            pcls.append(rng.integers(0, nb_class))
+            pscore.append(round(float(rng.uniform(0.05, 1.0)), 2))
+        images.append((np.asarray(preds, np.float32).reshape(-1, 4), np.asarray(pcls, np.int64), np.asarray(pscore, np.float32), t_bbox, t_cls))
+    return images
+
+
+def check_map():
+    fx = {}
+    for ci, (seed, n_images, nb_class) in enumerate([(71, 12, 6), (72, 30, 3), (73, 5, 10)]):
+        images = make_map_case(seed, n_images, nb_class)
+        thresholds = [x / 100.0 for x in range(50, 100, 5)]                   # eval.py:33
+        class_names = [f"class_{i}" for i in range(nb_class)]
+        ap_data = {"box": [[ref_map.APDataObject() for _ in class_names] for _ in thresholds],
+                   "mask": [[ref_map.APDataObject() for _ in class_names] for _ in thresholds]}
+        for p_bbox, p_cls, p_score, t_bbox, t_cls in images:                  # eval.py:54 (dummy all-zero masks)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ref_map.cal_map(p_bbox, p_cls, p_score, np.zeros((138, 138, len(p_bbox))), t_bbox, t_cls, np.zeros((138, 138, len(t_bbox))),
+                                ap_data, thresholds)
+        per_class = np.array([[ap_data["box"][t][c].get_ap() if not ap_data["box"][t][c].is_empty() else -1.0 for c in range(nb_class)]
+                              for t in range(len(thresholds))], np.float64)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            all_maps = ref_map.calc_map(ap_data, thresholds, class_names, print_result=True)
+        fx[f"m{ci}_nb_class"], fx[f"m{ci}_n_images"] = np.int64(nb_class), np.int64(n_images)
+        for i, (p_bbox, p_cls, p_score, t_bbox, t_cls) in enumerate(images):
+            fx[f"m{ci}_{i}_p_bbox"], fx[f"m{ci}_{i}_p_cls"], fx[f"m{ci}_{i}_p_score"] = p_bbox, p_cls, p_score
+            fx[f"m{ci}_{i}_t_bbox"], fx[f"m{ci}_{i}_t_cls"] = t_bbox, t_cls
+        fx[f"m{ci}_per_class_ap"] = per_class
+        fx[f"m{ci}_box_keys"] = np.array([str(k) for k in all_maps["box"].keys()])
+        fx[f"m{ci}_box_vals"] = np.array(list(all_maps["box"].values()), np.float64)
+        fx[f"m{ci}_mask_vals"] = np.array(list(all_maps["mask"].values()), np.float64)
+        fx[f"m{ci}_table"] = np.array(buf.getvalue())
+        print(f"[D] reference cal_map / calc_map on {n_images} images, {nb_class} classes: box mAP {all_maps['box']['all']}, mask mAP {all_maps['mask']['all']}")
+    fx["n_cases"] = np.int64(3)
+    np.savez_compressed(os.path.join(GOLD, "refpy_map.npz"), **fx)
+    print("    wrote refpy_map.npz")
+
+
 if __name__ == "__main__":
+    check_map()
     check_bbox()
     check_set_loss()
     check_forward()

@@ -732,7 +732,7 @@ def test_clip_adam_vs_oracle(hip):
         scale = [1e-3, 10.0, 1.0][step - 1]    # below / above the clip threshold
         grads = {i: (rng.normal(size=s) * scale).astype(np.float32) for i, s in enumerate(shapes)}
         gflat = g(torch.tensor(np.concatenate([grads[i].ravel() for i in range(len(shapes))])))
-        sumsq = torch.zeros(len(shapes), device=DEV)
+        sumsq = torch.zeros(len(ct), device=DEV)              # per-chunk partials; the per-tensor sum is formed in a fixed order
         hip.call("detr_hip_sumsq_segments_f32", gflat.data_ptr(), ctd.data_ptr(), csd.data_ptr(), sed.data_ptr(), len(ct),
                  chunk, sumsq.data_ptr())
         hyper = torch.tensor([lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) for lr in lrs] + [0.1, 0.9, 0.999, 1e-7, 0],
