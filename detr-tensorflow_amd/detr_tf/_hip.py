@@ -77,6 +77,12 @@ class Conv3x3Desc(Structure):
                 ("x_dtype", c_int32), ("y_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
 
 
+class InputDesc(Structure):
+    _fields_ = [("B", c_int32), ("Hs", c_int32), ("Ws", c_int32), ("Hd", c_int32), ("Wd", c_int32),
+                ("src", c_void_p), ("src_batch_stride", c_int64), ("dst", c_void_p), ("lut", c_void_p),
+                ("perm", c_int32 * 3), ("interpolation", c_int32)]
+
+
 class PostprocessDesc(Structure):
     _fields_ = [("B", c_int32), ("Q", c_int32), ("C", c_int32),
                 ("logits", c_void_p), ("sL_b", c_int64), ("sL_q", c_int64),
@@ -130,6 +136,8 @@ _SIGNATURES = {
     "detr_hip_scale_cols_t_f32": [f32p, f32p, f32p, c_int32, c_int32, c_void_p],
     "detr_hip_bn_fold_f32": [f32p, f32p, f32p, f32p, f32p, f32p, c_int32, c_float, c_void_p],
     "detr_hip_postprocess": [POINTER(PostprocessDesc), c_void_p],
+    "detr_hip_input_stage": [POINTER(InputDesc), c_void_p],
+    "detr_hip_pad_labels": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     "detr_hip_match_cost_f32": [POINTER(SetLossDesc), f32p, c_void_p],
     "detr_hip_assign_f32": [f32p, c_int32, c_int32, c_int32, f32p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     "detr_hip_set_loss_sums_f32": [POINTER(SetLossDesc), c_void_p, f32p, c_void_p],

@@ -346,6 +346,27 @@ int detr_hip_set_loss_grad_f32(const detr_setloss_desc *d, const int32_t *tgt_fo
                                float loss_scale, float *d_logits, float *d_boxes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Device-side input stage (the step's producer side; detr_tf/data/processing.py:6-21,35-55, data/transformation.py:82-91).
+ *   detr_hip_input_stage: uint8 NHWC batch -> fixed-size resize (cv2.resize semantics in fp32: half-pixel centres,
+ *     replicated border, cubic a = -0.75; rounded + saturated back to uint8) -> normalisation through a [3][256] float
+ *     lookup table the host builds in float64 exactly as `normalized_images` does (dst channel c = lut[c][src channel
+ *     perm[c]]; "tf_resnet" = BGR order, perm {2,1,0}) -> float32 NHWC.
+ *   detr_hip_pad_labels: ragged targets (boxes [N,4] cx,cy,w,h; classes [N]; offsets [B+1]) -> the reference's padded
+ *     layout with the in-band header row: t_bbox [B,R,4] (row 0 = [n,0,0,0]), t_class [B,R] (row 0 = 0), zero padded.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, Hs, Ws, Hd, Wd;
+    const uint8_t *src; int64_t src_batch_stride;    /* bytes between images */
+    float *dst;                                      /* [B, Hd, Wd, 3] */
+    const float *lut;                                /* [3][256] */
+    int32_t perm[3];
+    int32_t interpolation;                           /* 0 nearest, 1 linear, 2 cubic (imgaug's Resize default) */
+} detr_input_desc;
+int detr_hip_input_stage(const detr_input_desc *d, void *stream);
+int detr_hip_pad_labels(const float *boxes, const int64_t *classes, const int32_t *offsets, int32_t B, int32_t R,
+                        float *t_bbox, int64_t *t_class, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Batched post-processing (detr_tf/inference.py:68-95, which handles batch element 0 only; the validation loops call it
  * once per image, logger/training_logging.py:61-88, eval.py:41-55).  One launch for the whole batch: per query
  * score = max softmax probability, label = first arg-max of the probabilities; queries whose label is `background_class`

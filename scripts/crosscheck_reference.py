@@ -34,6 +34,7 @@ from detr_tf import bbox as ref_bbox                              # noqa: E402  
 from detr_tf import inference as ref_inference                    # noqa: E402
 from detr_tf import optimizers as ref_optimizers                  # noqa: E402
 from detr_tf import training as ref_training                      # noqa: E402
+from detr_tf.data import processing as ref_processing             # noqa: E402
 from detr_tf.loss import compute_map as ref_map                    # noqa: E402
 from detr_tf.loss import loss as ref_loss                         # noqa: E402
 from detr_tf.loss.hungarian_matching import hungarian_matching as ref_hungarian      # noqa: E402
@@ -42,7 +43,7 @@ from detr_tf.training_config import TrainingConfig as RefConfig   # noqa: E402
 
 assert ref_loss.__file__.startswith("/root/reference/"), ref_loss.__file__
 
-from oracle import detr_ref as R, dropout_ref as DR, optim_ref as O, set_loss_ref as L      # noqa: E402
+from oracle import detr_ref as R, dropout_ref as DR, input_ref as I, optim_ref as O, set_loss_ref as L      # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
@@ -493,7 +494,37 @@ def check_map():
     print("    wrote refpy_map.npz")
 
 
+# =====================================================================================================
+# E. input stage: normalized_images / pad_labels (data/processing.py) -- the resize is third-party (imgaug / cv2)
+# =====================================================================================================
+def check_input():
+    fx = {}
+    rng = np.random.default_rng(81)
+    img = rng.integers(0, 256, (2, 37, 53, 3)).astype(np.uint8)
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[:, None, None], 3, 2)             # every pixel value in every channel
+    for method in ("torch_resnet", "tf_resnet"):
+        cfg = RefConfig()
+        cfg.normalized_method = method
+        for name, x in (("img", img), ("ramp", ramp)):
+            ref = ref_processing.normalized_images(x, cfg)
+            assert ref.dtype == np.float32 and np.array_equal(ref, I.normalized_images(x, method))
+            fx[f"norm_{method}_{name}"] = ref
+    fx["img"], fx["ramp"] = img, ramp
+    for ci, n in enumerate((0, 1, 7, 99)):
+        tb = rng.uniform(0.1, 0.9, (n, 4)).astype(np.float32)
+        tc = rng.integers(1, 91, (n, 1)).astype(np.int64)
+        _, rb, rc = ref_processing.pad_labels(None, tft(tb), tft(tc))
+        ob, oc = I.pad_labels(tb, tc)
+        assert tuple(rb.shape) == (100, 4) and tuple(rc.shape) == (100, 1) and npy(rb).dtype == np.float32 and npy(rc).dtype == np.int64
+        assert np.array_equal(npy(rb), ob) and np.array_equal(npy(rc), oc)
+        fx[f"pad{ci}_in_bbox"], fx[f"pad{ci}_in_class"], fx[f"pad{ci}_bbox"], fx[f"pad{ci}_class"] = tb, tc, npy(rb), npy(rc)
+    fx["n_pad"] = np.int64(4)
+    np.savez_compressed(os.path.join(GOLD, "refpy_input.npz"), **fx)
+    print("[E] normalized_images (both methods, every pixel value) and pad_labels: reference == oracle; wrote refpy_input.npz")
+
+
 if __name__ == "__main__":
+    check_input()
     check_map()
     check_bbox()
     check_set_loss()

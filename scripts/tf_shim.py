@@ -163,7 +163,7 @@ def _sparse_ce(labels, logits, name=None):
 
 tf.cast, tf.shape, tf.slice, tf.tile, tf.gather, tf.where = _cast, _shape, _slice, _tile, _gather, _where
 tf.squeeze = lambda x, axis=None: x.squeeze() if axis is None else x.squeeze(axis)
-tf.expand_dims = lambda x, axis: x.unsqueeze(axis)
+tf.expand_dims = lambda x, axis: _t(x).unsqueeze(axis)
 tf.concat = lambda xs, axis: torch.cat(list(xs), dim=axis)
 tf.stack = lambda xs, axis=0: torch.stack(list(xs), dim=axis)
 tf.zeros, tf.zeros_like, tf.reshape = _zeros, torch.zeros_like, _reshape
@@ -176,6 +176,9 @@ tf.reduce_max = lambda x, axis=None: x.max() if axis is None else x.max(axis).va
 tf.abs, tf.sigmoid = torch.abs, torch.sigmoid
 tf.clip_by_value = lambda x, lo, hi: torch.clamp(x, lo, hi)
 tf.numpy_function = _numpy_function
+tf.pad = lambda x, paddings, mode="CONSTANT", constant_values=0: F.pad(
+    _t(x), [int(v) for pr in reversed([[_int(a), _int(b)] for a, b in paddings]) for v in pr], value=constant_values)
+tf.constant = lambda v, dtype=None: _t(np.asarray(v), dtype)
 tf.function = lambda f=None, **kw: f if f is not None else (lambda g: g)
 
 tf.math = types.ModuleType("tensorflow.math")
@@ -602,16 +605,36 @@ class _Permissive(types.ModuleType):
         return None
 
 
+class _PermissiveFinder:
+    """Any submodule of a permissive root (skimage.color, imgaug.augmentables.segmaps, pycocotools.coco ...) resolves to
+    another permissive module."""
+    ROOTS = ("cv2", "wandb", "imgaug", "imageio", "pycocotools", "skimage", "matplotlib", "requests")
+
+    def find_spec(self, name, path=None, target=None):
+        import importlib.machinery
+        if name.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Permissive(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
 def install():
     """Put the stand-ins into sys.modules and /root/reference on sys.path (build container only)."""
     mods = {"tensorflow": tf, "tensorflow.keras": keras, "tensorflow.keras.layers": layers, "tensorflow.keras.models": models,
             "tensorflow.keras.initializers": initializers, "tensorflow.keras.optimizers": optimizers,
             "tensorflow.keras.applications": applications, "tensorflow.math": tf.math, "tensorflow.nn": tf.nn,
             "tensorflow.linalg": tf.linalg, "tensorflow.compat": tf.compat, "tensorflow.compat.v1": tf.compat.v1}
-    for n in ("cv2", "wandb", "imgaug", "imgaug.augmenters", "imgaug.augmentables", "imgaug.augmentables.bbs", "imageio",
-              "pycocotools", "pycocotools.coco", "skimage", "matplotlib", "matplotlib.pyplot", "requests"):
-        mods[n] = _Permissive(n)
     sys.modules.update(mods)
+    for n in _PermissiveFinder.ROOTS:            # (matplotlib is really installed here: the stand-in keeps the import cheap)
+        sys.modules.pop(n, None)
+    sys.meta_path.insert(0, _PermissiveFinder())
     if not hasattr(np, "bool"):
         np.bool = bool                       # hungarian_matching.py:37,41 predates numpy 1.24
     if "/root/reference" not in sys.path:
