@@ -618,6 +618,50 @@ __global__ void set_u32x8_kernel(uint32_t *dst, uint32_t v0, uint32_t v1, uint32
 }
 }  // namespace detr
 
+namespace detr {
+// out[c] += scale[c] * sum_r x[r*ld + c] for an fp32 or bf16 matrix: the bias gradient of a conv whose frozen BN is folded
+// into it (tf_backbone=True: keras.applications convs carry a trainable bias; y = scale*(conv + b) + ... -> db = scale * sum dz)
+template <bool X16>
+__global__ __launch_bounds__(256) void colsum_scaled_kernel(const void *__restrict__ xv, float *__restrict__ out, long long rows,
+                                                            int cols, long long ld, const float *__restrict__ scale,
+                                                            int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        if (X16) s += __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(xv)[r * ld + c] << 16);
+        else s += reinterpret_cast<const float *>(xv)[r * ld + c];
+    }
+    unsafeAtomicAdd(out + c, (scale ? scale[c] : 1.0f) * s);
+}
+
+// table-driven out[i] = a[i] * b[i] + c[i] for n small vectors in ONE launch (the effective BN shift of every conv with a bias)
+__global__ __launch_bounds__(256) void fma_vec_group_kernel(const detr_fma_entry *__restrict__ table) {
+    const detr_fma_entry e = table[blockIdx.x];
+    for (int i = threadIdx.x; i < e.n; i += blockDim.x) e.out[i] = e.a[i] * e.b[i] + e.c[i];
+}
+}  // namespace detr
+
+extern "C" int detr_hip_colsum_scaled(const void *x, int32_t x_dtype, int64_t rows, int32_t cols, int64_t ld, const float *scale,
+                                      float *out, void *stream) {
+    DETR_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols && (x_dtype == 0 || x_dtype == 1), "colsum_scaled: bad args");
+    const int rpb = (int)((rows + 255) / 256 > 64 ? (rows + 255) / 256 : 64);
+    dim3 grid((unsigned)cdiv(cols, 256), (unsigned)cdiv(rows, rpb));
+    if (x_dtype == 1) hipLaunchKernelGGL(colsum_scaled_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, cols, (long long)ld, scale, rpb);
+    else hipLaunchKernelGGL(colsum_scaled_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, cols, (long long)ld, scale, rpb);
+    DETR_LAUNCH_CHECK("colsum_scaled");
+    return 0;
+}
+
+extern "C" int detr_hip_fma_vec_group(const detr_fma_entry *table, int32_t n, void *stream) {
+    DETR_REQUIRE(table && n > 0, "fma_vec_group: bad args");
+    hipLaunchKernelGGL(fma_vec_group_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, table);
+    DETR_LAUNCH_CHECK("fma_vec_group");
+    return 0;
+}
+
 extern "C" int detr_hip_multi_copy(const detr_copy_entry *table, int32_t n, int32_t blocks_per_entry, void *stream) {
     DETR_REQUIRE(table && n > 0 && n <= 65535 && blocks_per_entry > 0, "multi_copy: bad args");
     hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks_per_entry, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table);

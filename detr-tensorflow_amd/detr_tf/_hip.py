@@ -126,6 +126,8 @@ _SIGNATURES = {
     "detr_hip_attention_bwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p, c_void_p],
     "detr_hip_multi_copy": [c_void_p, c_int32, c_int32, c_void_p],
+    "detr_hip_colsum_scaled": [c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p],
+    "detr_hip_fma_vec_group": [c_void_p, c_int32, c_void_p],
     "detr_hip_set_u32x8": [c_void_p] + [ctypes.c_uint32] * 8 + [c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],

@@ -22,13 +22,14 @@ import numpy as np
 import torch
 
 from . import _hip as hip
-from .params import ParamStore, RESNET50_BLOCKS
+from .params import ParamStore, RESNET50_BLOCKS, block_names, bn_conv_pairs, stem_names
 
 D = 256
 HEADS = 8
 HD = 32
 FF = 2048
 BN_EPS = 1e-5
+KERAS_BN_EPS = 1.001e-5      # tf.keras.applications.resnet BatchNormalization(epsilon=1.001e-5) (tf_backbone=True)
 LN_EPS = 1e-5
 # implicit-GEMM stem convolution (default) vs the im2col buffer + GEMM path (DETR_HIP_IMPLICIT_STEM=0)
 IMPLICIT_STEM = os.environ.get("DETR_HIP_IMPLICIT_STEM", "1") != "0"
@@ -75,7 +76,7 @@ def position_embedding_sine_host(H, W, num_pos_features=128, temperature=10000.0
 
 class DetrEngine:
     def __init__(self, device="cuda:0", blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, num_queries=100,
-                 num_classes=92, nb_class=None, seed=0):
+                 num_classes=92, nb_class=None, seed=0, tf_backbone=False):
         hip.load()
         self.device = torch.device(device)
         hip.ensure_workspace(self.device)
@@ -83,7 +84,13 @@ class DetrEngine:
         self.num_enc, self.num_dec, self.Q = num_enc, num_dec, num_queries
         self.nb_class = nb_class
         self.C = num_classes if nb_class is None else nb_class
-        self.P = ParamStore(self.device, blocks, num_enc, num_dec, num_queries, num_classes, nb_class, seed)
+        # tf_backbone=True (detr.py:146-148): tf.keras.applications ResNet50 -- ResNet v1 (the stride of a stage sits on the
+        # FIRST 1x1 conv of its first block), convs with a trainable bias, BatchNormalization(eps 1.001e-5) in inference mode
+        self.tf_backbone = bool(tf_backbone)
+        self.bn_eps = KERAS_BN_EPS if self.tf_backbone else BN_EPS
+        self.P = ParamStore(self.device, blocks, num_enc, num_dec, num_queries, num_classes, nb_class, seed, tf_backbone=tf_backbone)
+        self._stem = stem_names(self.tf_backbone)
+        self._pairs = bn_conv_pairs(self.blocks, self.tf_backbone)
         self._bufs = {}
         self._pos_cache = {}
         self._shape = None
@@ -145,10 +152,24 @@ class DetrEngine:
             sc = self.buf(f"bnscale:{p}", (c,))
             sh = self.buf(f"bnshift:{p}", (c,))
             hip.call("detr_hip_bn_fold_f32", raw[0].data_ptr(), raw[1].data_ptr(), raw[2].data_ptr(), raw[3].data_ptr(),
-                     sc.data_ptr(), sh.data_ptr(), c, c_float(BN_EPS))
-            self.bn_scale[p], self.bn_shift[p] = sc, sh
+                     sc.data_ptr(), sh.data_ptr(), c, c_float(self.bn_eps))
+            self.bn_scale[p] = sc
+            # a conv bias under the frozen BN moves into the shift: scale*(conv + b) + shift0 (rebuilt by _refresh_bias_shift)
+            self.bn_shift[p] = self.buf(f"bnshift_eff:{p}", (c,)) if self.tf_backbone else sh
         self.weights_dirty = True
         self._fold_table = None
+        self._shift_table = None
+
+    def _refresh_bias_shift(self):
+        """tf_backbone=True: effective shift = bias * scale + (beta - mean * scale) for every conv, one launch."""
+        if self._shift_table is None:
+            rows = []
+            for bn_name, conv_name in self._pairs:
+                c = self.P.bn[bn_name]
+                rows.append([self.P.views[f"{conv_name}/bias"].data_ptr(), self.bn_scale[bn_name].data_ptr(),
+                             self._bufs[f"bnshift:{bn_name}"].data_ptr(), self.bn_shift[bn_name].data_ptr(), c])
+            self._shift_table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        hip.call("detr_hip_fma_vec_group", self._shift_table.data_ptr(), self._shift_table.shape[0])
 
     def load_params(self, params):
         missing = self.P.load_dict(params)
@@ -173,11 +194,8 @@ class DetrEngine:
         (kernel, bn scale, bf16 out, n/4, cols/4) entries, built once -- the tensors it points at never move."""
         if getattr(self, "_fold_table", None) is None:
             rows = []
-            for bn_name in self.P.bn:
-                if bn_name == "backbone/bn1":
-                    continue
-                head, leaf = bn_name.rsplit("/", 1)
-                conv_name = f"{head}/downsample_0/kernel" if leaf == "downsample_1" else f"{head}/conv{leaf[2:]}/kernel"
+            for bn_name, conv in self._pairs[1:]:               # (the stem kernel takes the fp32 copy)
+                conv_name = f"{conv}/kernel"
                 w = self.P.views[conv_name]
                 co = w.shape[-1]
                 ws16 = self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)
@@ -190,7 +208,7 @@ class DetrEngine:
         """kernel * bn scale per output channel (the frozen-BN fold into the conv); bf16 compute mode: the bf16 copy."""
         w = self.P.views[conv_name]
         co = w.shape[-1]
-        if self.compute == 1 and conv_name != "backbone/conv1/kernel":      # (the stem kernel takes the fp32 copy)
+        if self.compute == 1 and conv_name != f"{self._stem['conv']}/kernel":      # (the stem kernel takes the fp32 copy)
             return self.buf(f"ws16:{conv_name}", w.shape, torch.bfloat16)     # filled by _refold_group()
         ws = self.buf(f"ws:{conv_name}", w.shape)
         if self._stale(f"ws:{conv_name}"):
@@ -366,6 +384,8 @@ class DetrEngine:
         hip.COMPUTE_BF16 = self.compute
         if self.compute == 1 and (self._stale("shadow16") or self.P.views16 is None):
             self._refresh_shadow()
+        if self.tf_backbone and self._stale("bias_shift"):
+            self._refresh_bias_shift()
         try:
             return self._forward_impl(images, training)
         finally:
@@ -397,16 +417,16 @@ class DetrEngine:
         # ---------------- stem (resnet_backbone.py:11-26) ----------------
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         M1 = B * H1 * W1
-        ws = self._scaled_kernel("backbone/conv1/kernel", "backbone/bn1")
+        ws = self._scaled_kernel(f"{self._stem['conv']}/kernel", self._stem["bn"])
         adt = torch.bfloat16 if (self.compute == 1 and ACT16) else torch.float32      # storage type of backbone activations
         self._adt = adt
         stem = self.buf("stem:out", (B, H1, W1, 64), adt)
         if IMPLICIT_STEM:       # implicit GEMM: the 7x7x3 patches are gathered from the image by the A loader (stem_conv.hip)
-            hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift["backbone/bn1"], act=1)
+            hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift[self._stem["bn"]], act=1)
         else:                   # im2col buffer + GEMM (DETR_HIP_IMPLICIT_STEM=0)
             col = self.buf("stem:col", (M1, 160))
             hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
-            hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift["backbone/bn1"], act=1)
+            hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift[self._stem["bn"]], act=1)
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         pool = self.buf("stem:pool", (B, H2, W2, 64), adt)
         amax = self.buf("stem:amax", (B, H2, W2, 64), torch.uint8)
@@ -418,31 +438,36 @@ class DetrEngine:
         for li, nb in enumerate(self.blocks):
             d1, d2 = 64 * 2 ** li, 256 * 2 ** li
             for b in range(nb):
-                p = f"backbone/layer{li + 1}/{b}"
+                n = block_names(li, b, self.tf_backbone)
+                p = n["tag"]
                 stride = 2 if (b == 0 and li > 0) else 1
                 ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
                 M_in, M_out = B * h * w, B * ho * wo
-                y1 = self.buf(f"{p}:y1", (B, h, w, d1), adt)
-                self._conv1x1_fwd(x, M_in, cin, d1, f"{p}/conv1/kernel", f"{p}/bn1", y1)
+                xs = x
+                if stride == 2 and (b == 0):
+                    # stride-2 1x1 convs read every second pixel: gather them once (a plain 16-byte-chunk copy: bf16 tensors
+                    # pass as cin/2 "float" channels)
+                    xs = self.buf(f"{p}:xs", (B, ho, wo, cin), adt)
+                    hip.call("detr_hip_subsample2_fwd_f32", x.data_ptr(), xs.data_ptr(), B, h, w,
+                             cin // 2 if adt == torch.bfloat16 else cin, ho, wo)
+                if self.tf_backbone:            # ResNet v1 (keras.applications): the stride sits on the FIRST 1x1 conv
+                    x1, M1, h1, w1, s2 = xs, M_out, ho, wo, 1
+                else:                           # reference backbone (resnet_backbone.py:104-105): on the 3x3 conv
+                    x1, M1, h1, w1, s2 = x, M_in, h, w, stride
+                y1 = self.buf(f"{p}:y1", (B, h1, w1, d1), adt)
+                self._conv1x1_fwd(x1, M1, cin, d1, f"{n['conv1']}/kernel", n["bn1"], y1)
                 y2 = self.buf(f"{p}:y2", (B, ho, wo, d1), adt)
-                hip.conv3x3(0, y1, self._scaled_kernel(f"{p}/conv2/kernel", f"{p}/bn2"), y2, B, h, w, d1, ho, wo, d1,
-                            stride, bias=self.bn_shift[f"{p}/bn2"], act=1)
+                hip.conv3x3(0, y1, self._scaled_kernel(f"{n['conv2']}/kernel", n["bn2"]), y2, B, h1, w1, d1, ho, wo, d1,
+                            s2, bias=self.bn_shift[n["bn2"]], act=1)
                 if b == 0:
-                    if stride == 2:
-                        xs = self.buf(f"{p}:xs", (B, ho, wo, cin), adt)
-                        # a plain 16-byte-chunk gather: bf16 tensors pass as cin/2 "float" channels
-                        hip.call("detr_hip_subsample2_fwd_f32", x.data_ptr(), xs.data_ptr(), B, h, w,
-                                 cin // 2 if adt == torch.bfloat16 else cin, ho, wo)
-                    else:
-                        xs = x
                     idn = self.buf(f"{p}:idn", (B, ho, wo, d2), adt)
-                    self._conv1x1_fwd(xs, M_out, cin, d2, f"{p}/downsample_0/kernel", f"{p}/downsample_1", idn, act=0)
+                    self._conv1x1_fwd(xs, M_out, cin, d2, f"{n['down']}/kernel", n["bnd"], idn, act=0)
                 else:
-                    xs, idn = None, x
+                    idn = x
                 out = self.buf(f"{p}:out", (B, ho, wo, d2), adt)
-                self._conv1x1_fwd(y2, M_out, d1, d2, f"{p}/conv3/kernel", f"{p}/bn3", out, residual=idn)
-                self._block_meta.append(dict(p=p, x=x, xs=xs, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, cin=cin,
-                                             d1=d1, d2=d2, stride=stride, first=(b == 0)))
+                self._conv1x1_fwd(y2, M_out, d1, d2, f"{n['conv3']}/kernel", n["bn3"], out, residual=idn)
+                self._block_meta.append(dict(p=p, n=n, x=x, xs=xs, x1=x1, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, h1=h1, w1=w1,
+                                             M1=M1, s2=s2, cin=cin, d1=d1, d2=d2, stride=stride, first=(b == 0)))
                 x, h, w, cin = out, ho, wo, d2
         self.weights_dirty = False
         feat, Hf, Wf = x, h, w

@@ -35,7 +35,28 @@ def variable_group(name, nlayers):
     return 0
 
 
-def trainable_shapes(blocks, num_enc, num_dec, num_queries, num_classes, nb_class, model_dim=256, ff=2048):
+def block_names(li, b, tf_backbone=False):
+    """Layer names of bottleneck b of stage li: conv1/bn1 (1x1), conv2/bn2 (3x3), conv3/bn3 (1x1), down/bnd (shortcut).
+    Reference backbone: resnet_backbone.py:94-137 (`layer{n}/{b}/convK`, `bnK`, `downsample_0/1`); tf_backbone=True:
+    tf.keras.applications ResNet50 (`conv{s}_block{k}_{1,2,3,0}_{conv,bn}`)."""
+    if tf_backbone:
+        q = f"resnet50/conv{li + 2}_block{b + 1}"
+        return dict(conv1=f"{q}_1_conv", bn1=f"{q}_1_bn", conv2=f"{q}_2_conv", bn2=f"{q}_2_bn", conv3=f"{q}_3_conv", bn3=f"{q}_3_bn",
+                    down=f"{q}_0_conv", bnd=f"{q}_0_bn", tag=f"{q}")
+    p = f"backbone/layer{li + 1}/{b}"
+    return dict(conv1=f"{p}/conv1", bn1=f"{p}/bn1", conv2=f"{p}/conv2", bn2=f"{p}/bn2", conv3=f"{p}/conv3", bn3=f"{p}/bn3",
+                down=f"{p}/downsample_0", bnd=f"{p}/downsample_1", tag=p)
+
+
+def stem_names(tf_backbone=False):
+    return dict(conv="resnet50/conv1_conv", bn="resnet50/conv1_bn") if tf_backbone else dict(conv="backbone/conv1", bn="backbone/bn1")
+
+
+BN_LEAVES = {False: ("weight", "bias", "running_mean", "running_var"),          # FrozenBatchNorm2D custom_layers.py:11-18
+             True: ("gamma", "beta", "moving_mean", "moving_variance")}         # tf.keras BatchNormalization
+
+
+def trainable_shapes(blocks, num_enc, num_dec, num_queries, num_classes, nb_class, model_dim=256, ff=2048, tf_backbone=False):
     """Ordered (reverse-forward) dict name -> shape of the trainable tensors."""
     s = OrderedDict()
 
@@ -87,44 +108,65 @@ def trainable_shapes(blocks, num_enc, num_dec, num_queries, num_classes, nb_clas
     cins = [64]
     for li in range(4):
         cins.append(256 * 2 ** li)
+    def conv(name, shape):
+        s[f"{name}/kernel"] = shape
+        if tf_backbone:                       # keras.applications convs carry a (trainable) bias
+            s[f"{name}/bias"] = (shape[3],)
+
     for li in reversed(range(4)):
         d1 = 64 * 2 ** li
         d2 = 4 * d1
         for b in reversed(range(blocks[li])):
             cin = cins[li] if b == 0 else d2
-            p = f"backbone/layer{li + 1}/{b}"
-            s[f"{p}/conv3/kernel"] = (1, 1, d1, d2)
-            s[f"{p}/conv2/kernel"] = (3, 3, d1, d1)
-            s[f"{p}/conv1/kernel"] = (1, 1, cin, d1)
+            n = block_names(li, b, tf_backbone)
+            conv(n["conv3"], (1, 1, d1, d2))
+            conv(n["conv2"], (3, 3, d1, d1))
+            conv(n["conv1"], (1, 1, cin, d1))
             if b == 0:
-                s[f"{p}/downsample_0/kernel"] = (1, 1, cin, d2)
-    s["backbone/conv1/kernel"] = (7, 7, 3, 64)
+                conv(n["down"], (1, 1, cin, d2))
+    conv(stem_names(tf_backbone)["conv"], (7, 7, 3, 64))
     return s
 
 
-def bn_names(blocks):
-    """name prefix -> channels of every FrozenBatchNorm2D used by the graph."""
+def bn_names(blocks, tf_backbone=False):
+    """name prefix -> channels of every frozen batch norm used by the graph."""
     out = OrderedDict()
-    out["backbone/bn1"] = 64
+    out[stem_names(tf_backbone)["bn"]] = 64
     for li in range(4):
         d1 = 64 * 2 ** li
         d2 = 4 * d1
         for b in range(blocks[li]):
-            p = f"backbone/layer{li + 1}/{b}"
-            out[f"{p}/bn1"] = d1
-            out[f"{p}/bn2"] = d1
-            out[f"{p}/bn3"] = d2
+            n = block_names(li, b, tf_backbone)
+            out[n["bn1"]] = d1
+            out[n["bn2"]] = d1
+            out[n["bn3"]] = d2
             if b == 0:
-                out[f"{p}/downsample_1"] = d2
+                out[n["bnd"]] = d2
+    return out
+
+
+def bn_conv_pairs(blocks, tf_backbone=False):
+    """[(bn prefix, conv prefix)] of every conv + frozen BN pair of the backbone, stem first."""
+    st = stem_names(tf_backbone)
+    out = [(st["bn"], st["conv"])]
+    for li in range(4):
+        for b in range(blocks[li]):
+            n = block_names(li, b, tf_backbone)
+            out += [(n["bn1"], n["conv1"]), (n["bn2"], n["conv2"]), (n["bn3"], n["conv3"])]
+            if b == 0:
+                out.append((n["bnd"], n["down"]))
     return out
 
 
 class ParamStore:
     def __init__(self, device, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, num_queries=100, num_classes=92,
-                 nb_class=None, seed=0):
+                 nb_class=None, seed=0, tf_backbone=False):
         self.device = device
-        self.shapes = trainable_shapes(blocks, num_enc, num_dec, num_queries, num_classes, nb_class)
-        self.bn = bn_names(blocks)
+        self.tf_backbone = bool(tf_backbone)
+        self.blocks = tuple(blocks)
+        self.bn_leaves = BN_LEAVES[self.tf_backbone]
+        self.shapes = trainable_shapes(blocks, num_enc, num_dec, num_queries, num_classes, nb_class, tf_backbone=tf_backbone)
+        self.bn = bn_names(blocks, tf_backbone)
         self.offsets = OrderedDict()
         off = 0
         for k, shp in self.shapes.items():
@@ -190,7 +232,7 @@ class ParamStore:
             else:
                 missing.append(k)
         for p in self.bn:
-            for i, leaf in enumerate(("weight", "bias", "running_mean", "running_var")):
+            for i, leaf in enumerate(self.bn_leaves):
                 if f"{p}/{leaf}" in params:
                     self.bn_raw[p][i].copy_(torch.as_tensor(np.asarray(params[f"{p}/{leaf}"]), dtype=torch.float32))
                 else:
@@ -200,7 +242,7 @@ class ParamStore:
     def state_dict(self):
         out = {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
         for p in self.bn:
-            for i, leaf in enumerate(("weight", "bias", "running_mean", "running_var")):
+            for i, leaf in enumerate(self.bn_leaves):
                 out[f"{p}/{leaf}"] = self.bn_raw[p][i].cpu().numpy().copy()
         return out
 
@@ -238,8 +280,8 @@ class ParamStore:
         [heads+decoder+encoder], [input_proj, query_embed, layer4], [layer3], [layer2, layer1, stem]."""
         def start(name):
             return self.offsets[name][0]
-        names = list(self.shapes)
         b1 = start("input_proj/kernel")
-        l3 = next(k for k in names if k.startswith("backbone/layer3/"))
-        l2 = next(k for k in names if k.startswith("backbone/layer2/"))
+        # the first tensor (in reverse-forward order) of stage 3 / stage 2: conv3 of their last block
+        l3 = block_names(2, self.blocks[2] - 1, self.tf_backbone)["conv3"] + "/kernel"
+        l2 = block_names(1, self.blocks[1] - 1, self.tf_backbone)["conv3"] + "/kernel"
         return [(0, b1), (b1, start(l3)), (start(l3), start(l2)), (start(l2), self.total)]

@@ -256,6 +256,19 @@ typedef struct detr_copy_entry {
     int32_t reserved;
 } detr_copy_entry;
 int detr_hip_multi_copy(const detr_copy_entry *table, int32_t n, int32_t blocks_per_entry, void *stream);
+/* tf_backbone=True (tf.keras.applications ResNet50, detr.py:146-148: convs WITH a trainable bias under a frozen BatchNorm):
+ *   out[c] += scale[c] * sum_r x[r*ld + c]   (x fp32: x_dtype 0, bf16: 1) -- the bias gradient through the folded BN;
+ *   out[i] = a[i]*b[i] + c[i] for n small vectors in one launch (table in DEVICE memory) -- the effective shift
+ *   beta - mean*scale + scale*bias of every conv, rebuilt when the biases move. */
+typedef struct detr_fma_entry {
+    const float *a, *b, *c;
+    float *out;
+    int32_t n;
+    int32_t reserved;
+} detr_fma_entry;
+int detr_hip_colsum_scaled(const void *x, int32_t x_dtype, int64_t rows, int32_t cols, int64_t ld, const float *scale,
+                           float *out, void *stream);
+int detr_hip_fma_vec_group(const detr_fma_entry *table, int32_t n, void *stream);
 /* dst[0..7] = v0..v7 (uint32; the values travel as kernel arguments): the per-step dropout seed */
 int detr_hip_set_u32x8(uint32_t *dst, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t v5,
                        uint32_t v6, uint32_t v7, void *stream);

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-5          # detr_tf/networks/custom_layers.py:5
+KERAS_BN_EPS = 1.001e-5  # tf.keras.applications.resnet (third-party): BatchNormalization(epsilon=1.001e-5)
 LN_EPS = 1e-5          # detr_tf/networks/transformer.py:151-152,200-202
 RESNET50_BLOCKS = (3, 4, 6, 3)      # detr_tf/networks/resnet_backbone.py:39-48
 RESNET101_BLOCKS = (3, 4, 23, 3)    # detr_tf/networks/resnet_backbone.py:56-65
@@ -28,8 +29,32 @@ RESNET101_BLOCKS = (3, 4, 23, 3)    # detr_tf/networks/resnet_backbone.py:56-65
 # --------------------------------------------------------------------------------------
 # parameter construction (seeded; SURVEY.md 8d "Weights")
 # --------------------------------------------------------------------------------------
+def tf_backbone_shapes(s, blocks=RESNET50_BLOCKS):
+    """tf.keras.applications.ResNet50(include_top=False) (third-party Keras code the reference instantiates when
+    tf_backbone=True, detr.py:146-148): every conv has a bias, BatchNormalization layers carry gamma / beta /
+    moving_mean / moving_variance, block k of stack s is `conv{s}_block{k}_{0=shortcut,1,2,3}_{conv,bn}`."""
+    def conv(name, kh, ci, co):
+        s[f"resnet50/{name}_conv/kernel"] = (kh, kh, ci, co)
+        s[f"resnet50/{name}_conv/bias"] = (co,)
+        for n in ("gamma", "beta", "moving_mean", "moving_variance"):
+            s[f"resnet50/{name}_bn/{n}"] = (co,)
+
+    conv("conv1", 7, 3, 64)
+    cin = 64
+    for li, nb in enumerate(blocks):
+        f = 64 * 2 ** li
+        for b in range(nb):
+            q = f"conv{li + 2}_block{b + 1}"
+            if b == 0:
+                conv(f"{q}_0", 1, cin, 4 * f)
+            conv(f"{q}_1", 1, cin, f)
+            conv(f"{q}_2", 3, f, f)
+            conv(f"{q}_3", 1, f, 4 * f)
+            cin = 4 * f
+
+
 def param_shapes(blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, num_queries=100,
-                 num_classes=92, model_dim=256, ff=2048, nb_class=None):
+                 num_classes=92, model_dim=256, ff=2048, nb_class=None, tf_backbone=False):
     """Ordered dict name -> shape, names per SURVEY.md A.6 (Keras layer/weight names)."""
     s = {}
 
@@ -37,10 +62,13 @@ def param_shapes(blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, num_queries=100,
         for n in ("weight", "bias", "running_mean", "running_var"):
             s[f"{prefix}/{n}"] = (c,)
 
-    s["backbone/conv1/kernel"] = (7, 7, 3, 64)
-    bn("backbone/bn1", 64)
+    if tf_backbone:
+        tf_backbone_shapes(s, blocks)
+    else:
+        s["backbone/conv1/kernel"] = (7, 7, 3, 64)
+        bn("backbone/bn1", 64)
     cin = 64
-    for li, nb in enumerate(blocks):
+    for li, nb in enumerate(blocks if not tf_backbone else ()):
         d1 = 64 * 2 ** li
         d2 = 4 * d1
         for b in range(nb):
@@ -115,13 +143,13 @@ def make_params(seed=0, **kw):
     out = {}
     for name, shp in param_shapes(**kw).items():
         leaf = name.rsplit("/", 1)[1]
-        is_bn = ("/bn" in name) or ("/downsample_1/" in name)
-        if is_bn and leaf == "weight":
+        is_bn = ("/bn" in name) or ("/downsample_1/" in name) or ("_bn/" in name)
+        if is_bn and leaf in ("weight", "gamma") and "/norm" not in name:
             # the last BN of a residual branch gets a small gain so that 16 stacked blocks keep O(1) activations
-            v = rng.uniform(0.2, 0.4, shp) if "/bn3/" in name else rng.uniform(0.5, 1.5, shp)
-        elif is_bn and leaf == "running_var":
+            v = rng.uniform(0.2, 0.4, shp) if ("/bn3/" in name or "_3_bn/" in name) else rng.uniform(0.5, 1.5, shp)
+        elif is_bn and leaf in ("running_var", "moving_variance"):
             v = rng.uniform(0.5, 1.5, shp)
-        elif is_bn and leaf in ("running_mean", "bias"):
+        elif is_bn and leaf in ("running_mean", "bias", "moving_mean", "beta"):
             v = rng.normal(0.0, 0.1, shp)
         elif leaf == "gamma":
             v = rng.uniform(0.8, 1.2, shp)
@@ -129,7 +157,7 @@ def make_params(seed=0, **kw):
             v = rng.normal(0.0, 0.05, shp)
         elif len(shp) == 4:
             fan_in = shp[0] * shp[1] * shp[2]
-            gain = 1.0 if ("conv3" in name or "downsample_0" in name or "input_proj" in name) else math.sqrt(2.0)
+            gain = 1.0 if ("conv3" in name or "downsample_0" in name or "input_proj" in name or "_3_conv" in name or "_0_conv" in name) else math.sqrt(2.0)
             v = rng.normal(0.0, gain / math.sqrt(fan_in), shp)
         elif len(shp) == 2:
             lim = math.sqrt(6.0 / (shp[0] + shp[1]))
@@ -148,8 +176,9 @@ def to_torch(params, dtype=torch.float32, requires_grad=False):
 
 
 def trainable(name):
-    """FrozenBatchNorm2D vectors are trainable=False (custom_layers.py:11-18)."""
-    return not (("/bn" in name) or ("/downsample_1/" in name))
+    """FrozenBatchNorm2D vectors are trainable=False (custom_layers.py:11-18); with tf_backbone=True the Keras
+    BatchNormalization layers are set trainable=False by optimizers.disable_batchnorm_training (optimizers.py:3-8)."""
+    return not (("/bn" in name) or ("/downsample_1/" in name) or ("_bn/" in name))
 
 
 # --------------------------------------------------------------------------------------
@@ -202,6 +231,40 @@ def backbone(images_nhwc, P, blocks=RESNET50_BLOCKS, taps=None):
         for b in range(nb):
             stride = 2 if (b == 0 and li > 0) else 1     # resnet_backbone.py:39-48,80-81
             x = bottleneck(x, P, f"backbone/layer{li + 1}/{b}", stride, b == 0, taps)
+        if taps is not None:
+            taps[f"layer{li + 1}"] = x
+    return x
+
+
+def keras_bn(x, P, prefix):
+    """tf.keras BatchNormalization in inference mode (trainable=False): gamma * (x - mean) / sqrt(var + eps) + beta."""
+    inv = P[f"{prefix}/gamma"] * torch.rsqrt(P[f"{prefix}/moving_variance"] + KERAS_BN_EPS)
+    return x * inv + (P[f"{prefix}/beta"] - P[f"{prefix}/moving_mean"] * inv)
+
+
+def backbone_tf(images_nhwc, P, blocks=RESNET50_BLOCKS, taps=None):
+    """tf.keras.applications.resnet.ResNet50(include_top=False) as the reference uses it for tf_backbone=True
+    (detr.py:146-148; third-party Keras code, restated from its published definition): ZeroPadding2D(3) + 7x7/2 conv WITH
+    bias + BN + ReLU + ZeroPadding2D(1) + 3x3/2 max pool; bottleneck `block1`: shortcut 1x1 conv (stride s) + BN on the
+    first block of a stack, then 1x1 conv (stride s -- ResNet v1: the stride sits on the FIRST 1x1) + BN + ReLU, 3x3
+    'same' conv + BN + ReLU, 1x1 conv + BN, add, ReLU; stacks (64,3,s1) (128,4,s2) (256,6,s2) (512,3,s2)."""
+    def conv(x, name, stride=1, pad=0):
+        return conv2d_valid(x, P[f"resnet50/{name}_conv/kernel"], stride=stride, pad=pad) + P[f"resnet50/{name}_conv/bias"]
+
+    x = torch.relu(keras_bn(conv(images_nhwc, "conv1", stride=2, pad=3), P, "resnet50/conv1_bn"))
+    if taps is not None:
+        taps["stem_conv"] = x
+    xp = F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1), value=0.0)
+    x = F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1)
+    for li, nb in enumerate(blocks):
+        for b in range(nb):
+            q = f"conv{li + 2}_block{b + 1}"
+            stride = 2 if (b == 0 and li > 0) else 1
+            shortcut = keras_bn(conv(x, f"{q}_0", stride=stride), P, f"resnet50/{q}_0_bn") if b == 0 else x
+            y = torch.relu(keras_bn(conv(x, f"{q}_1", stride=stride), P, f"resnet50/{q}_1_bn"))
+            y = torch.relu(keras_bn(conv(y, f"{q}_2", pad=1), P, f"resnet50/{q}_2_bn"))
+            y = keras_bn(conv(y, f"{q}_3"), P, f"resnet50/{q}_3_bn")
+            x = torch.relu(shortcut + y)
         if taps is not None:
             taps[f"layer{li + 1}"] = x
     return x
@@ -316,7 +379,7 @@ def transformer(src_nhwc, pos_nhwc, query_embed, P, num_enc=6, num_dec=6, taps=N
 # --------------------------------------------------------------------------------------
 def detr_hs(images_nhwc, P, blocks=RESNET50_BLOCKS, num_enc=6, num_dec=6, taps=None, drop=None):
     """The inner Keras model "detr": images -> hs  (detr.py:170-177)."""
-    x = backbone(images_nhwc, P, blocks, taps)
+    x = backbone_tf(images_nhwc, P, blocks, taps) if "resnet50/conv1_conv/kernel" in P else backbone(images_nhwc, P, blocks, taps)
     B, H, W, _ = x.shape
     pos = position_embedding_sine(B, H, W, dtype=x.dtype)
     proj = conv2d_valid(x, P["input_proj/kernel"]) + P["input_proj/bias"]
