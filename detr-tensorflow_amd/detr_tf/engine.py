@@ -714,51 +714,72 @@ class DetrEngine:
         hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
         # ---------------- residual stages ----------------
         n_blocks = len(self._block_meta)
+        tfb = self.tf_backbone
+        f32c = 2 if adt == torch.bfloat16 else 1        # the subsample kernels copy 16-byte chunks: bf16 passes as C/2 "floats"
+
+        def bias_grad(conv, bn, dz, rows, cols):
+            """tf_backbone: db = scale * column sums of the gradient at the conv + BN output (the folded BN scales the bias)."""
+            if tfb:
+                hip.call("detr_hip_colsum_scaled", dz.data_ptr(), 1 if dz.dtype == torch.bfloat16 else 0, rows, cols, cols,
+                         self.bn_scale[bn].data_ptr(), G[f"{conv}/bias"].data_ptr())
+
         for bi in reversed(range(n_blocks)):
             m = self._block_meta[bi]
-            p, x, y1, y2 = m["p"], m["x"], m["y1"], m["y2"]
+            p, n, x, xs, x1, y1, y2 = m["p"], m["n"], m["x"], m["xs"], m["x1"], m["y1"], m["y2"]
             h, w, ho, wo, cin, d1, d2, stride = m["h"], m["w"], m["ho"], m["wo"], m["cin"], m["d1"], m["d2"], m["stride"]
+            h1, w1, M1, s2 = m["h1"], m["w1"], m["M1"], m["s2"]
             M_in, M_out = B * h * w, B * ho * wo
             wk = "ws16" if self.compute == 1 else "ws"       # scaled kernels of the forward (bf16 shadow in bf16 mode)
-            ws1 = self._bufs[f"{wk}:{p}/conv1/kernel"]
-            ws2 = self._bufs[f"{wk}:{p}/conv2/kernel"]
-            ws3 = self._bufs[f"{wk}:{p}/conv3/kernel"]
+            ws1 = self._bufs[f"{wk}:{n['conv1']}/kernel"]
+            ws2 = self._bufs[f"{wk}:{n['conv2']}/kernel"]
+            ws3 = self._bufs[f"{wk}:{n['conv3']}/kernel"]
             # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
-            self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{p}/conv3/kernel"], d2, scale=self.bn_scale[f"{p}/bn3"])
+            self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
+            bias_grad(n["conv3"], n["bn3"], g, M_out, d2)
             dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1), adt)
             hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
             # conv2 (3x3)
-            hip.conv3x3(2, y1, dz2, G[f"{p}/conv2/kernel"], B, h, w, d1, ho, wo, d1, stride, scale=self.bn_scale[f"{p}/bn2"])
-            dz1 = self.buf(f"scratch:dz1:{d1}:{h}", (B, h, w, d1), adt)
-            hip.conv3x3(1, dz2, ws2, dz1, B, h, w, d1, ho, wo, d1, stride, mask=y1)
+            hip.conv3x3(2, y1, dz2, G[f"{n['conv2']}/kernel"], B, h1, w1, d1, ho, wo, d1, s2, scale=self.bn_scale[n["bn2"]])
+            bias_grad(n["conv2"], n["bn2"], dz2, M_out, d1)
+            dz1 = self.buf(f"scratch:dz1:{d1}:{h1}", (B, h1, w1, d1), adt)
+            hip.conv3x3(1, dz2, ws2, dz1, B, h1, w1, d1, ho, wo, d1, s2, mask=y1)
             # conv1
-            self._wgrad(cin, d1, M_in, x, cin, dz1, d1, G[f"{p}/conv1/kernel"], d1, scale=self.bn_scale[f"{p}/bn1"])
+            self._wgrad(cin, d1, M1, x1, cin, dz1, d1, G[f"{n['conv1']}/kernel"], d1, scale=self.bn_scale[n["bn1"]])
+            bias_grad(n["conv1"], n["bn1"], dz1, M1, d1)
             is_first_block = bi == 0
             gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin), adt)
             mask = None if is_first_block else x           # x = ReLU output of the previous block
+            strided = m["first"] and stride == 2
             if m["first"]:
-                xs = m["xs"]
-                wsd = self._bufs[f"{wk}:{p}/downsample_0/kernel"]
-                self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{p}/downsample_0/kernel"], d2,
-                            scale=self.bn_scale[f"{p}/downsample_1"])
-                if stride == 2:
-                    dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
-                    hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
-                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
-                    hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w,
-                             cin // 2 if adt == torch.bfloat16 else cin, ho, wo)
-                else:
-                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
-                    hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
+                wsd = self._bufs[f"{wk}:{n['down']}/kernel"]
+                self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{n['down']}/kernel"], d2, scale=self.bn_scale[n["bnd"]])
+                bias_grad(n["down"], n["bnd"], g, M_out, d2)
+            if tfb and strided:
+                # both branches read the subsampled input: d_xs = g @ Wd^T + dz1 @ W1^T (ReLU-masked at the sampled pixels),
+                # scattered back into the zero-filled full-resolution gradient
+                dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
+                hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
+                hip.gemm(M_out, cin, d1, dz1, d1, 1, ws1, d1, 1, dxs, cin, residual=dxs, ldr=cin,
+                         mask=(None if is_first_block else xs), ldmask=(0 if is_first_block else cin))
+                hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), gx.data_ptr(), B, h, w, cin // f32c, ho, wo)
             else:
-                idg = g
-            hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
-                     ldmask=(cin if mask is not None else 0))
+                if m["first"]:
+                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
+                    if strided:
+                        dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
+                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
+                        hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin // f32c, ho, wo)
+                    else:
+                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
+                else:
+                    idg = g
+                hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
+                         ldmask=(cin if mask is not None else 0))
             g = gx
             if on_bucket:
-                if p == "backbone/layer4/0":
+                if p == block_names(3, 0, tfb)["tag"]:
                     on_bucket(1)
-                elif p == "backbone/layer3/0":
+                elif p == block_names(2, 0, tfb)["tag"]:
                     on_bucket(2)
         # ---------------- stem ----------------
         stem, pool, amax = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax"))
@@ -769,10 +790,13 @@ class DetrEngine:
                  amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
         if IMPLICIT_STEM:
             M1 = B * H1 * W1
-            hip.stem_conv(2, self.images, d_stem, G["backbone/conv1/kernel"], B, self._shape[1], self._shape[2], H1, W1,
-                          scale=self.bn_scale["backbone/bn1"], split=max(1, min(512, M1 // 4096)))
+            hip.stem_conv(2, self.images, d_stem, G[f"{self._stem['conv']}/kernel"], B, self._shape[1], self._shape[2], H1, W1,
+                          scale=self.bn_scale[self._stem["bn"]], split=max(1, min(512, M1 // 4096)))
         else:
-            self._wgrad(147, 64, B * H1 * W1, self._bufs["stem:col"], 160, d_stem, 64, G["backbone/conv1/kernel"], 64,
-                        scale=self.bn_scale["backbone/bn1"])
+            self._wgrad(147, 64, B * H1 * W1, self._bufs["stem:col"], 160, d_stem, 64, G[f"{self._stem['conv']}/kernel"], 64,
+                        scale=self.bn_scale[self._stem["bn"]])
+        if self.tf_backbone:
+            hip.call("detr_hip_colsum_scaled", d_stem.data_ptr(), 1 if d_stem.dtype == torch.bfloat16 else 0, B * H1 * W1, 64, 64,
+                     self.bn_scale[self._stem["bn"]].data_ptr(), G[f"{self._stem['conv']}/bias"].data_ptr())
         if on_bucket:
             on_bucket(3)

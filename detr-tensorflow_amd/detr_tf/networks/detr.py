@@ -29,7 +29,7 @@ class _Layer:
 
 class DetrModel:
     def __init__(self, include_top=True, nb_class=None, num_decoder_layers=6, num_encoder_layers=6, num_queries=100,
-                 backbone="resnet50", device=None, seed=0, dropout=0.1, precision="fp32"):
+                 backbone="resnet50", device=None, seed=0, dropout=0.1, precision="fp32", tf_backbone=False):
         device = device or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None)
         if device is None:
             raise RuntimeError("DETR HIP model needs a GPU: the hot path has no CPU fallback")
@@ -37,7 +37,9 @@ class DetrModel:
         self.include_top = include_top
         self.headless = (not include_top) and nb_class is None
         self.name = "detr" if self.headless else "detr_finetuning"
-        self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed)
+        self.tf_backbone = bool(tf_backbone)
+        self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed,
+                                 tf_backbone=tf_backbone)
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' (exact, parity mode) or 'bf16' (bf16 MFMA, fp32 storage/accumulate)")
         self.engine.compute = 1 if precision == "bf16" else 0
@@ -117,10 +119,15 @@ def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_ba
     extensions (the reference never exposes num_queries / ResNet101); `dropout` is the
     transformer dropout rate of training mode (the reference hard-codes 0.1, transformer.py:9)."""
     if tf_backbone:
-        raise NotImplementedError("tf_backbone=True (keras.applications ResNet50) is not on the HIP hot path yet")
+        # detr.py:146-148: the backbone becomes tf.keras.applications.ResNet50 (ResNet v1, conv biases, BatchNormalization in
+        # inference mode) and the data pipeline switches to the caffe-style BGR mean subtraction.  (The reference also
+        # downloads the ImageNet weights; here the backbone starts from the seeded random init unless `weights` is given.)
+        if backbone != "resnet50":
+            raise ValueError("tf_backbone=True is tf.keras.applications.ResNet50")
+        config.normalized_method = "tf_resnet"
     model = DetrModel(include_top=include_top, nb_class=nb_class, num_decoder_layers=num_decoder_layers,
                       num_encoder_layers=num_encoder_layers, num_queries=num_queries, backbone=backbone, device=device,
-                      seed=seed, dropout=dropout, precision=precision)
+                      seed=seed, dropout=dropout, precision=precision, tf_backbone=tf_backbone)
     if weights is not None:
         if isinstance(weights, str) and weights == "detr":
             raise NotImplementedError('weights="detr": the reference downloads a TF checkpoint from GCS (weights.py:5-11); convert the '

@@ -538,3 +538,54 @@ def test_c4_resnet101_full_size_forward_parity(hip):
     assert tuple(out["pred_logits"].shape) == (1, 100, 92)
     assert _rel(out["pred_logits"], ref["pred_logits"]) < 1e-3
     assert _rel(out["pred_boxes"], ref["pred_boxes"]) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_tf_backbone_variant_train_step_vs_oracle(hip, precision):
+    """SURVEY.md 8f row N4 -- get_detr_model(tf_backbone=True) (detr.py:146-148, the path train_coco.py:39 uses): the backbone is
+    tf.keras.applications.ResNet50 (ResNet v1: stride on the first 1x1 conv of a stage, conv biases, BatchNormalization
+    eps 1.001e-5 in inference mode), the config switches to the caffe-style normalisation.  fp32: forward, loss and every
+    gradient (conv biases included) against the oracle's autograd; bf16: deviation bounds."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg()
+    params = R.make_params(17, num_enc=1, num_dec=2, tf_backbone=True)
+    model = get_detr_model(cfg, include_top=True, tf_backbone=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0,
+                           precision=precision)
+    assert cfg.normalized_method == "tf_resnet"
+    assert not model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    assert len(opt["backbone_optimizer"].names) == 2 * 53 + 3          # 53 conv kernels + biases, input_proj (2), query_embed
+    images = np.random.default_rng(18).normal(size=(2, 128, 160, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=19, force_full=False)
+    out, total, log, steps = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    P = R.to_torch(params, requires_grad=True)
+    taps = {}
+    ref_out = R.detr_forward(torch.from_numpy(images), P, num_enc=1, num_dec=2, taps=taps)
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    ref_total.backward()
+    torch.cuda.synchronize()
+    eng = model.engine
+    dl, dloss = _rel(out["pred_logits"], ref_out["pred_logits"]), abs(float(total) - float(ref_total)) / abs(float(ref_total))
+    if precision == "fp32":
+        assert _rel(eng._bufs["stem:out"].float(), taps["stem_conv"]) < 1e-4
+        assert _rel(eng._bufs["resnet50/conv5_block3:out"].float(), taps["layer4"]) < 2e-4
+        assert dl < 2e-4 and dloss < 1e-3, (dl, dloss)
+        rows = _grad_report(eng, P)
+        bad = [r for r in rows if r[0] > 1.0]
+        assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
+        for name in steps:
+            training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], 0, cfg)
+        # the biases moved: the effective BN shift of the next forward must follow
+        b0 = eng.P.views["resnet50/conv2_block1_1_conv/bias"].clone()
+        assert not torch.equal(b0, torch.from_numpy(params["resnet50/conv2_block1_1_conv/bias"]).to(b0.device))
+        model(images, training=False)
+        want = eng.bn_scale["resnet50/conv2_block1_1_bn"] * b0 + eng._bufs["bnshift:resnet50/conv2_block1_1_bn"]
+        assert torch.allclose(eng.bn_shift["resnet50/conv2_block1_1_bn"], want, rtol=1e-6, atol=1e-7)
+    else:
+        assert dl < 3e-2 and dloss < 2e-2, (dl, dloss)
+        g = eng.P.gviews["resnet50/conv3_block1_0_conv/bias"].cpu().double()
+        r = P["resnet50/conv3_block1_0_conv/bias"].grad.double()
+        assert float((g - r).norm() / r.norm()) < 0.2

@@ -109,3 +109,49 @@ def test_hip_forward_equals_huggingface_detr_on_mapped_weights(hip, tmp_path):
     assert torch.equal(m2.engine.P.flat, m.engine.P.flat)
     with pytest.raises(NotImplementedError):
         get_detr_model(TrainingConfig(), include_top=True, weights="detr")
+
+
+def test_oracle_keras_resnet50_wiring_equals_huggingface_resnet_v1():
+    """tf_backbone=True: the oracle's restatement of tf.keras.applications.ResNet50 (third-party; ResNet v1 with the stride on
+    the FIRST 1x1 conv of a stage) against an independent implementation of the same wiring -- HuggingFace ResNetModel with
+    downsample_in_bottleneck=True (no conv biases there: the oracle's are set to zero; BN eps 1e-5 vs Keras' 1.001e-5)."""
+    transformers = pytest.importorskip("transformers")
+    from oracle import detr_ref as R
+    torch.manual_seed(3)
+    cfg = transformers.ResNetConfig(downsample_in_bottleneck=True, out_features=["stage4"])
+    m = transformers.ResNetModel(cfg).eval()
+    with torch.no_grad():
+        for name, buf in m.named_buffers():
+            if name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+            elif name.endswith("running_mean"):
+                buf.normal_(0.0, 0.1)
+        for name, p in m.named_parameters():
+            if name.endswith("normalization.weight"):
+                p.uniform_(0.2, 0.4) if ".layer.2." in name else p.uniform_(0.5, 1.5)
+            elif name.endswith("normalization.bias"):
+                p.normal_(0.0, 0.1)
+    sd = m.state_dict()
+    P = {}
+
+    def put(src_conv, src_bn, dst):
+        P[f"resnet50/{dst}_conv/kernel"] = sd[src_conv + ".weight"].permute(2, 3, 1, 0).contiguous()
+        P[f"resnet50/{dst}_conv/bias"] = torch.zeros(sd[src_conv + ".weight"].shape[0])
+        for a, b in (("weight", "gamma"), ("bias", "beta"), ("running_mean", "moving_mean"), ("running_var", "moving_variance")):
+            P[f"resnet50/{dst}_bn/{b}"] = sd[f"{src_bn}.{a}"]
+
+    put("embedder.embedder.convolution", "embedder.embedder.normalization", "conv1")
+    for s_, nb in enumerate((3, 4, 6, 3)):
+        for b in range(nb):
+            pre, q = f"encoder.stages.{s_}.layers.{b}", f"conv{s_ + 2}_block{b + 1}"
+            if b == 0:
+                put(f"{pre}.shortcut.convolution", f"{pre}.shortcut.normalization", f"{q}_0")
+            for k in range(3):
+                put(f"{pre}.layer.{k}.convolution", f"{pre}.layer.{k}.normalization", f"{q}_{k + 1}")
+    assert set(P) == {k for k in R.param_shapes(tf_backbone=True) if k.startswith("resnet50/")}
+    x = torch.randn(2, 3, 96, 128)
+    with torch.no_grad():
+        ref = m(x).last_hidden_state                       # [2, 2048, 3, 4]
+        ours = R.backbone_tf(x.permute(0, 2, 3, 1).contiguous(), P).permute(0, 3, 1, 2)
+    assert ours.shape == ref.shape
+    assert _rel(ours, ref) < 1e-4, _rel(ours, ref)
