@@ -18,6 +18,8 @@ for w in "$@"; do
     bench_f32) timeout 600 python bench.py --steps 5 --warmup 2 --precision fp32 --no-cpu-baseline --dump-shapes $OUT/shapes_f32.json > $OUT/bench_f32.log 2>&1; echo "bench_f32 rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench_f32.log | cut -c1-800 ;;
     prof16) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt
           python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 > $OUT/prof16_summary.txt 2>&1; head -70 $OUT/prof16_summary.txt ;;
+    n4) timeout 600 python -m pytest tests/test_gpu_model.py -k "tf_backbone" tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider > $OUT/n4.log 2>&1; echo "n4 rc=$?" >> $OUT/summary.txt; tail -30 $OUT/n4.log ;;
+    ab_split) for v in 1 2; do DETR_HIP_SPLIT_XCD=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --dump-shapes $OUT/shapes_split$v.json > $OUT/bench_split$v.log 2>&1; echo "split$v rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_split$v.log | cut -c1-330; done ;;
     *) echo "unknown $w" ;;
   esac
 done
