@@ -6,7 +6,6 @@
 // Reference: detr_tf/networks/resnet_backbone.py:11-32,98-137 (see include/detr_hip.h).
 #include "gemm_core.h"
 #include "gemm_bf16_core.h"
-#include "conv_stream.h"
 
 namespace detr {
 
@@ -1159,23 +1158,6 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         else if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         DETR_LAUNCH_CHECK("conv3x3 wgrad");
-        return 0;
-    }
-    // streaming kernel for the 64-channel stride-1 convs in bf16 storage (conv_stream.h); opt-in: DETR_HIP_CONV_STREAM=1
-    if (d->compute == 1 && d->stride == 1 && d->pad == 1 && d->Ci == 64 && d->Co == 64 && d->w_dtype == 1 && d->x_dtype == 1 &&
-        d->y_dtype == 1 && !d->residual && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) &&
-        (!d->mask || d->m_dtype == 1) && env_tile("DETR_HIP_CONV_STREAM") == 1) {
-        ConvStreamArgs c;
-        c.N = d->N; c.H = d->Hi; c.W = d->Wi; c.M = d->N * d->Hi * d->Wi;
-        c.src = reinterpret_cast<const unsigned short *>(d->x);
-        c.w = reinterpret_cast<const unsigned short *>(d->w);
-        c.dst = reinterpret_cast<unsigned short *>(d->y);
-        c.mask = reinterpret_cast<const unsigned short *>(d->mask);
-        c.bias = d->bias;
-        c.act = d->act;
-        c.row_tiles = 0;
-        DETR_REQUIRE(launch_conv_stream(c, mode == 1, s) == 0, "conv3x3 (stream): cannot reserve %d bytes of LDS", CS_SMEM);
-        DETR_LAUNCH_CHECK("conv3x3 (stream)");
         return 0;
     }
     ConvArgs a;

@@ -31,8 +31,6 @@ FF = 2048
 BN_EPS = 1e-5
 KERAS_BN_EPS = 1.001e-5      # tf.keras.applications.resnet BatchNormalization(epsilon=1.001e-5) (tf_backbone=True)
 LN_EPS = 1e-5
-# implicit-GEMM stem convolution (default) vs the im2col buffer + GEMM path (DETR_HIP_IMPLICIT_STEM=0)
-IMPLICIT_STEM = os.environ.get("DETR_HIP_IMPLICIT_STEM", "1") != "0"
 # bf16 STORAGE of the backbone activations and their gradients in precision="bf16" (default on; DETR_HIP_ACT16=0 keeps
 # fp32 storage with bf16 MFMA operands only)
 ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
@@ -421,12 +419,8 @@ class DetrEngine:
         adt = torch.bfloat16 if (self.compute == 1 and ACT16) else torch.float32      # storage type of backbone activations
         self._adt = adt
         stem = self.buf("stem:out", (B, H1, W1, 64), adt)
-        if IMPLICIT_STEM:       # implicit GEMM: the 7x7x3 patches are gathered from the image by the A loader (stem_conv.hip)
-            hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift[self._stem["bn"]], act=1)
-        else:                   # im2col buffer + GEMM (DETR_HIP_IMPLICIT_STEM=0)
-            col = self.buf("stem:col", (M1, 160))
-            hip.call("detr_hip_stem_im2col_f32", images.data_ptr(), col.data_ptr(), B, H, W, H1, W1, 160)
-            hip.gemm(M1, 64, 147, col, 160, 1, ws, 64, 0, stem, 64, bias=self.bn_shift[self._stem["bn"]], act=1)
+        # implicit GEMM: the 7x7x3 patches are gathered from the image by the A loader (stem_conv.hip), no im2col buffer
+        hip.stem_conv(0, images, ws, stem, B, H, W, H1, W1, bias=self.bn_shift[self._stem["bn"]], act=1)
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         pool = self.buf("stem:pool", (B, H2, W2, 64), adt)
         amax = self.buf("stem:amax", (B, H2, W2, 64), torch.uint8)
@@ -788,13 +782,9 @@ class DetrEngine:
         d_stem = self.buf("scratch:d_stem", stem.shape, adt)
         hip.call("detr_hip_maxpool3x3s2_bwd_bf16" if adt == torch.bfloat16 else "detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(),
                  amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
-        if IMPLICIT_STEM:
-            M1 = B * H1 * W1
-            hip.stem_conv(2, self.images, d_stem, G[f"{self._stem['conv']}/kernel"], B, self._shape[1], self._shape[2], H1, W1,
-                          scale=self.bn_scale[self._stem["bn"]], split=max(1, min(512, M1 // 4096)))
-        else:
-            self._wgrad(147, 64, B * H1 * W1, self._bufs["stem:col"], 160, d_stem, 64, G[f"{self._stem['conv']}/kernel"], 64,
-                        scale=self.bn_scale[self._stem["bn"]])
+        M1 = B * H1 * W1
+        hip.stem_conv(2, self.images, d_stem, G[f"{self._stem['conv']}/kernel"], B, self._shape[1], self._shape[2], H1, W1,
+                      scale=self.bn_scale[self._stem["bn"]], split=max(1, min(512, M1 // 4096)))
         if self.tf_backbone:
             hip.call("detr_hip_colsum_scaled", d_stem.data_ptr(), 1 if d_stem.dtype == torch.bfloat16 else 0, B * H1 * W1, 64, 64,
                      self.bn_scale[self._stem["bn"]].data_ptr(), G[f"{self._stem['conv']}/bias"].data_ptr())
