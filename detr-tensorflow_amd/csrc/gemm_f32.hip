@@ -392,6 +392,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroupArg
                           r.rs_alpha, blockIdx.x, r.nblocks);
 }
 
+constexpr int REDUCE_MANY = 16;
+struct ReduceManyArgs { ReduceOne r[REDUCE_MANY]; };
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceManyArgs R) {
+    const ReduceOne &r = R.r[blockIdx.y];
+    if ((int)blockIdx.x >= r.nblocks) return;
+    splitk_reduce_body<G>(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, r.vec, r.rs_ws, r.rs_out,
+                          r.rs_alpha, blockIdx.x, r.nblocks);
+}
+
 static void reduce_plan(ReduceOne &r, bool &small) {
     r.vec = (r.cols % 4 == 0) && (r.ldc % 4 == 0) && (r.part_stride % 4 == 0) && aligned16(r.ws) && aligned16(r.C) &&
             (!r.scale || aligned16(r.scale));
@@ -649,6 +659,15 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     else if (p.tile == 5) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
     else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     DETR_LAUNCH_CHECK("gemm");
+    if (p.partial && d->defer_out) {      // the caller reduces later, many slabs per launch (detr_hip_splitk_reduce_many)
+        detr_reduce_desc *o = d->defer_out;
+        o->ws = d->workspace; o->splits = p.split; o->part_stride = p.part; o->rows = d->M; o->cols = d->N;
+        o->C = d->C; o->ldc = d->ldc; o->alpha = p.final_e.alpha; o->scale = p.final_e.scale;
+        o->rs_ws = d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr;
+        o->rs_out = d->rowsum_a; o->rs_alpha = d->rowsum_alpha;
+        return 0;
+    }
+    if (d->defer_out) d->defer_out->splits = 0;
     if (p.partial) {
         launch_splitk_reduce(d->workspace, p.split, p.part, d->M, d->N, d->C, d->ldc, p.final_e.alpha, p.final_e.scale, s,
                              d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr, d->rowsum_a, d->rowsum_alpha);
@@ -724,14 +743,25 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         else launch_group_f32<false, false>(G, grid, s);
 #undef DETR_GROUP_BF16
         DETR_LAUNCH_CHECK("gemm group");
-        // the members' split-K reductions, again as one launch
+        // the members' split-K reductions, again as one launch (or handed back to the caller: detr_gemm_desc.defer_out)
         ReduceGroupArgs R;
         int nr = 0;
         unsigned rx = 1;
         bool all_small = true, any_small = false;
         for (int i = 0; i < m; ++i) {
-            if (!p[i].partial) continue;
             const detr_gemm_desc *d = p[i].d;
+            if (d->defer_out) {
+                detr_reduce_desc *o = d->defer_out;
+                o->splits = 0;
+                if (p[i].partial) {
+                    o->ws = d->workspace; o->splits = p[i].split; o->part_stride = p[i].part; o->rows = d->M; o->cols = d->N;
+                    o->C = d->C; o->ldc = d->ldc; o->alpha = p[i].final_e.alpha; o->scale = p[i].final_e.scale;
+                    o->rs_ws = d->rowsum_a ? d->workspace + (long long)p[i].split * p[i].part : nullptr;
+                    o->rs_out = d->rowsum_a; o->rs_alpha = d->rowsum_alpha;
+                }
+                continue;
+            }
+            if (!p[i].partial) continue;
             ReduceOne &r = R.r[nr];
             r.ws = d->workspace; r.splits = p[i].split; r.part_stride = p[i].part; r.rows = d->M; r.cols = d->N;
             r.C = d->C; r.ldc = d->ldc; r.alpha = p[i].final_e.alpha; r.scale = p[i].final_e.scale;
@@ -759,5 +789,43 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         }
         done += m;
     }
+    return 0;
+}
+
+
+// Deferred split-K reductions (detr_gemm_desc.defer_out): n slab sets reduced by ceil(n / 16) launches per size class instead of
+// one launch each -- the ~90 reductions of a training step were ~9 us latency-bound launches (rocprofv3: 0.9 ms per step).
+extern "C" int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_t n, void *stream) {
+    DETR_REQUIRE(descs != nullptr && n >= 1, "splitk_reduce_many: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    for (int pass = 0; pass < 2; ++pass) {           // pass 0: small outputs (16 split groups per block), pass 1: large ones
+        ReduceManyArgs R;
+        int cnt = 0;
+        unsigned rx = 1;
+        auto flush = [&]() {
+            if (cnt == 0) return;
+            for (int i = cnt; i < REDUCE_MANY; ++i) R.r[i] = R.r[0];
+            if (pass == 0) hipLaunchKernelGGL(splitk_reduce_many_kernel<16>, dim3(rx, (unsigned)cnt), dim3(256), 0, s, R);
+            else hipLaunchKernelGGL(splitk_reduce_many_kernel<4>, dim3(rx, (unsigned)cnt), dim3(256), 0, s, R);
+            cnt = 0;
+            rx = 1;
+        };
+        for (int i = 0; i < n; ++i) {
+            const detr_reduce_desc &d = descs[i];
+            if (d.splits <= 0) continue;
+            DETR_REQUIRE(d.ws && d.C && d.rows > 0 && d.cols > 0, "splitk_reduce_many: entry %d is malformed", i);
+            ReduceOne r;
+            r.ws = d.ws; r.splits = d.splits; r.part_stride = d.part_stride; r.rows = d.rows; r.cols = d.cols; r.C = d.C; r.ldc = d.ldc;
+            r.alpha = d.alpha; r.scale = d.scale; r.rs_ws = d.rs_ws; r.rs_out = d.rs_out; r.rs_alpha = d.rs_alpha;
+            bool small;
+            reduce_plan(r, small);
+            if (small != (pass == 0)) continue;
+            R.r[cnt++] = r;
+            rx = (unsigned)r.nblocks > rx ? (unsigned)r.nblocks : rx;
+            if (cnt == REDUCE_MANY) flush();
+        }
+        flush();
+    }
+    DETR_LAUNCH_CHECK("splitk_reduce_many");
     return 0;
 }

@@ -16,6 +16,12 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdetr_hip.so")
 f32p = c_void_p
 
 
+class ReduceDesc(Structure):
+    _fields_ = [("ws", c_void_p), ("splits", c_int32), ("part_stride", c_int64), ("rows", c_int32), ("cols", c_int32),
+                ("C", c_void_p), ("ldc", c_int64), ("alpha", c_float), ("scale", c_void_p),
+                ("rs_ws", c_void_p), ("rs_out", c_void_p), ("rs_alpha", c_float)]
+
+
 class GemmDesc(Structure):
     _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32),
                 ("A", c_void_p), ("lda", c_int64), ("a_kcontig", c_int32),
@@ -33,7 +39,7 @@ class GemmDesc(Structure):
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
                 ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32),
                 ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32),
-                ("dropout_step", c_void_p)]
+                ("dropout_step", c_void_p), ("defer_out", POINTER(ReduceDesc))]
 
 
 class AttnDesc(Structure):
@@ -105,6 +111,7 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_gemm_group_f32": [POINTER(GemmDesc), c_int32, c_void_p],
+    "detr_hip_splitk_reduce_many": [POINTER(ReduceDesc), c_int32, c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -208,6 +215,12 @@ class KernelProfiler:
 
 
 PROFILER = None
+# Deferred split-K reductions: while DEFER is a list (the engine's backward pass), every split-K GEMM gets a private slab from
+# the bump allocator over DEFER_WS and only DESCRIBES its reduction; flush_reduces() then reduces up to 16 slab sets per launch.
+DEFER = None
+DEFER_WS = None
+_defer_top = 0
+_defer_outs = set()
 COMPUTE_BF16 = 0      # default compute mode of gemm / conv3x3: 0 = exact fp32 MFMA, 1 = bf16 MFMA (fp32 storage)
 WORKSPACE = None      # fp32 scratch tensor for the deterministic split-K reductions (set by the engine)
 
@@ -218,6 +231,66 @@ def ensure_workspace(device, floats=64 * 1024 * 1024):
     if WORKSPACE is None or WORKSPACE.device != torch.device(device) or WORKSPACE.numel() < floats:
         WORKSPACE = torch.empty(floats, dtype=torch.float32, device=device)
     return WORKSPACE
+
+
+DEFER_LIMIT = int(os.environ.get("DETR_HIP_DEFER_MB", "512")) * 1024 * 1024     # pending slab bytes that trigger a flush
+
+
+def ensure_defer_workspace(device):
+    """Slab pool of the queued split-K reductions: twice the flush threshold (a launch may overshoot it by its own slabs)."""
+    global DEFER_WS
+    nbytes = 2 * DEFER_LIMIT
+    if DEFER_WS is None or DEFER_WS.device != torch.device(device) or DEFER_WS.numel() * 4 < nbytes:
+        DEFER_WS = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return DEFER_WS
+
+
+def begin_deferred_reduces(device):
+    global DEFER, _defer_top, _defer_outs
+    ensure_defer_workspace(device)
+    DEFER, _defer_top, _defer_outs = [], 0, set()
+
+
+def flush_reduces(end=False):
+    """Reduce everything pending (bucket boundary / a consumer of the gradients / end of the backward pass): up to 16 slab
+    sets per launch; the slabs become reusable."""
+    global DEFER, _defer_top, _defer_outs
+    if DEFER is None:
+        return
+    if DEFER:
+        arr = (ReduceDesc * len(DEFER))(*DEFER)
+        _check(load().detr_hip_splitk_reduce_many(arr, len(DEFER), _stream()), "detr_hip_splitk_reduce_many")
+    _defer_top, _defer_outs = 0, set()
+    DEFER = None if end else []
+
+
+def _defer_push(rds):
+    """Queue the reductions a launch described.  Two reductions into the same output would race inside one grouped launch
+    (read-modify-write of C): the earlier ones are flushed first.  A full slab pool flushes too."""
+    rds = [r for r in rds if r is not None and r.splits > 0]
+    outs = [r.C for r in rds] + [r.rs_out for r in rds if r.rs_out]
+    if len(set(outs)) != len(outs) or any(o in _defer_outs for o in outs):
+        flush_reduces()
+        if len(set(outs)) != len(outs):          # duplicates inside one group: one launch each
+            for r in rds:
+                DEFER.append(r)
+                flush_reduces()
+            return
+    DEFER.extend(rds)
+    _defer_outs.update(outs)
+    if _defer_top >= DEFER_LIMIT:
+        flush_reduces()
+
+
+def _defer_slab(nbytes):
+    """256-byte aligned share of DEFER_WS, or None when it is full (the caller then reduces immediately)."""
+    global _defer_top
+    nbytes = (nbytes + 255) & ~255
+    if _defer_top + nbytes > DEFER_WS.numel() * 4:
+        return None
+    ptr_ = DEFER_WS.data_ptr() + _defer_top
+    _defer_top += nbytes
+    return ptr_, nbytes
 
 
 def load():
@@ -296,6 +369,13 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
         idx, cnt = ws_slice
         share = (ws.numel() * 4 // cnt) & ~255
         d.workspace, d.workspace_bytes = ws.data_ptr() + idx * share, share
+    rd = None
+    if DEFER is not None and split_k > 1 and batch == 1 and workspace is None:
+        slab = _defer_slab(split_k * (M * N + M) * 4)
+        if slab is not None:
+            rd = ReduceDesc()
+            d.workspace, d.workspace_bytes = slab
+            d.defer_out = ctypes.pointer(rd)
     tf = lambda v: "true" if v else "false"      # family = the kernel symbol as rocprofv3 names it (tile sizes pooled)
     fam = (f"gemm_bf16c_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}, {tf(d.a_dtype)}, {tf(d.b_dtype)}>" if d.compute == 1
            else f"gemm_f32_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}>")
@@ -310,14 +390,16 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     nbytes = float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
                              + (residual.element_size() * M * N if residual is not None else 0)
                              + (mask.element_size() * M * N if mask is not None else 0))     # algorithmic bytes at the stored widths
-    return d, (fam, 2.0 * M * N * K * batch, sig, nbytes)
+    return d, (fam, 2.0 * M * N * K * batch, sig, nbytes, rd)
 
 
 def gemm(*args, **kw):
     """C = epi(A @ B) on raw layouts (see detr_gemm_desc).  *_off are element offsets."""
-    d, (fam, flops, sig, nbytes) = _gemm_desc(*args, **kw)
+    d, (fam, flops, sig, nbytes, rd) = _gemm_desc(*args, **kw)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_f32(byref(d), _stream()), "detr_hip_gemm_f32")
+    if rd is not None:
+        _defer_push([rd])
     if ev0 is not None:
         PROFILER.end(fam, flops, ev0, sig, nbytes)
 
@@ -335,6 +417,8 @@ def gemm_group(calls):
         infos.append(info)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_gemm_group_f32(arr, n, _stream()), "detr_hip_gemm_group_f32")
+    if DEFER is not None:
+        _defer_push([info[4] for info in infos])
     if ev0 is not None:
         PROFILER.end(infos[0][0], sum(i[1] for i in infos), ev0, f"group{n}: " + infos[0][2], sum(i[3] for i in infos))
 

@@ -36,6 +36,7 @@ LN_EPS = 1e-5
 ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
 # bf16 STORAGE of the FFN hidden activation in precision="bf16" (bit-identical: it only feeds GEMM operands; DETR_HIP_H16=0 = fp32)
 H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
+DEFER_REDUCE = os.environ.get("DETR_HIP_DEFER_REDUCE", "1") != "0"     # queue the weight gradients' split-K reductions (A/B switch)
 
 
 def mix32(x):
@@ -78,6 +79,8 @@ class DetrEngine:
         hip.load()
         self.device = torch.device(device)
         hip.ensure_workspace(self.device)
+        if DEFER_REDUCE:
+            hip.ensure_defer_workspace(self.device)        # allocated here, never inside a graph capture
         self.blocks = tuple(blocks)
         self.num_enc, self.num_dec, self.Q = num_enc, num_dec, num_queries
         self.nb_class = nb_class
@@ -391,10 +394,22 @@ class DetrEngine:
 
     def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
         hip.COMPUTE_BF16 = self.compute
+        cb = on_bucket
+        if DEFER_REDUCE:
+            # the weight gradients are only read by the bucket exchange / the optimiser: their split-K reductions are queued
+            # and run 16 per launch (hip.flush_reduces) instead of one ~9 us latency-bound launch behind every GEMM
+            hip.begin_deferred_reduces(self.device)
+            if on_bucket:
+                def cb(i):
+                    hip.flush_reduces()
+                    on_bucket(i)
         try:
-            return self._backward_impl(d_logits, d_boxes, backbone, on_bucket)
+            return self._backward_impl(d_logits, d_boxes, backbone, cb)
         finally:
-            hip.COMPUTE_BF16 = 0
+            try:
+                hip.flush_reduces(end=True)
+            finally:
+                hip.COMPUTE_BF16 = 0
 
     def _forward_impl(self, images, training=False):
         """images: CUDA fp32 NHWC [B,H,W,3] (already normalised, processing.py:12-16).
@@ -675,6 +690,7 @@ class DetrEngine:
         hip.zero_(ct["gb"])
         hip.gemm_group([hip.linear_wgrad_call(dKV[:, 0:nd * D], mem_pos, ct["gW"][0:nd * D], bias_grad=ct["gb"][0:nd * D]),
                         hip.linear_wgrad_call(dKV[:, nd * D:], memory, ct["gW"][nd * D:], bias_grad=ct["gb"][nd * D:])])
+        hip.flush_reduces()                            # the scatter reads the gathered gradient
         hip.multi_copy(ct["scatter"])
         d_mem = self.buf("scratch:d_mem", (B * L, D))
         hip.linear_dgrad(dKV, ct["Wkv"], d_mem)        # d(memory + pos) through K and d(memory) through V land on the same tensor

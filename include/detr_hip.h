@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 2
+#define DETR_HIP_ABI_VERSION 3
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -51,6 +51,15 @@ int detr_hip_memset_zero(void *ptr, size_t bytes, void *stream);
  *     atomically ADDED to C (C must hold zeros or the value to accumulate onto); only
  *     scale and alpha are allowed in the epilogue then.
  * ------------------------------------------------------------------------------------------- */
+/* one deferred deterministic split-K reduction: C[r][c] += alpha * scale[c] * sum_s ws[s*part_stride + r*cols + c]
+ * (+ the fused bias gradient rs_out[r] += rs_alpha * sum_s rs_ws[s*rows + r]); filled by detr_hip_gemm_f32 /
+ * detr_hip_gemm_group_f32 when detr_gemm_desc.defer_out is set, consumed by detr_hip_splitk_reduce_many */
+typedef struct detr_reduce_desc {
+    const float *ws; int32_t splits; int64_t part_stride; int32_t rows, cols;
+    float *C; int64_t ldc; float alpha; const float *scale;
+    const float *rs_ws; float *rs_out; float rs_alpha;
+} detr_reduce_desc;
+
 typedef struct {
     int32_t M, N, K;
     const float *A; int64_t lda; int32_t a_kcontig;
@@ -93,8 +102,13 @@ typedef struct {
      * fp32 and the result is rounded once.  Not with split_k / batch (partial slabs and gradients of parameters stay fp32). */
     int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask */
     const uint32_t *dropout_step;                   /* see dropout_p */
+    /* optional (HOST pointer): with deterministic split-K, do not launch the reduction but describe it here (splits = 0 when
+     * no reduction is pending); the caller keeps `workspace` intact and reduces many slabs per launch with
+     * detr_hip_splitk_reduce_many -- the weight gradients of a backward pass are only needed by the optimiser */
+    detr_reduce_desc *defer_out;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
+int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_t n, void *stream);
 /* n independent GEMMs in one call.  Consecutive members (up to 4) that share one kernel variant -- 64x64 tiles, same operand
  * layouts / storage types, no batch -- are issued as ONE launch (members on blockIdx.y) and their split-K reductions as one
  * more; otherwise the members are launched one after the other.  Members must not alias each other's outputs or workspaces.

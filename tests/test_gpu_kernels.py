@@ -1059,6 +1059,51 @@ def test_gemm_group_matches_individual_launches(hip, compute):
         hip.COMPUTE_BF16 = old
 
 
+@pytest.mark.parametrize("compute", [0, 1])
+def test_deferred_split_k_reductions_match_immediate(hip, compute):
+    """detr_gemm_desc.defer_out + detr_hip_splitk_reduce_many: 20 weight-gradient GEMMs (plain and grouped, with fused bias
+    gradients, small and large outputs, one output hit twice) whose reductions are queued and run 16 per launch give
+    bit-identical results to the immediate reductions (same reduction body, same summation order)."""
+    torch.manual_seed(60 + compute)
+    hip.ensure_workspace(DEV)
+    M = 8400
+    shapes = [(256, 256)] * 6 + [(256, 2048), (2048, 256), (128, 64), (92, 256)] * 3 + [(256, 256)] * 2
+    xs = [g(torch.randn(M, k)) for (n, k) in shapes]
+    dys = [g(torch.randn(M, n)) for (n, k) in shapes]
+    def run(deferred):
+        dws = [torch.zeros(n, k, device=DEV) for (n, k) in shapes]
+        dbs = [torch.zeros(n, device=DEV) for (n, k) in shapes]
+        dws[-1], dbs[-1] = dws[0], dbs[0]                       # two reductions into one gradient: must not share a launch
+        calls = [hip.linear_wgrad_call(dys[i], xs[i], dws[i], alpha=(0.5 if i % 3 == 0 else 1.0), bias_grad=dbs[i])
+                 for i in range(len(shapes))]
+        if deferred:
+            hip.begin_deferred_reduces(DEV)
+        try:
+            hip.gemm_group(calls[0:3])
+            hip.gemm_group(calls[3:6])
+            for a, kw in calls[6:]:
+                hip.gemm(*a, **kw)
+            if deferred:
+                assert hip.DEFER is not None and len(hip.DEFER) >= 1
+                assert float(dws[7].abs().max()) == 0.0, "a deferred reduction ran early"
+        finally:
+            hip.flush_reduces(end=True)
+        assert hip.DEFER is None
+        torch.cuda.synchronize()
+        return dws, dbs
+    old = hip.COMPUTE_BF16
+    hip.COMPUTE_BF16 = compute
+    try:
+        (w_i, b_i), (w_d, b_d) = run(False), run(True)
+    finally:
+        hip.COMPUTE_BF16 = old
+    for i in range(len(shapes)):
+        assert torch.equal(w_i[i], w_d[i]) and torch.equal(b_i[i], b_d[i]), f"deferred wgrad {i} {shapes[i]} differs"
+        assert float(w_i[i].abs().max()) > 0
+    ref = dys[1].double().t() @ xs[1].double()
+    assert (w_d[1].double() - ref).abs().max() < (2.0 if compute else 2e-2)
+
+
 def test_gemm_bf16_compute_split_k(hip):
     torch.manual_seed(31)
     M, N, K = 256, 512, 20000

@@ -127,6 +127,32 @@ def test_backward_vs_oracle_autograd(hip, small):
     assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
 
 
+def test_backward_immediate_split_k_reductions_vs_oracle(hip, small, monkeypatch):
+    """The A/B switch of the queued split-K reductions (engine.DEFER_REDUCE, default on -- every other test of this file runs
+    with it): with immediate reductions the gradients still match the oracle, and the two modes agree to rounding (the set
+    loss sums use fp32 atomics, so two runs differ by ulps; the reductions themselves are bit-identical, test_gpu_kernels)."""
+    from detr_tf import engine as E, training
+    from detr_tf.optimizers import setup_optimizers
+    from oracle import detr_ref as R, set_loss_ref as L
+    model = small["model"]
+    opt = setup_optimizers(model, small["cfg"])
+    assert E.DEFER_REDUCE
+    training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
+    torch.cuda.synchronize()
+    g_def = model.engine.P.grad.clone()
+    monkeypatch.setattr(E, "DEFER_REDUCE", False)
+    training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
+    torch.cuda.synchronize()
+    g_imm = model.engine.P.grad.clone()
+    assert float((g_def - g_imm).norm()) <= 1e-5 * float(g_imm.norm())
+    P = R.to_torch(small["params"], requires_grad=True)
+    ref_out = R.detr_forward(torch.from_numpy(small["images"]), P)
+    ref_total, _ = L.get_losses(ref_out, torch.from_numpy(small["t_bbox"]), torch.from_numpy(small["t_class"]), 91)
+    ref_total.backward()
+    bad = [r for r in _grad_report(model.engine, P) if r[0] > 1.0]
+    assert not bad, f"gradient mismatch with immediate reductions: {bad[:12]}"
+
+
 def test_backward_small_shapes_vs_oracle(hip):
     """Same check on the reduced model / tiny feature map (3x4 tokens) used by the train-step test:
     exercises the partial-tile and split-free code paths of every backward kernel."""
