@@ -25,6 +25,8 @@ for w in "$@"; do
     listpmc) (cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 -L > /root/repo/$OUT/pmc_avail.txt 2>&1); grep -c "SQ_" $OUT/pmc_avail.txt ;;
     pmc16) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $c -d /root/repo/$OUT/pmc_$c -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/pmc_$c.log 2>&1); echo "pmc $c rc=$?" >> $OUT/summary.txt; done
           python scripts/pmc_summary.py $OUT gemm_stream $OUT/traffic_bf16.json > $OUT/pmc_hbm_summary.txt 2>&1; head -30 $OUT/pmc_hbm_summary.txt; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
+    pmc32) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $c -d /root/repo/$OUT/pmc_$c -o pmc -- python /root/repo/bench.py --steps 1 --warmup 1 --precision fp32 --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/pmc32_$c.log 2>&1); echo "pmc32 $c rc=$?" >> $OUT/summary.txt; done
+          python scripts/pmc_summary.py $OUT gemm_f32 $OUT/traffic.json > $OUT/pmc_hbm_summary_fp32.txt 2>&1; head -12 $OUT/pmc_hbm_summary_fp32.txt; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
     sqA) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d /root/repo/$OUT/pmc_SQ -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" >> $OUT/summary.txt
           python scripts/pmc_sq_summary.py $OUT pmc_SQ > $OUT/pmc_sq_summary.txt 2>&1; head -40 $OUT/pmc_sq_summary.txt | cut -c1-120; rm -rf $OUT/pmc_SQ ;;
     sqB) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d /root/repo/$OUT/pmc_SQB -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --no-graph > /root/repo/$OUT/pmc_SQB.log 2>&1); echo "pmc SQB rc=$?" >> $OUT/summary.txt
