@@ -1067,13 +1067,13 @@ def test_deferred_split_k_reductions_match_immediate(hip, compute):
     torch.manual_seed(60 + compute)
     hip.ensure_workspace(DEV)
     M = 8400
-    shapes = [(256, 256)] * 6 + [(256, 2048), (2048, 256), (128, 64), (92, 256)] * 3 + [(256, 256)] * 2
+    shapes = [(256, 256)] * 6 + [(256, 2048), (2048, 256), (256, 256)] + [(128, 64), (92, 256), (256, 2048), (2048, 256)] * 3
     xs = [g(torch.randn(M, k)) for (n, k) in shapes]
     dys = [g(torch.randn(M, n)) for (n, k) in shapes]
     def run(deferred):
         dws = [torch.zeros(n, k, device=DEV) for (n, k) in shapes]
         dbs = [torch.zeros(n, device=DEV) for (n, k) in shapes]
-        dws[-1], dbs[-1] = dws[0], dbs[0]                       # two reductions into one gradient: must not share a launch
+        dws[8], dbs[8] = dws[0], dbs[0]          # two reductions into one gradient must not share a launch: the queue is flushed
         calls = [hip.linear_wgrad_call(dys[i], xs[i], dws[i], alpha=(0.5 if i % 3 == 0 else 1.0), bias_grad=dbs[i])
                  for i in range(len(shapes))]
         if deferred:
@@ -1085,7 +1085,8 @@ def test_deferred_split_k_reductions_match_immediate(hip, compute):
                 hip.gemm(*a, **kw)
             if deferred:
                 assert hip.DEFER is not None and len(hip.DEFER) >= 1
-                assert float(dws[7].abs().max()) == 0.0, "a deferred reduction ran early"
+                assert float(dws[7].abs().max()) > 0.0, "the repeated output did not flush the queue"
+                assert float(dws[12].abs().max()) == 0.0 and float(dws[20].abs().max()) == 0.0, "a deferred reduction ran early"
         finally:
             hip.flush_reduces(end=True)
         assert hip.DEFER is None
