@@ -41,6 +41,21 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 #define DETR_GEMM64_MINW 1
 #endif
 
+// Ablation builds for timing experiments only (scripts/experiments/ablate.sh; results are WRONG with any bit set): bit 0 = no
+// MFMA issue, bit 1 = no global operand requests inside the K loop, bit 2 = no LDS operand stores inside the K loop, bit 3 = no
+// workgroup barrier inside the K loop, bit 4 = no LDS fragment reads.  The product library is built with 0.
+#ifndef DETR_ABLATE
+#define DETR_ABLATE 0
+#endif
+#if defined(__HIPCC__)
+template <typename T>
+__device__ __forceinline__ void ablate_keep(const T &v) {      // keeps a loaded register alive without using it
+    const unsigned *p = reinterpret_cast<const unsigned *>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) asm volatile("" ::"v"(p[i]));
+}
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire of ALL address
 // spaces, and on gfx9 loads and stores share vmcnt -- it therefore drains every outstanding global load, which would
 // serialise an operand prefetch that is meant to stay in flight across the barrier.

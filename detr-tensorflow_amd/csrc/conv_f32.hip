@@ -31,6 +31,10 @@ struct ConvArgs {
     int x16;                     // the source tensor (x for fwd, dy for dgrad) is bf16 in memory
 };
 
+}  // namespace detr
+#include "conv_halo.h"
+namespace detr {
+
 // tap (kh, kw) of K-tile group t (t-th tap of the launch)
 __device__ __forceinline__ void conv_tap(const ConvArgs &a, int t, int &kh, int &kw) {
     if (a.par_on) {
@@ -480,11 +484,16 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN
     load_ab(2, ra1, rb1);
     lds_barrier();
     auto iter = [&](const int kt, const int cur, typename LAc::Reg (&rpa)[LAc::NV], typename LB::Reg (&rpb)[NRB]) {
-        la.store(sm.A[cur ^ 1], rpa);
-        lb.store(sm.B[cur ^ 1], rpb);
-        load_ab(kt + 3, rpa, rpb);
+        if constexpr ((DETR_ABLATE & 4) == 0) {
+            la.store(sm.A[cur ^ 1], rpa);
+            lb.store(sm.B[cur ^ 1], rpb);
+        } else {
+            for (int i = 0; i < LAc::NV; ++i) ablate_keep(rpa[i]);
+            for (int i = 0; i < NRB; ++i) ablate_keep(rpb[i]);
+        }
+        if constexpr ((DETR_ABLATE & 2) == 0) load_ab(kt + 3, rpa, rpb);
         mma_ktile_bf16<BM, BN, WGM, WGN, false, !DGRAD>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
-        lds_barrier();
+        if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
     };
     {
         int kt = 0;
@@ -1182,6 +1191,17 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
                  "conv3x3: a bf16 kernel tensor needs compute = bf16, mode 0/1 and channel counts %% 32 == 0");
     a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
     const bool dgrad = mode == 1;
+    // stride-1 convs on bf16 tensors up to 256 channels: the halo-staged kernel (conv_halo.h; DETR_HIP_CONV_HALO=2 = off).
+    // The 512-channel convs (25 x 42 maps) stay on the tile kernel: they are bound by the kernel-tensor traffic, which a
+    // 256-pixel tile does not reduce there.
+    if (d->compute == 1 && d->stride == 1 && d->pad == 1 && a.w16 && a.x16 && e.c16 && a.Cs % 32 == 0 && a.Cd % 64 == 0 &&
+        a.Cd <= 256 && (!d->mask || e.m16) && !d->residual && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) &&
+        env_tile("DETR_HIP_CONV_HALO") != 2) {
+        if (a.Cd >= 128) { if (launch_conv_halo<128>(a, dgrad, s)) return -1; }
+        else if (launch_conv_halo<64>(a, dgrad, s)) return -1;
+        DETR_LAUNCH_CHECK("conv3x3 (halo)");
+        return 0;
+    }
     const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
     auto launch = [&](const ConvArgs &c) {
         const long long big = (long long)cdiv(c.M, 128) * cdiv(c.Cd, 128);

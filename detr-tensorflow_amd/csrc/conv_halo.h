@@ -1,0 +1,280 @@
+// conv_halo.h -- stride-1 3x3 convolution forward / input gradient on bf16 tensors with the input HALO STAGED ONCE
+// (included by conv_f32.hip; reference: detr_tf/networks/resnet_backbone.py:98-137, the conv2 of every BottleNeck).
+//
+// Why (ablation builds, scripts/experiments/ablate.sh, profiles/r02_ablation_tile_kernels.txt): in the implicit-GEMM
+// tile kernel the operand REQUESTS and their LDS stores cost 35-45 % of the kernel (C = 64: 108 us with them, 60 us
+// without) -- every one of the 9 taps re-fetches its [pixels][32 ch] operand through the vector memory path although
+// the taps of a tile read the same (tile + 1 pixel border) input patch, and a 64 / 128 pixel tile re-fetches the whole
+// 9 x Ci x Co kernel per 64 / 128 output pixels.  Here a workgroup owns 8 x 32 = 256 output pixels x BN output
+// channels: per 32-channel chunk the 10 x 34 pixel patch is staged in LDS once ([pixel][32 ch], 80-byte rows) and the
+// nine taps read their MFMA A fragments from it at a constant LDS offset ((dh * 34 + dw) * 80 bytes -- the fragment
+// rows of a 32-pixel tile row stay consecutive patch rows, so every ds_read_b128 is conflict free for any tap); only
+// the weights stream through LDS per (chunk, tap), two tiles deep like the GEMM engine.  Vector-memory traffic per
+// launch, C = 64 / 128 / 256 at B = 8, 800 x 1333: 1230 -> 270, 1230 -> 230, 620 -> 240 MB.
+// The dgrad form reads dy through the same patch with the taps flipped and the kernel transposed (K = Co).
+#pragma once
+#include "gemm_bf16_core.h"
+
+namespace detr {
+
+constexpr int CH_TH = 8, CH_TW = 32;                     // output pixels of a workgroup tile
+constexpr int CH_PW = CH_TW + 2, CH_PH = CH_TH + 2;      // input patch (1 pixel border)
+constexpr int CH_PIX = CH_PH * CH_PW;                    // 340 patch pixels
+constexpr int CH_GRAN = CH_PIX * 4;                      // 16-byte granules (8 channels) of a 32-channel chunk
+constexpr int CH_NG = (CH_GRAN + 255) / 256;             // granules per thread (the last round is partial)
+constexpr int CH_PATCH_BYTES = CH_PIX * BF_LD * 2;       // 27200
+
+template <int BN>
+struct ConvHaloSmem {
+    unsigned short P[2][CH_PIX][BF_LD];                  // input patch of chunk c in P[c & 1]
+    unsigned short B[2][BN][BF_LD];                      // kernel tile of step s in B[s & 1]
+};
+template <int BN>
+struct ConvHaloSmemBytes {
+    static constexpr int TILES = (int)sizeof(ConvHaloSmem<BN>);
+    static constexpr int STAGE = StageCfg<BN, 2>::BYTES;
+    static constexpr int VALUE = TILES > STAGE ? TILES : STAGE;
+};
+
+// Epilogue of the 256-pixel tile: y = mask(relu(acc + bias)) rounded to bf16.  One strip = one tile row (32 pixels) x the
+// wave's BN / 2 channels, transposed through a WAVE-PRIVATE LDS region (no workgroup barrier between strips); a lane owns
+// 8 consecutive channels of a pixel: one 16-byte mask load, one 16-byte store, all of a strip's mask loads requested
+// before its LDS round trip.  (The generic epilogue of gemm_core.h walks a strip in a rolled loop with the bias / mask
+// loads inside: with 4 strips per wave and only 8 waves per CU that was 16 dependent L2 round trips per workgroup --
+// 71 of the 103 us of the C = 64 launch, ablation build 31.)
+template <int BN>
+__device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[4][BN / 64], float *stage_base, unsigned short *dst,
+                                              const ConvArgs &a, int n, int h0, int w0, int n0, int wm, int wn, int lane,
+                                              int wave) {
+    constexpr int TN = BN / 64, WTN = BN / 2;
+    constexpr int LD = WTN + 4;                         // floats per staged row (16-byte aligned rows)
+    constexpr int L8 = WTN / 8;                         // lanes per pixel
+    constexpr int RPI = 64 / L8, ITERS = 32 / RPI;      // pixels per pass, passes per strip
+    float *stage = stage_base + wave * (32 * LD);
+    const int l31 = lane & 31, rh = (lane >> 5) * 4;
+    const int c8 = (lane % L8) * 8, rsub = lane / L8;
+    const int col = n0 + wn * WTN + c8;
+    const EpiArgs &e = a.e;
+    float bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bi[j] = 0.0f;
+    if (e.bias) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(e.bias + col), b1 = *reinterpret_cast<const float4 *>(e.bias + col + 4);
+        bi[0] = b0.x; bi[1] = b0.y; bi[2] = b0.z; bi[3] = b0.w; bi[4] = b1.x; bi[5] = b1.y; bi[6] = b1.z; bi[7] = b1.w;
+    }
+    const unsigned short *mask = reinterpret_cast<const unsigned short *>(e.mask);
+    const int wn_ok = a.Wd - w0;                        // valid pixels of a tile row
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int h = h0 + 4 * wm + mi;
+        const bool row_ok = h < a.Hd;
+        const long long prow0 = ((long long)n * a.Hd + h) * a.Wd + w0;
+        uint4 mk[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int tw = it * RPI + rsub;
+            mk[it] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            if (mask && row_ok && tw < wn_ok) mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + tw) * e.ldmask + col);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();                // the previous strip's reads are done
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rh) * LD + ni * 32 + l31] = acc[mi][ni][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int tw = it * RPI + rsub;
+            const float4 v0 = *reinterpret_cast<const float4 *>(stage + tw * LD + c8);
+            const float4 v1 = *reinterpret_cast<const float4 *>(stage + tw * LD + c8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const unsigned mw[4] = {mk[it].x, mk[it].y, mk[it].z, mk[it].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] += bi[j];
+                if (e.act == 1) v[j] = fmaxf(v[j], 0.0f);
+                const float m = bf16_bits_to_f32((j & 1) ? (mw[j >> 1] >> 16) : (mw[j >> 1] & 0xFFFFu));
+                v[j] = (m > 0.0f) ? v[j] : 0.0f;
+            }
+            if (row_ok && tw < wn_ok)
+                *reinterpret_cast<uint4 *>(dst + (prow0 + tw) * a.Cd + col) =
+                    make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7]));
+        }
+    }
+}
+
+// ConvArgs as for conv3x3_bf16c_kernel (stride 1, pad 1, bf16 src / w / dst); Hp / Wp carry the tile counts along H / W.
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
+    using T = TileCfg<CH_TH * CH_TW, BN, 2, 2>;          // wave tile: 4 pixel rows x BN / 2 channels
+    extern __shared__ __attribute__((aligned(16))) char halo_smem[];
+    ConvHaloSmem<BN> &sm = *reinterpret_cast<ConvHaloSmem<BN> *>(halo_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = id % a.tiles_n;
+    int t = id / a.tiles_n;
+    const int twi = t % a.Wp;
+    t /= a.Wp;
+    const int thi = t % a.Hp;
+    const int n = t / a.Hp;
+    const int h0 = thi * CH_TH, w0 = twi * CH_TW, n0 = tn * BN;
+    const int nchunks = a.Cs / BF_BK;
+    const long long tapstride = (long long)a.Ci * a.Co;
+
+    // ---- patch loader: granule g = tid + 256 * i -> patch pixel g >> 2, channels 8 * (g & 3) of the chunk
+    BufSrc src;
+    src.init_bytes(a.src, (long long)a.N * a.Hs * a.Ws * a.Cs * 2);
+    unsigned goff[CH_NG];
+#pragma unroll
+    for (int i = 0; i < CH_NG; ++i) {
+        const int g = tid + 256 * i;
+        const int px = g >> 2;
+        const int pr = px / CH_PW, pc = px - pr * CH_PW;
+        const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+        const bool ok = g < CH_GRAN && h >= 0 && h < a.Hs && w >= 0 && w < a.Ws;
+        goff[i] = ok ? ((unsigned)((n * a.Hs + h) * a.Ws + w) * (unsigned)a.Cs + (unsigned)(g & 3) * 8u) * 2u : BUF_OOB;
+    }
+    auto patch_load = [&](int c, uint4 (&r)[CH_NG]) {      // chunk c >= nchunks: every lane out of range, no traffic
+        const bool live = c < nchunks;
+#pragma unroll
+        for (int i = 0; i < CH_NG; ++i) r[i] = src.ld16((live && goff[i] != BUF_OOB) ? goff[i] + (unsigned)c * (BF_BK * 2u) : BUF_OOB);
+    };
+    auto patch_store = [&](int buf, const uint4 (&r)[CH_NG]) {
+        unsigned short *flat = &sm.P[buf][0][0];
+#pragma unroll
+        for (int i = 0; i < CH_NG; ++i) {
+            const int g = tid + 256 * i;
+            if (i + 1 < CH_NG || g < CH_GRAN)
+                *reinterpret_cast<uint4 *>(flat + (g >> 2) * BF_LD + (g & 3) * 8) = r[i];
+        }
+    };
+    // ---- kernel loader: fwd [k = ci][n = co] (transpose-read image), dgrad [n = ci][k = co]
+    using LB = typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN>>::type;
+    constexpr int NRB = LB::NREG;
+    LB lb;
+    lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);
+    auto b_load = [&](int c, int tp, typename LB::Reg (&rb)[NRB]) {      // step (chunk c, patch offset tp = 3 * dh + dw)
+        const bool live = c < nchunks;
+        const int wt = DGRAD ? 8 - tp : tp;                                // dgrad: the kernel tap is the flipped offset
+        lb.load(c * BF_BK, live ? a.Cs : 0, rb, live ? (unsigned)(wt * tapstride * 2) : 0u);
+    };
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int l31 = lane & 31, kh8 = (lane >> 5) * 8;
+    // A fragment of tile row (4 * wm + mi), patch offset (dh, dw), k-step ks: patch row ((4 * wm + mi + dh) * 34 + l31 + dw)
+    const unsigned short *pa_base = &sm.P[0][0][0] + ((4 * wm) * CH_PW + l31) * BF_LD + kh8;
+    auto mma_tap = [&](int pbuf, int bbuf, int tp) {
+        const int dh = tp / 3, dw = tp - 3 * (tp / 3);
+        const unsigned short *pa = pa_base + pbuf * (CH_PIX * BF_LD) + (dh * CH_PW + dw) * BF_LD;
+        const unsigned short(*Bs)[BF_LD] = sm.B[bbuf];
+#pragma unroll
+        for (int ks = 0; ks < BF_BK; ks += 16) {
+            bf16x8 fa[T::TM], fb[T::TN];
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi) {
+                if constexpr ((DETR_ABLATE & 16) != 0) fa[mi] = __builtin_bit_cast(bf16x8, make_uint4(lane, mi, ks, 0x3f803f80u));
+                else fa[mi] = *reinterpret_cast<const bf16x8 *>(pa + mi * (CH_PW * BF_LD) + ks);
+            }
+#pragma unroll
+            for (int ni = 0; ni < T::TN; ++ni) {
+                if constexpr ((DETR_ABLATE & 16) != 0) fb[ni] = __builtin_bit_cast(bf16x8, make_uint4(lane, ni, ks, 0x3f803f80u));
+                else if (!DGRAD) fb[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
+                else fb[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh8]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::TN; ++ni) {
+                    if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(fa[mi]); ablate_keep(fb[ni]); }
+                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- pipeline.  Step s = 9 * c + tp multiplies patch P[c & 1] at offset tp with kernel tile B[s & 1].  The kernel tile
+    // of step s + 1 waits in one register set (stored at the top of step s), the tile of step s + 2 is in flight into the
+    // other; the patch of chunk c + 1 is requested at tp = 4 of chunk c - 1 and stored at tp = 2 of chunk c (its buffer was
+    // last read in chunk c - 1).  Every request and LDS store is unconditional (past the end: out-of-range offsets, a buffer
+    // nobody reads) and the nine taps are unrolled, so that the compiler's vmcnt waits are exact -- see gemm_bf16c_body.
+    uint4 rp[CH_NG];
+    typename LB::Reg rb0[NRB], rb1[NRB];
+    patch_load(0, rp);
+    b_load(0, 0, rb0);
+    patch_store(0, rp);
+    lb.store(sm.B[0], rb0);
+    patch_load(1, rp);
+    b_load(0, 1, rb0);
+    b_load(0, 2, rb1);
+    lds_barrier();
+    // one chunk; PAR = parity of its first step (9 taps per chunk: chunks alternate)
+    auto chunk = [&](const int c, auto par) {
+        constexpr int PAR = decltype(par)::value;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int cur = (PAR + tp) & 1;
+            // kernel tile of the next step: register set `cur ^ PAR ...` -- step parity decides the set, statically
+            if (((PAR + tp) & 1) == 0) {
+                if constexpr ((DETR_ABLATE & 4) == 0) lb.store(sm.B[cur ^ 1], rb0);
+                else for (int i = 0; i < NRB; ++i) ablate_keep(rb0[i]);
+                if constexpr ((DETR_ABLATE & 2) == 0) b_load(c + (tp + 3) / 9, (tp + 3) % 9, rb0);
+            } else {
+                if constexpr ((DETR_ABLATE & 4) == 0) lb.store(sm.B[cur ^ 1], rb1);
+                else for (int i = 0; i < NRB; ++i) ablate_keep(rb1[i]);
+                if constexpr ((DETR_ABLATE & 2) == 0) b_load(c + (tp + 3) / 9, (tp + 3) % 9, rb1);
+            }
+            if (tp == 2) {
+                if constexpr ((DETR_ABLATE & 4) == 0) patch_store((c + 1) & 1, rp);
+                else for (int i = 0; i < CH_NG; ++i) ablate_keep(rp[i]);
+            }
+            if (tp == 4) {
+                if constexpr ((DETR_ABLATE & 2) == 0) patch_load(c + 2, rp);
+            }
+            mma_tap(c & 1, cur, tp);
+            if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
+        }
+    };
+    {
+        int c = 0;
+        for (; c + 2 <= nchunks; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+    halo_epilogue<BN>(acc, reinterpret_cast<float *>(halo_smem), reinterpret_cast<unsigned short *>(a.dst), a, n, h0, w0, n0, wm, wn, lane, wave);
+}
+
+template <int BN>
+static int launch_conv_halo(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+    ConvArgs a = a0;
+    a.Hp = cdiv(a.Hd, CH_TH);
+    a.Wp = cdiv(a.Wd, CH_TW);
+    a.tiles_m = a.N * a.Hp * a.Wp;
+    a.tiles_n = cdiv(a.Cd, BN);
+    constexpr int smem = ConvHaloSmemBytes<BN>::VALUE;
+    static bool reserved[2] = {false, false};
+    const void *fn = dgrad ? reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, true>)
+                           : reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, false>);
+    if (!reserved[dgrad ? 1 : 0]) {
+        hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        DETR_REQUIRE(err == hipSuccess, "conv3x3 (halo): cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(err));
+        reserved[dgrad ? 1 : 0] = true;
+    }
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, true>), grid, block, smem, s, a);
+    else hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, false>), grid, block, smem, s, a);
+    return 0;
+}
+
+}  // namespace detr

@@ -231,19 +231,23 @@ __device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BF_LD]
         bf16x8 a[T::TM], b[T::TN];
 #pragma unroll
         for (int mi = 0; mi < T::TM; ++mi) {
-            if (ATR) a[mi] = frag_tr<BM>(As, wm * T::WTM + mi * 32, ks, lane);
+            if constexpr ((DETR_ABLATE & 16) != 0) a[mi] = __builtin_bit_cast(bf16x8, make_uint4(lane, mi, ks, 0x3f803f80u));
+            else if (ATR) a[mi] = frag_tr<BM>(As, wm * T::WTM + mi * 32, ks, lane);
             else a[mi] = *reinterpret_cast<const bf16x8 *>(&As[wm * T::WTM + mi * 32 + l31][ks + kh]);
         }
 #pragma unroll
         for (int ni = 0; ni < T::TN; ++ni) {
-            if (BTR) b[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
+            if constexpr ((DETR_ABLATE & 16) != 0) b[ni] = __builtin_bit_cast(bf16x8, make_uint4(lane, ni, ks, 0x3f803f80u));
+            else if (BTR) b[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
             else b[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh]);
         }
 #pragma unroll
         for (int mi = 0; mi < T::TM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < T::TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < T::TN; ++ni) {
+                if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(a[mi]); ablate_keep(b[ni]); }
+                else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
     }
 }
 

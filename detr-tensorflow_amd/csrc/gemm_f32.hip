@@ -270,12 +270,19 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     // one iteration: `rp` holds tile kt+1 (stored now, then refilled with tile kt+3), LDS[cur] holds tile kt
     auto iter = [&](const int kt, const int cur, typename LA::Reg (&rpa)[NRA], typename LB::Reg (&rpb)[NRB]) {
         if (do_rs && kt + 1 < kt1) rs_add(rpa);
-        la.store(sm.A[cur ^ 1], rpa);              // (unconditional as well: after the last tile it writes a buffer nobody reads)
-        lb.store(sm.B[cur ^ 1], rpb);
-        la.load((kt + 3) * BF_BK, kend, rpa);
-        lb.load((kt + 3) * BF_BK, kend, rpb);
+        if constexpr ((DETR_ABLATE & 4) == 0) {
+            la.store(sm.A[cur ^ 1], rpa);          // (unconditional as well: after the last tile it writes a buffer nobody reads)
+            lb.store(sm.B[cur ^ 1], rpb);
+        } else {
+            for (int i = 0; i < NRA; ++i) ablate_keep(rpa[i]);
+            for (int i = 0; i < NRB; ++i) ablate_keep(rpb[i]);
+        }
+        if constexpr ((DETR_ABLATE & 2) == 0) {
+            la.load((kt + 3) * BF_BK, kend, rpa);
+            lb.load((kt + 3) * BF_BK, kend, rpb);
+        }
         mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
-        lds_barrier();
+        if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
     };
     {   // whole pairs in the loop, an odd last tile after it: every path into the loop header carries the same
         // sequence of outstanding requests, so the compiler's vmcnt waits are exact (vmcnt(2) / vmcnt(3) before the stores)

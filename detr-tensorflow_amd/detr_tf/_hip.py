@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, byref, c_float, c_int32, c_int64, c_size_
 import torch  # imported first so that libamdhip64 (same SONAME) is the one torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdetr_hip.so")
+LIB_PATH = os.environ.get("DETR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdetr_hip.so")   # DETR_HIP_LIB: A/B builds (scripts/experiments)
 
 f32p = c_void_p
 
@@ -266,16 +266,16 @@ def flush_reduces(end=False):
 
 def _defer_push(rds):
     """Queue the reductions a launch described.  Two reductions into the same output would race inside one grouped launch
-    (read-modify-write of C): the earlier ones are flushed first.  A full slab pool flushes too."""
+    (read-modify-write of C): then the queue is flushed first and the new ones run right away, one launch each (their slabs
+    must not outlive the flush, which recycles the slab pool).  A full slab pool flushes too."""
     rds = [r for r in rds if r is not None and r.splits > 0]
     outs = [r.C for r in rds] + [r.rs_out for r in rds if r.rs_out]
     if len(set(outs)) != len(outs) or any(o in _defer_outs for o in outs):
         flush_reduces()
-        if len(set(outs)) != len(outs):          # duplicates inside one group: one launch each
-            for r in rds:
-                DEFER.append(r)
-                flush_reduces()
-            return
+        for r in rds:
+            arr = (ReduceDesc * 1)(r)
+            _check(load().detr_hip_splitk_reduce_many(arr, 1, _stream()), "detr_hip_splitk_reduce_many")
+        return
     DEFER.extend(rds)
     _defer_outs.update(outs)
     if _defer_top >= DEFER_LIMIT:

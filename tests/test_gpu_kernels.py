@@ -971,11 +971,14 @@ def test_gemm_bf16_activation_storage(hip, M, N, K, bk):
 
 
 @pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 25, 42, 256, 256, 1)])
-def test_conv3x3_bf16_activation_storage(hip, N, H, W, Ci, Co, stride):
+def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stride):
     """conv3x3 forward / dgrad / wgrad and the stem max pooling on bf16-STORED tensors: bit-identical to bf16(result of the
     fp32-storage kernels) on the same (bf16-representable) values; weight gradients (fp32) identical."""
     torch.manual_seed(N + H + W + Ci + stride + 9)
     hip.ensure_workspace(DEV)
+    # (the stride-1 all-bf16 calls would take the halo-staged kernel, which sums the taps in another order: it has its own
+    #  test below; this one pins the storage-type identity of the tile kernel)
+    monkeypatch.setenv("DETR_HIP_CONV_HALO", "2")
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     b16 = lambda t: t.to(torch.bfloat16)
     x, dy = g(_bf(torch.randn(N, H, W, Ci)).float()), g(_bf(torch.randn(N, Ho, Wo, Co)).float())
@@ -1009,6 +1012,43 @@ def test_conv3x3_bf16_activation_storage(hip, N, H, W, Ci, Co, stride):
         xb, gb = b16(x), b16(gp)
         hip.call("detr_hip_maxpool3x3s2_bwd_bf16", gb.data_ptr(), a16.data_ptr(), xb.data_ptr(), d16.data_ptr(), N, H, W, C, H2, W2)
         assert torch.equal(d16, b16(d32))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 19, 45, 64), (1, 8, 32, 128), (2, 25, 70, 256), (1, 40, 33, 64), (3, 9, 31, 128)])
+def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C):
+    """The halo-staged stride-1 kernel (csrc/conv_halo.h: bf16 x / w / y, 8 x 32 pixel tiles, one staged input patch per
+    32-channel chunk) -- forward (+ BN shift, ReLU) and input gradient (+ ReLU mask) against fp64 on the same bf16 operands
+    (one bf16 rounding) and against the tile kernel on the same call (DETR_HIP_CONV_HALO=2): the two sum the (tap, chunk)
+    products in different orders, i.e. may differ by one bf16 ulp on a small fraction of the outputs.  The shapes cover
+    ragged tile rows / columns, several tiles per image and several images."""
+    torch.manual_seed(N + H + W + C)
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    x, dy = _bf(torch.randn(N, H, W, C)), _bf(torch.randn(N, H, W, C))
+    w = _bf(torch.randn(3, 3, C, C) / (3 * C ** 0.5))
+    shift, msk = torch.randn(C).double(), _bf(torch.randn(N, H, W, C))
+    w_oihw = w.permute(3, 2, 0, 1).contiguous()
+    ref_y = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w_oihw, padding=1).permute(0, 2, 3, 1) + shift)
+    ref_dx = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2), w_oihw, padding=1).permute(0, 2, 3, 1)
+    ref_dx = torch.where(msk > 0, ref_dx, torch.zeros_like(ref_dx))
+    xd, dyd, wd, md, sd = b16(x), b16(dy), b16(w), b16(msk), g(shift.float())
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("DETR_HIP_CONV_HALO", mode)
+        y = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
+        dx = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.conv3x3(0, xd, wd, y, N, H, W, C, H, W, C, 1, bias=sd, act=1, compute=1)
+        hip.conv3x3(1, dyd, wd, dx, N, H, W, C, H, W, C, 1, mask=md, compute=1)
+        torch.cuda.synchronize()
+        outs[mode] = (y.float().cpu().double(), dx.float().cpu().double())
+    monkeypatch.delenv("DETR_HIP_CONV_HALO")
+    for what, halo, tile, ref in (("forward", outs["0"][0], outs["2"][0], ref_y), ("dgrad", outs["0"][1], outs["2"][1], ref_dx)):
+        scale = float(ref.abs().max())
+        assert scale > 0
+        err = (halo - ref).abs()
+        assert float((err / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.1, f"halo conv {what}: more than one bf16 rounding from fp64"
+        diff = (halo - tile).abs()
+        assert float((diff > 0).double().mean()) < 5e-3, (what, float((diff > 0).double().mean()))
+        assert float((diff / (tile.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7, what
 
 
 @pytest.mark.parametrize("compute", [0, 1])
