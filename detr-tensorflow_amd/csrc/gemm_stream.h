@@ -42,9 +42,14 @@ struct StreamArgs {
 
 constexpr int STREAM_LD = 68;                      // floats per staged row (64 + 4): conflict-free b128 writes and reads
 
-template <int K>
+// SL = column slices (64 columns each) a workgroup owns: its 4 waves are SL slice owners x 4 / SL row walkers, and the SL
+// owners of one walker work on the SAME 32 rows at the same time, so the A rows of a strip leave L2 once per workgroup
+// instead of once per slice.  (Measured: the kernel's time is proportional to the number of slice-strips -- M534400 K64:
+// 33 us for N = 64 at 6.2 TB/s, 131 us for N = 256 -- i.e. the A rows re-read from L2 by the other slices cost as much as
+// HBM bytes; scripts/experiments/stream_stride_probe.py.)
+template <int K, int SL>
 struct StreamSmem {
-    unsigned short B[64][K + 8];                   // [n][k], +8 bf16 of padding: 16-byte fragment reads spread over the banks
+    unsigned short B[SL][64][K + 8];               // [slice][n][k], +8 bf16 of padding: 16-byte fragment reads spread over the banks
     float stage[4][32][STREAM_LD];                 // one 32 x 64 fp32 strip per wave
 };
 
@@ -56,27 +61,29 @@ __device__ __forceinline__ void stream_unpack8(uint4 r, float (&o)[8]) {
 }
 
 // workgroups per CU that fit the 160 KB of LDS (at most 3: 12 waves / CU already keep > 100 KB of requests in flight)
-template <int K>
+template <int K, int SL>
 struct StreamOcc {
-    static constexpr int BYTES = (int)sizeof(StreamSmem<K>);
+    static constexpr int BYTES = (int)sizeof(StreamSmem<K, SL>);
     static constexpr int VALUE = (3 * BYTES <= 160 * 1024) ? 3 : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
 };
 
-template <int K, bool BKC, bool RES, bool MASK>
-__global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_kernel(StreamArgs a) {
+template <int K, bool BKC, bool RES, bool MASK, int SL = 1>
+__global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
+    constexpr int WPS = 4 / SL;                    // row walkers (waves per slice) of a workgroup
     constexpr int KC = (K > 128) ? 128 : K;       // A rows are held in registers one K chunk (<= 128) at a time
     constexpr int NC = K / KC;                     // chunks per strip: 1, or an even number
     constexpr int KK = KC / 16;                    // MFMA k-steps per chunk
     static_assert(K % KC == 0 && (NC == 1 || NC % 2 == 0), "gemm_stream: K must be 64, 128 or a multiple of 256");
-    __shared__ __attribute__((aligned(16))) StreamSmem<K> sm;
+    __shared__ __attribute__((aligned(16))) StreamSmem<K, SL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup id -> (XCD, column slice, walker): ids are dealt round-robin over the 8 XCDs, so the n_tiles slices of
     // one walker p are consecutive multiples of 8 apart -- same XCD, dispatched together, same A rows
     const int id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
-    const int nt = j % a.n_tiles, p = (j / a.n_tiles) * 8 + xcd;
-    const int n0 = nt * 64;
-    const int stride = a.q * 8 * 4;                // wave slots per column slice
+    const int nt = j % a.n_tiles, p = (j / a.n_tiles) * 8 + xcd;      // n_tiles = slice GROUPS of SL slices
+    const int ws = wave % SL, wr = wave / SL;      // this wave's slice inside the group, its row walker
+    const int n0 = (nt * SL + ws) * 64;
+    const int stride = a.q * 8 * WPS;              // wave slots per column slice
 
     // ---- per-lane constants ----------------------------------------------------------------------------------------------
     const int l31 = lane & 31, h = lane >> 5;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_ker
             const bf16x8 af = __builtin_bit_cast(bf16x8, f[kk]);
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[ws][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
                 acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
             }
         }
@@ -184,26 +191,27 @@ __global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_ker
         __builtin_amdgcn_wave_barrier();
     };
 
-    int rt = p * 4 + wave;
+    int rt = p * WPS + wr;
     uint4 a0[KK], a1[KK];
     load_a(rt, 0, a0);                             // first A rows: in flight while the B slice is staged
 
     // ---- prologue: B slice -> LDS as [n][k] (the only workgroup barrier of the kernel) ---------------------------
+    const int g0 = nt * SL * 64;                   // first column of the group
     if (BKC) {
-        for (int c = tid; c < 64 * (K / 8); c += 256) {
+        for (int c = tid; c < SL * 64 * (K / 8); c += 256) {
             const int n = c / (K / 8), kc = c - n * (K / 8);
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(n0 + n) * a.ldb + kc * 8);
-            *reinterpret_cast<uint4 *>(&sm.B[n][kc * 8]) = v;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(g0 + n) * a.ldb + kc * 8);
+            *reinterpret_cast<uint4 *>(&sm.B[n >> 6][n & 63][kc * 8]) = v;
         }
     } else {
-        for (int c = tid; c < K * 8; c += 256) {
-            const int k = c >> 3, nc = c & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + n0 + nc * 8);
+        for (int c = tid; c < K * 8 * SL; c += 256) {
+            const int k = c / (8 * SL), nc = c - k * (8 * SL);
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + g0 + nc * 8);
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sm.B[nc * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
-                sm.B[nc * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
+                sm.B[nc >> 3][(nc & 7) * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
+                sm.B[nc >> 3][(nc & 7) * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
             }
         }
     }
@@ -220,20 +228,20 @@ __global__ __launch_bounds__(256, StreamOcc<K>::VALUE) void gemm_stream_bf16_ker
     }
 }
 
-// Host side: eligibility is decided by the caller (gemm_f32.hip); here only the grid.
-template <int K>
-static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
-    a.n_tiles = a.N / 64;
+// Host side: eligibility is decided by the caller (gemm_f32.hip); here the slice grouping and the grid.
+template <int K, int SL>
+static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s) {
+    a.n_tiles = a.N / (64 * SL);
     a.row_tiles = (a.M + 31) / 32;
-    const int wgs_per_cu = StreamOcc<K>::VALUE;
+    const int wgs_per_cu = StreamOcc<K, SL>::VALUE;
     int q = (256 * wgs_per_cu) / (8 * a.n_tiles);
-    const int qmax = a.row_tiles / (8 * 4 * 2);                 // at least two strips per wave
+    const int qmax = a.row_tiles / (8 * (4 / SL) * 2);          // at least two strips per wave
     if (q > qmax) q = qmax;
     if (q < 1) q = 1;
     a.q = q;
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
-#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_>), grid, dim3(256), 0, s, a)
+#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL>), grid, dim3(256), 0, s, a)
     if (bkc) {
         if (r && m) DETR_STREAM_LAUNCH(true, true, true);
         else if (r) DETR_STREAM_LAUNCH(true, true, false);
@@ -246,6 +254,23 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
         else DETR_STREAM_LAUNCH(false, false, false);
     }
 #undef DETR_STREAM_LAUNCH
+}
+
+template <int K>
+static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
+    // slices per workgroup, by measurement (scripts/experiments/ablate_stream.py with DETR_HIP_STREAM_SL = 1 / 2 / 4, the tuning
+    // hook below; SL 1 -> chosen): M534400 N256 K64 130 -> 123 us (+mask 180 -> 171), M133600 N512 K128 +res 95 -> 87 (SL 2),
+    // +res +mask 116 -> 95 (SL 4), M133600 N512 K256 144 -> 126 (SL 2); M33600 N1024 K256 stays at SL 1 (52 vs 57 us)
+    int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : (a.N <= 512 ? 2 : 1));
+    const int force = env_tile("DETR_HIP_STREAM_SL");
+    if (force == 1 || force == 2 || force == 4) sl = force;
+    while (sl > 1 && (a.N % (64 * sl) != 0 || (int)sizeof(StreamSmem<K, 1>) + (sl - 1) * 64 * (K + 8) * 2 > 160 * 1024)) sl >>= 1;
+    if (sl == 4) {
+        if constexpr (K <= 128) { launch_gemm_stream_sl<K, 4>(a, bkc, s); return; }
+        sl = 2;
+    }
+    if (sl == 2) launch_gemm_stream_sl<K, 2>(a, bkc, s);
+    else launch_gemm_stream_sl<K, 1>(a, bkc, s);
 }
 
 }  // namespace detr
