@@ -43,7 +43,8 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 
 // Ablation builds for timing experiments only (scripts/experiments/ablate.sh; results are WRONG with any bit set): bit 0 = no
 // MFMA issue, bit 1 = no global operand requests inside the K loop, bit 2 = no LDS operand stores inside the K loop, bit 3 = no
-// workgroup barrier inside the K loop, bit 4 = no LDS fragment reads.  The product library is built with 0.
+// workgroup barrier inside the K loop, bit 4 = no LDS fragment reads; gemm_stream.h: bit 5 = no residual / mask requests,
+// bit 6 = no output stores.  The product library is built with 0.
 #ifndef DETR_ABLATE
 #define DETR_ABLATE 0
 #endif

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 
     auto load_a = [&](int rt, int chunk, uint4 (&f)[KK]) {
         const int row = rt * 32 + l31;
-        const unsigned base = (rt < a.row_tiles && row < a.M) ? (unsigned)((long long)row * a.lda * 2) + a_lane + chunk * (KC * 2) : BUF_OOB;
+        const bool a_live = (DETR_ABLATE & 2) == 0 || rt < stride;      // ablation bit 1: only a wave's first strip is requested
+        const unsigned base = (a_live && rt < a.row_tiles && row < a.M) ? (unsigned)((long long)row * a.lda * 2) + a_lane + chunk * (KC * 2) : BUF_OOB;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
     };
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
                 const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[ws][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
-                acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
+                if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(bfr); ablate_keep(af); }
+                else acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
             }
         }
     };
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
         for (int it = 0; it < 4; ++it) {
             const int row = r0 + it * 8 + erow;
             const unsigned colb = (unsigned)((n0 + ecg * 8) * 2);
-            if (RES) rres[it] = srcR.ld16(row < a.M ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
-            if (MASK) rmsk[it] = srcM.ld16(row < a.M ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            const bool ep_live = (DETR_ABLATE & 32) == 0;               // ablation bit 5: no residual / mask requests
+            if (RES) rres[it] = srcR.ld16((ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
+            if (MASK) rmsk[it] = srcM.ld16((ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
             }
-            if (row < a.M)
+            if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f))      // ablation bit 6: no output stores
                 *reinterpret_cast<uint4 *>(a.C + (long long)row * a.ldc + n0 + ecg * 8) =
                     make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]),
                                f32_to_bf16_pair(v[6], v[7]));
