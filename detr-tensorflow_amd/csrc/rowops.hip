@@ -449,6 +449,11 @@ extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream
                        d->dx, d->dgamma, d->dbeta, rows, C, partial, d->dx_add, d->dx_drop, drop_scale, drop_thresh16(d->dropout_p),
                        d->dropout_site, d->dropout_step, d->dx_drop16);
     DETR_LAUNCH_CHECK("layernorm bwd");
+    if (d->defer_blocks_out) {
+        DETR_REQUIRE(partial != nullptr, "layernorm bwd: defer_blocks_out needs a workspace of %d * 2 * C floats", grid);
+        *d->defer_blocks_out = grid;
+        return 0;
+    }
     if (partial) {
         hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, grid,
                            C, d->dgamma, d->dbeta);

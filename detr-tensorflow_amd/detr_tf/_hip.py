@@ -60,7 +60,7 @@ class LayerNormDesc(Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dx_add", c_void_p),
                 ("dx_drop", c_void_p), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p),
-                ("dx_drop16", c_void_p)]
+                ("dx_drop16", c_void_p), ("defer_blocks_out", POINTER(c_int32))]
 
 
 class StemDesc(Structure):
@@ -591,18 +591,36 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None, y16=
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, dx_drop=None, dropout_p=0.0, dropout_site=0,
-                  dropout_step=None, dx_drop16=None):
+                  dropout_step=None, dx_drop16=None, defer=True):
+    """defer=False: finish the gamma / beta reduction at once even while reductions are being queued (a LayerNorm whose
+    parameters receive several backward passes per step -- two queued reductions into one output would force a flush)."""
     d = LayerNormDesc()
     d.rows, d.C = x.shape[0], x.shape[1]
     d.dy, d.x, d.gamma, d.mean, d.rstd = dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     d.dx, d.dgamma, d.dbeta = dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
     if WORKSPACE is not None:                                       # deterministic gamma / beta reduction
         d.workspace, d.workspace_bytes = WORKSPACE.data_ptr(), WORKSPACE.numel() * 4
+    blocks = None
+    if DEFER is not None and defer:  # queue the gamma / beta finish with the split-K reductions (the optimiser is their only reader)
+        slab = _defer_slab(512 * 2 * d.C * 4)
+        if slab is not None:
+            blocks = c_int32(0)
+            d.workspace, d.workspace_bytes = slab
+            d.defer_blocks_out = ctypes.pointer(blocks)
     d.dx_add = ptr(dx_add)
     if dx_drop is not None or dx_drop16 is not None:
         d.dx_drop, d.dx_drop16 = ptr(dx_drop), ptr(dx_drop16)
         d.dropout_p, d.dropout_site, d.dropout_step = dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
     _check(load().detr_hip_layernorm_bwd(byref(d), _stream()), "detr_hip_layernorm_bwd")
+    if blocks is not None:
+        C = d.C
+        rds = []
+        for off, out in ((0, dgamma), (C, dbeta)):
+            r = ReduceDesc()
+            r.ws, r.splits, r.part_stride, r.rows, r.cols = d.workspace + 4 * off, blocks.value, 2 * C, 1, C
+            r.C, r.ldc, r.alpha = out.data_ptr(), C, 1.0
+            rds.append(r)
+        _defer_push(rds)
 
 
 def copy_table(entries, device):

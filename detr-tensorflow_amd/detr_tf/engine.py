@@ -262,7 +262,8 @@ class DetrEngine:
                 dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}", dx.shape)
         hip.layernorm_bwd(dy, x, self.P.views[f"{pfx}/gamma"], self._bufs[f"{tag}:mean"], self._bufs[f"{tag}:rstd"], dx,
                           self.P.gviews[f"{pfx}/gamma"], self.P.gviews[f"{pfx}/beta"], dx_add=dx_add, dx_drop=dx_drop,
-                          dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev, dx_drop16=dx_drop16)
+                          dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev, dx_drop16=dx_drop16,
+                          defer=(pfx != "transformer/decoder/norm"))       # the shared decoder norm: one backward per level
         if dx_drop16 is not None:
             return dx_drop16
         return dx if dx_drop is None else dx_drop

@@ -240,6 +240,10 @@ typedef struct {
      * mask of the forward GEMM epilogue regenerated on the gradient (element index row*C + col) */
     float *dx_drop; float dropout_p; uint32_t dropout_site; const uint32_t *dropout_step;
     uint16_t *dx_drop16;            /* optional bf16 twin of dx_drop (dropout_p = 0: of dx) */
+    /* optional (HOST pointer; needs the workspace path): do not launch the dgamma / dbeta finish but report the number of
+     * partial blocks -- the caller owns `workspace` ([blocks][2*C]: gamma partials, then beta partials, per block) and
+     * reduces it later through detr_hip_splitk_reduce_many (two entries: rows 1, cols C, splits = blocks, part_stride 2*C) */
+    int32_t *defer_blocks_out;
 } detr_layernorm_desc;
 int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream);
 int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);

@@ -466,6 +466,18 @@ def test_layernorm_fwd_bwd(hip, rows, C):
     close(res[0][0], gam.grad, rtol=5e-5, what="layernorm dgamma (workspace)")
     close(res[0][1], bet.grad, rtol=5e-5, what="layernorm dbeta (workspace)")
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # queued finish (detr_layernorm_desc.defer_blocks_out + detr_hip_splitk_reduce_many): same partials, same summation order
+    hip.begin_deferred_reduces(DEV)
+    try:
+        dg3, db3 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        hip.layernorm_bwd(dyd, xd, gd, mean, rstd, dxd, dg3, db3)
+        assert len(hip.DEFER) == 2 and float(dg3.abs().max()) == 0.0, "the gamma / beta finish ran early"
+    finally:
+        hip.flush_reduces(end=True)
+    if rows >= 64:       # >= 8 partial blocks: the grouped reduction sums them in the finish kernel's order
+        assert torch.equal(dg3, res[0][0]) and torch.equal(db3, res[0][1])
+    close(dg3, gam.grad, rtol=5e-5, what="layernorm dgamma (queued finish)")
+    close(db3, bet.grad, rtol=5e-5, what="layernorm dbeta (queued finish)")
 
 
 @pytest.mark.parametrize("rows,cols,ld", [(640, 1050, 1052), (64, 100, 100), (10, 7, 8), (33, 1344, 1344)])
