@@ -264,7 +264,9 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
     // slices per workgroup, by measurement (scripts/experiments/ablate_stream.py with DETR_HIP_STREAM_SL = 1 / 2 / 4, the tuning
     // hook below; SL 1 -> chosen): M534400 N256 K64 130 -> 123 us (+mask 180 -> 171), M133600 N512 K128 +res 95 -> 87 (SL 2),
     // +res +mask 116 -> 95 (SL 4), M133600 N512 K256 144 -> 126 (SL 2); M33600 N1024 K256 stays at SL 1 (52 vs 57 us)
-    int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : (a.N <= 512 ? 2 : 1));
+    // (in the step, HIP events: K = 256 without a residual / mask epilogue is SLOWER with 2 slices -- 102 KB of LDS, one workgroup per
+    //  CU: M133600 N512 0.091 -> 0.120 ms -- so K = 256 groups only the epilogue-heavy form)
+    int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : ((a.res && a.mask && a.N <= 512) ? 2 : 1));
     const int force = env_tile("DETR_HIP_STREAM_SL");
     if (force == 1 || force == 2 || force == 4) sl = force;
     while (sl > 1 && (a.N % (64 * sl) != 0 || (int)sizeof(StreamSmem<K, 1>) + (sl - 1) * 64 * (K + 8) * 2 > 160 * 1024)) sl >>= 1;
