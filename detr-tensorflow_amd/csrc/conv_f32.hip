@@ -742,27 +742,37 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
     lds_barrier();
     // one unit: the set `rp` holds unit u+1 (stored now, then refilled with unit u+3); LDS buffer cur holds unit u
     auto iter = [&](const int u, const int cur, Reg (&rpx)[7], Reg (&rpd)[2]) {
-        store_unit(cur ^ 1, rpx, rpd);
-        load_unit(u + 3, rpx, rpd);
+        if constexpr ((DETR_ABLATE & 4) == 0) store_unit(cur ^ 1, rpx, rpd);
+        else { for (int i = 0; i < 7; ++i) ablate_keep(rpx[i]); for (int i = 0; i < 2; ++i) ablate_keep(rpd[i]); }
+        if constexpr ((DETR_ABLATE & 2) == 0) load_unit(u + 3, rpx, rpd);
         const unsigned short *X = sm.X[cur];
         const unsigned short *D = sm.D[cur];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             // B fragment: dy[pixels 16 s2 + 8 hi ..][co = wn*32 + (lane & 31)]  (image of LoaderMNt<64>)
-            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2]));
-            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2] + 4 * 64));
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 bfrag;
+            if constexpr ((DETR_ABLATE & 16) != 0) bfrag = __builtin_bit_cast(bf16x8, make_uint4(lane, s2, 1, 0x3f803f80u));
+            else {
+                const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2]));
+                const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(D + dofs[s2] + 4 * 64));
+                bfrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][0] + kh * WF_ROW));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][1] + kh * WF_ROW));
-                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                    bf16x8 afrag;
+                    if constexpr ((DETR_ABLATE & 16) != 0) afrag = __builtin_bit_cast(bf16x8, make_uint4(lane, kh, kw, 0x3f803f80u));
+                    else {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][0] + kh * WF_ROW));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(X + xo[s2][kw][1] + kh * WF_ROW));
+                        afrag = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(afrag); ablate_keep(bfrag); }
+                    else acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
                 }
         }
-        lds_barrier();
+        if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
     };
     {
         int u = u_begin;

@@ -38,6 +38,10 @@ for (N, H, W, C) in [(8, 200, 334, 64), (8, 100, 167, 128), (8, 50, 84, 256), (8
         us = timeit(lambda: hip.conv3x3(mode, x, w, y, N, H, W, C, H, W, C, 1, bias=bias if mode == 0 else None, act=1 if mode == 0 else 0,
                                         mask=None, compute=1))
         out.append((f"conv3x3_{nm}_{H}x{W}x{C}", us, 2.0 * N * H * W * 9 * C * C))
+for (N, H, W, C) in [(8, 200, 334, 64), (8, 100, 167, 128), (8, 50, 84, 256), (8, 25, 42, 512)]:
+    x, dy, dw = bf(N, H, W, C), bf(N, H, W, C), torch.zeros(3, 3, C, C, device=dev)
+    us = timeit(lambda: hip.conv3x3(2, x, dy, dw, N, H, W, C, H, W, C, 1, compute=1))
+    out.append((f"conv3x3_wgrad_{H}x{W}x{C}", us, 2.0 * N * H * W * 9 * C * C))
 for (M, Nn, K, ak, bk, sk) in [(33600, 256, 1024, 1, 1, 1), (8400, 2048, 256, 1, 0, 1), (8400, 256, 2048, 1, 1, 1), (133600, 128, 512, 1, 1, 1),
                                (256, 1024, 33600, 0, 0, 32), (64, 256, 534400, 0, 0, 256), (1024, 256, 33600, 0, 0, 32)]:
     A = bf(M, K) if ak else bf(K, M)
