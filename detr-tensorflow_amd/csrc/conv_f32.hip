@@ -1,8 +1,8 @@
 // conv_f32.hip -- ResNet backbone convolution kernels (NHWC / HWIO, fp32) for gfx950:
 //   * 3x3 implicit-GEMM convolution forward / dgrad / wgrad on the MFMA tile engine
 //     (no im2col buffer: the A-operand loader gathers input pixels, zero-filling the halo);
-//   * stem helpers: 7x7/s2 im2col (Ci = 3 is too thin for an implicit loader), 3x3/s2 max pool
-//     over the zero-padded map + its backward, stride-2 subsample gather/scatter.
+//   * stem helpers: 3x3/s2 max pool over the zero-padded map + its backward, stride-2 subsample gather/scatter
+//     (the 7x7 stem convolution itself is stem_conv.hip).
 // Reference: detr_tf/networks/resnet_backbone.py:11-32,98-137 (see include/detr_hip.h).
 #include "gemm_core.h"
 #include "gemm_bf16_core.h"
@@ -795,36 +795,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
 // ------------------------------------------------------------------------------------------------
 // stem / pooling / subsample elementwise kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void stem_im2col_kernel(const float *__restrict__ img, float *__restrict__ col, int N, int H, int W,
-                                   int Ho, int Wo, int ldcol, long long total_v) {
-    const int vpr = ldcol >> 2;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_v;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long m = idx / vpr;
-        const int v = (int)(idx - m * vpr);
-        const int wo = (int)(m % Wo);
-        const long long t = m / Wo;
-        const int ho = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = v * 4 + j;
-            float val = 0.0f;
-            if (k < 147) {
-                const int kh = k / 21;
-                const int rem = k - kh * 21;
-                const int kw = rem / 3;
-                const int c = rem - kw * 3;
-                const int hi = ho * 2 - 3 + kh, wi = wo * 2 - 3 + kw;
-                if (hi >= 0 && wi >= 0 && hi < H && wi < W) val = img[(((long long)n * H + hi) * W + wi) * 3 + c];
-            }
-            o[j] = val;
-        }
-        *reinterpret_cast<float4 *>(col + m * ldcol + v * 4) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-}
-
 __global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, uint8_t *__restrict__ amax,
                                    int N, int H, int W, int C, int Ho, int Wo, long long total) {
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -1336,19 +1306,6 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         launch(a);
     }
     DETR_LAUNCH_CHECK("conv3x3");
-    return 0;
-}
-
-extern "C" int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W, int32_t Ho,
-                                        int32_t Wo, int32_t ldcol, void *stream) {
-    DETR_REQUIRE(img && col, "stem_im2col: null operand");
-    DETR_REQUIRE(ldcol >= 148 && ldcol % 4 == 0, "stem_im2col: ldcol=%d must be >=148 and a multiple of 4", ldcol);
-    DETR_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "stem_im2col: bad output size");
-    DETR_REQUIRE(aligned16(col), "stem_im2col: col must be 16-byte aligned");
-    const long long total = (long long)N * Ho * Wo * (ldcol / 4);
-    hipLaunchKernelGGL(stem_im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, img, col, N, H,
-                       W, Ho, Wo, ldcol, total);
-    DETR_LAUNCH_CHECK("stem_im2col");
     return 0;
 }
 

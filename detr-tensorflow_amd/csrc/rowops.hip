@@ -214,108 +214,6 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_finish_kernel(const float 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// attention softmax over rows of the score tensor (in place) and its backward.
-// One wave per row, three passes over an L1/L2 resident row.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float *__restrict__ s, long long rows, int cols,
-                                                               long long ld) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
-         row += (long long)gridDim.x * wpb) {
-        float *r = s + row * ld;
-        float mx = -INFINITY;
-        for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, r[j]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < cols; j += 64) {
-            const float e = expf(r[j] - mx);
-            r[j] = e;
-            sum += e;
-        }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int j = lane; j < cols; j += 64) r[j] = r[j] * inv;
-    }
-}
-
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__restrict__ p, float *__restrict__ dp,
-                                                               long long rows, int cols, long long ld) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
-         row += (long long)gridDim.x * wpb) {
-        const float *pr = p + row * ld;
-        float *dr = dp + row * ld;
-        float dot = 0.f;
-        for (int j = lane; j < cols; j += 64) dot += pr[j] * dr[j];
-        dot = wave_sum(dot);
-        for (int j = lane; j < cols; j += 64) dr[j] = pr[j] * (dr[j] - dot);
-    }
-}
-
-// Register-resident variants (cols <= 64*NV): one read + one write of the row instead of three passes.
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_fwd_reg_kernel(float *__restrict__ s, long long rows, int cols,
-                                                                   long long ld) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
-         row += (long long)gridDim.x * wpb) {
-        float *r = s + row * ld;
-        float v[NV];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int j = lane + 64 * i;
-            v[i] = (j < cols) ? r[j] : -INFINITY;
-            mx = fmaxf(mx, v[i]);
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[i] = expf(v[i] - mx);          // exp(-inf) = 0 for the padding lanes
-            sum += v[i];
-        }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int j = lane + 64 * i;
-            if (j < cols) r[j] = v[i] * inv;
-        }
-    }
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_bwd_reg_kernel(const float *__restrict__ p, float *__restrict__ dp,
-                                                                   long long rows, int cols, long long ld) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (long long row = blockIdx.x * (long long)wpb + (threadIdx.x >> 6); row < rows;
-         row += (long long)gridDim.x * wpb) {
-        const float *pr = p + row * ld;
-        float *dr = dp + row * ld;
-        float pv[NV], dv[NV];
-        float dot = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int j = lane + 64 * i;
-            pv[i] = (j < cols) ? pr[j] : 0.f;
-            dv[i] = (j < cols) ? dr[j] : 0.f;
-            dot += pv[i] * dv[i];
-        }
-        dot = wave_sum(dot);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int j = lane + 64 * i;
-            if (j < cols) dr[j] = pv[i] * (dv[i] - dot);
-        }
-    }
-}
-
 // out[c] += alpha * sum_r x[r*ld + c] ; grid (col blocks of 256, row chunks)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long long rows,
                                                      int cols, long long ld, float alpha, int rows_per_block) {
@@ -459,31 +357,6 @@ extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream
                            C, d->dgamma, d->dbeta);
         DETR_LAUNCH_CHECK("layernorm bwd finish");
     }
-    return 0;
-}
-
-extern "C" int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream) {
-    DETR_REQUIRE(s && rows > 0 && cols > 0 && ld >= cols, "softmax fwd: bad args");
-    const int grid = (int)((rows + 3) / 4 > 16384 ? 16384 : (rows + 3) / 4);
-    hipStream_t st = (hipStream_t)stream;
-    if (cols <= 128) hipLaunchKernelGGL(softmax_rows_fwd_reg_kernel<2>, dim3(grid), dim3(256), 0, st, s, (long long)rows, cols, (long long)ld);
-    else if (cols <= 512) hipLaunchKernelGGL(softmax_rows_fwd_reg_kernel<8>, dim3(grid), dim3(256), 0, st, s, (long long)rows, cols, (long long)ld);
-    else if (cols <= 1536) hipLaunchKernelGGL(softmax_rows_fwd_reg_kernel<24>, dim3(grid), dim3(256), 0, st, s, (long long)rows, cols, (long long)ld);
-    else hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid), dim3(256), 0, st, s, (long long)rows, cols, (long long)ld);
-    DETR_LAUNCH_CHECK("softmax fwd");
-    return 0;
-}
-
-extern "C" int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,
-                                             void *stream) {
-    DETR_REQUIRE(p && dp && rows > 0 && cols > 0 && ld >= cols, "softmax bwd: bad args");
-    const int grid = (int)((rows + 3) / 4 > 16384 ? 16384 : (rows + 3) / 4);
-    hipStream_t st = (hipStream_t)stream;
-    if (cols <= 128) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<2>, dim3(grid), dim3(256), 0, st, p, dp, (long long)rows, cols, (long long)ld);
-    else if (cols <= 512) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<8>, dim3(grid), dim3(256), 0, st, p, dp, (long long)rows, cols, (long long)ld);
-    else if (cols <= 1536) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<24>, dim3(grid), dim3(256), 0, st, p, dp, (long long)rows, cols, (long long)ld);
-    else hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid), dim3(256), 0, st, p, dp, (long long)rows, cols, (long long)ld);
-    DETR_LAUNCH_CHECK("softmax bwd");
     return 0;
 }
 

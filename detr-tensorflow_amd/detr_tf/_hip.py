@@ -120,15 +120,12 @@ _SIGNATURES = {
     "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
     "detr_hip_scale_cols_bf16_group": [c_void_p, c_int32, c_void_p],
     "detr_hip_stem_conv7x7_f32": [POINTER(StemDesc), c_int32, c_void_p],
-    "detr_hip_stem_im2col_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_f32": [f32p, f32p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_f32": [f32p, c_void_p, f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_subsample2_fwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_subsample2_bwd_f32": [f32p, f32p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_layernorm_fwd": [POINTER(LayerNormDesc), c_void_p],
     "detr_hip_layernorm_bwd": [POINTER(LayerNormDesc), c_void_p],
-    "detr_hip_softmax_rows_fwd_f32": [f32p, c_int64, c_int32, c_int64, c_void_p],
-    "detr_hip_softmax_rows_bwd_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_void_p],
     "detr_hip_attention_fwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_attention_bwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p, c_void_p],

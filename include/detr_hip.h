@@ -149,8 +149,6 @@ int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream)
 
 /* ---------------------------------------------------------------------------------------------
  * Stem helpers (detr_tf/networks/resnet_backbone.py:11-26):
- *   im2col of the 7x7 stride-2 pad-3 conv on a 3-channel NHWC image into rows of `ldcol`
- *   (>= 147, multiple of 4) floats, k = (kh*7+kw)*3+c, tail zero -- the GEMM above does the conv;
  *   3x3 stride-2 max pool over the ZERO-padded (pad 1) map (padding takes part in the max, as
  *   ZeroPadding2D + MaxPool2D('valid') does) with argmax for the backward;
  *   maxpool backward fused with the stem ReLU mask.
@@ -170,8 +168,6 @@ typedef struct detr_scale_entry {
     int32_t reserved;
 } detr_scale_entry;
 int detr_hip_scale_cols_bf16_group(const detr_scale_entry *table, int32_t n, void *stream);
-int detr_hip_stem_im2col_f32(const float *img, float *col, int32_t N, int32_t H, int32_t W,
-                             int32_t Ho, int32_t Wo, int32_t ldcol, void *stream);
 
 /* The stem convolution as an IMPLICIT GEMM (no im2col buffer): ZeroPadding2D(3) + 7x7 stride-2 VALID conv 3 -> 64
  * (+ folded frozen BN + ReLU), resnet_backbone.py:11-26.   mode 0: y[M,64] = act((gather(img) @ w[147][64]) * scale + bias) * ...
@@ -247,10 +243,6 @@ typedef struct {
 } detr_layernorm_desc;
 int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream);
 int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);
-int detr_hip_softmax_rows_fwd_f32(float *s, int64_t rows, int32_t cols, int64_t ld, void *stream);
-/* ds = p * (dp - sum(dp*p)), written over dp */
-int detr_hip_softmax_rows_bwd_f32(const float *p, float *dp, int64_t rows, int32_t cols, int64_t ld,
-                                  void *stream);
 /* out[c] += alpha * sum_r x[r*ld + c] (atomic) */
 int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha,
                         void *stream);

@@ -379,20 +379,10 @@ def test_conv3x3_all_modes(hip, N, H, W, Ci, Co, stride):
     close(dwd, w.grad * scale, rtol=5e-5, what="conv3x3 wgrad(+scale)")
 
 
-def test_stem_im2col_gemm_and_pool(hip):
+def test_maxpool_fp32_fwd_bwd(hip):
     torch.manual_seed(11)
-    N, H, W = 2, 37, 50
-    img = torch.randn(N, H, W, 3)
-    k = torch.randn(7, 7, 3, 64) / 12.0
-    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    ref = F.conv2d(img.double().permute(0, 3, 1, 2), k.double().permute(3, 2, 0, 1), stride=2, padding=3).permute(0, 2, 3, 1)
-    col = torch.full((N * Ho * Wo, 160), 9.0, device=DEV)
-    imgd = g(img)
-    hip.call("detr_hip_stem_im2col_f32", imgd.data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, 160)
-    y = torch.zeros(N * Ho * Wo, 64, device=DEV)
-    hip.gemm(N * Ho * Wo, 64, 147, col, 160, 1, g(k.reshape(147, 64)), 64, 0, y, 64, act=1)
-    close(y.view(N, Ho, Wo, 64), ref.clamp_min(0), what="stem conv via im2col")
-    assert float(col[:, 147:].abs().max()) == 0.0
+    N, Ho, Wo = 2, 19, 25
+    y = g(torch.relu(torch.randn(N, Ho, Wo, 64)))
     # max pool over the zero padded map
     x = y.view(N, Ho, Wo, 64)
     Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
@@ -478,23 +468,6 @@ def test_layernorm_fwd_bwd(hip, rows, C):
         assert torch.equal(dg3, res[0][0]) and torch.equal(db3, res[0][1])
     close(dg3, gam.grad, rtol=5e-5, what="layernorm dgamma (queued finish)")
     close(db3, bet.grad, rtol=5e-5, what="layernorm dbeta (queued finish)")
-
-
-@pytest.mark.parametrize("rows,cols,ld", [(640, 1050, 1052), (64, 100, 100), (10, 7, 8), (33, 1344, 1344)])
-def test_softmax_rows(hip, rows, cols, ld):
-    torch.manual_seed(rows + cols)
-    s = (torch.randn(rows, cols, dtype=torch.float64) * 3).requires_grad_(True)
-    p = torch.softmax(s, -1)
-    dp = torch.randn(rows, cols, dtype=torch.float64)
-    p.backward(dp)
-    sd = torch.full((rows, ld), 5.0, device=DEV)
-    sd[:, :cols] = s.detach().float().to(DEV)
-    hip.call("detr_hip_softmax_rows_fwd_f32", sd.data_ptr(), rows, cols, ld)
-    close(sd[:, :cols], p, rtol=1e-5, what="softmax fwd")
-    dpd = torch.zeros(rows, ld, device=DEV)
-    dpd[:, :cols] = dp.float().to(DEV)
-    hip.call("detr_hip_softmax_rows_bwd_f32", sd.data_ptr(), dpd.data_ptr(), rows, cols, ld)
-    close(dpd[:, :cols], s.grad, rtol=2e-5, what="softmax bwd")
 
 
 def test_small_elementwise(hip):
