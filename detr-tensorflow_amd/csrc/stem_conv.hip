@@ -62,6 +62,142 @@ __device__ __forceinline__ float4 stem_gather4(const BufSrc &src, const StemArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward on bf16 activations, input rows staged once (the halo idea of conv_halo.h).  The gathering kernel below issues
+// 40 scalar dword loads (+ their k / 21 index arithmetic) per thread and 64 x 64 tile and runs at 1.15 TB/s / 123 TFLOP/s
+// (rocprofv3: 326 us at B = 8, 800 x 1333) -- neither roofline.  Here a persistent workgroup keeps the kernel tensor in
+// LDS for its lifetime and walks over tiles of 64 consecutive output pixels of one output row: the 7 input rows x 133
+// input pixels x 3 channels the tile touches are loaded with coalesced dword loads (14 per thread), rounded to bf16 and
+// staged as P[row][399]; output pixel m then finds the (kw, c) run of kernel row kh at P[kh][6 m ..]: with every kernel
+// row padded from 21 to 24 entries (zero weights) an MFMA k-step of 8 never straddles rows and its fragment is 16 bytes
+// at a 4-byte aligned LDS address (12 m + 2 j bytes, j in {0, 8, 16}; lane stride 3 dwords: conflict free).
+// K' = 7 x 24 = 168 -> 176 (11 k-steps).
+// ------------------------------------------------------------------------------------------------
+constexpr int SR_TW = 64;                          // output pixels per tile
+constexpr int SR_PE = (2 * SR_TW + 5) * 3;         // 399 input floats per staged row
+constexpr int SR_PLD = 408;                        // bf16 per staged row: >= 6 * 63 + 24, the tail stays zero
+constexpr int SR_KP = 176;                         // padded reduction depth
+constexpr int SR_SLD = 36;                         // floats per staged output row (32 + 4)
+
+struct StemRowsSmem {
+    unsigned short P[2][7][SR_PLD];
+    unsigned short B[SR_KP * 64];                  // transpose-read image of the padded kernel tensor (LoaderMNt<64> unit order)
+    float stage[4][32][SR_SLD];
+};
+
+__global__ __launch_bounds__(GEMM_THREADS, 3) void stem_fwd_rows_bf16_kernel(StemArgs a, int tiles_w, int ntiles) {
+    __shared__ __attribute__((aligned(16))) StemRowsSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    BufSrc src;
+    src.init(a.img, (long long)a.N * a.H * a.W * 3);
+    // ---- once per workgroup: zero tails of the patch rows, the padded kernel tensor as a transpose-read image
+    for (int i = tid; i < 2 * 7 * (SR_PLD - SR_PE); i += GEMM_THREADS) {
+        const int r = i / (SR_PLD - SR_PE), e = i - r * (SR_PLD - SR_PE);
+        (&sm.P[0][0][0])[r * SR_PLD + SR_PE + e] = 0;
+    }
+    for (int u = tid; u < SR_KP * 16; u += GEMM_THREADS) {
+        const int kp = u >> 4, col = (u & 15) * 4;
+        const int kh = kp / 24, j = kp - 24 * kh;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kh < 7 && j < 21) w = *reinterpret_cast<const float4 *>(a.w + (long long)(kh * 21 + j) * 64 + col);
+        const int o = (((kp >> 2) * 4 + (col >> 4)) * 64) + (kp & 3) * 16 + ((col >> 2) & 3) * 4;
+        *reinterpret_cast<uint2 *>(&sm.B[o]) = make_uint2(pack_bf16(w.x, w.y), pack_bf16(w.z, w.w));
+    }
+    // epilogue constants: a lane owns 8 consecutive channels of a pixel
+    const int c8 = (lane & 3) * 8, rsub = lane >> 2;
+    const int col = wn * 32 + c8;
+    float bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bi[j] = a.e.bias ? a.e.bias[col + j] : 0.0f;
+    // A fragment offsets (shorts, inside one patch buffer) of the 11 k-steps: k' = 16 s + 8 hi -> (kh, j)
+    int aoff[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        const int kp = 16 * s + 8 * hi;
+        const int kh = kp / 24, j = kp - 24 * kh;
+        aoff[s] = (kh < 7 ? kh : 6) * SR_PLD + 6 * (wm * 32 + l31) + (kh < 7 ? j : 0);      // (k' >= 168: zero weights, any finite data)
+    }
+    float rp[14];
+    auto patch_load = [&](int t, float (&rp)[14]) {                  // tile t >= ntiles: out-of-range offsets, no traffic
+        const int twi = t % tiles_w;
+        const int r2 = t / tiles_w;
+        const int ho = r2 % a.Ho, n = r2 / a.Ho;
+        const int fc0 = (2 * twi * SR_TW - 3) * 3;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int hin = 2 * ho - 3 + r;
+            const bool rok = t < ntiles && hin >= 0 && hin < a.H;
+            const unsigned rowb = (unsigned)((n * a.H + hin) * a.W * 3 + fc0) * 4u;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int e = tid + 256 * h2;
+                const bool ok = rok && e < SR_PE && fc0 + e >= 0 && fc0 + e < 3 * a.W;
+                rp[2 * r + h2] = src.ld1(ok ? rowb + 4u * (unsigned)e : BUF_OOB);
+            }
+        }
+    };
+    const int e1c = tid + 256 < SR_PLD - 1 ? tid + 256 : SR_PLD - 1;
+    auto patch_store = [&](int buf, const float (&rp)[14]) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            // (unconditional: elements past the 399 of a row were requested out of range = 0 and land in the zero tail)
+            sm.P[buf][r][tid] = (unsigned short)(pack_bf16(rp[2 * r], 0.0f) & 0xFFFFu);
+            sm.P[buf][r][e1c] = (unsigned short)(pack_bf16(rp[2 * r + 1], 0.0f) & 0xFFFFu);
+        }
+    };
+    int t = blockIdx.x;
+    patch_load(t, rp);
+    patch_store(0, rp);
+    patch_load(t + gridDim.x, rp);
+    __syncthreads();
+    int cur = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const unsigned short *P = &sm.P[cur][0][0];
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const uint32_t *pa = reinterpret_cast<const uint32_t *>(P + aoff[s]);
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(pa[0], pa[1], pa[2], pa[3]));
+            const bf16x8 fb = frag_tr<64>(reinterpret_cast<const unsigned short (*)[BF_LD]>(sm.B + (s >> 1) * 2048), wn * 32, (s & 1) * 16, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        // the next tile's rows (requested one tile ago) go to the other buffer; request the tile after it
+        patch_store(cur ^ 1, rp);
+        patch_load(t + 2 * gridDim.x, rp);
+        // ---- epilogue: wave-private transposition, y = relu(acc + shift) as bf16, 16 bytes per lane
+        const int twi = t % tiles_w;
+        const int r2 = t / tiles_w;
+        const long long prow0 = (long long)r2 * a.Wo + twi * SR_TW + wm * 32;      // r2 = n * Ho + ho
+        const int wn_ok = a.Wo - (twi * SR_TW + wm * 32);
+        float *stage = &sm.stage[wave][0][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * SR_SLD + l31] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int tw = it * 16 + rsub;
+            const float4 v0 = *reinterpret_cast<const float4 *>(stage + tw * SR_SLD + c8);
+            const float4 v1 = *reinterpret_cast<const float4 *>(stage + tw * SR_SLD + c8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] += bi[j];
+                if (a.e.act == 1) v[j] = fmaxf(v[j], 0.0f);
+            }
+            if (tw < wn_ok)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(a.y) + (prow0 + tw) * 64 + col) =
+                    make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7]));
+        }
+        __syncthreads();                           // patch[cur ^ 1] complete, patch[cur] and the stage free
+        cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward: y = act((gather(img) @ w) + bias)      tile 64 pixels x 64 channels
 // ------------------------------------------------------------------------------------------------
 template <bool BF>
@@ -287,6 +423,15 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
         e.c16 = d->y_dtype == 1;
         a.w = d->w; a.y = d->y; a.e = e;
         dim3 grid((unsigned)cdiv(a.M, 64));
+        // bf16 output, folded scale: the row-staging kernel (DETR_HIP_STEM_ROWS=2: the gathering kernel)
+        if (bf && e.c16 && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) && (!d->bias || aligned16(d->bias)) &&
+            env_tile("DETR_HIP_STEM_ROWS") != 2) {
+            const int tiles_w = cdiv(a.Wo, SR_TW), ntiles = a.N * a.Ho * tiles_w;
+            const int wgs = ntiles < 768 ? ntiles : 768;
+            hipLaunchKernelGGL(stem_fwd_rows_bf16_kernel, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, a, tiles_w, ntiles);
+            DETR_LAUNCH_CHECK("stem conv forward (staged rows)");
+            return 0;
+        }
         if (bf) hipLaunchKernelGGL(stem_fwd_kernel<true>, grid, dim3(GEMM_THREADS), 0, s, a);
         else hipLaunchKernelGGL(stem_fwd_kernel<false>, grid, dim3(GEMM_THREADS), 0, s, a);
         DETR_LAUNCH_CHECK("stem conv forward");

@@ -326,6 +326,38 @@ def test_stem_conv_implicit_gemm(hip, N, H, W, compute):
     close(dw1.view(7, 7, 3, 64), w.grad * scale, rtol=5e-5, what="stem conv wgrad (unsplit)")
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 37, 53), (1, 64, 300), (3, 23, 131), (1, 9, 8)])
+def test_stem_conv_row_staged_forward(hip, monkeypatch, N, H, W):
+    """The row-staging stem forward (bf16 output: persistent workgroups, kernel tensor resident in LDS, 7 input rows of a
+    64-pixel output run staged once, kernel rows padded 21 -> 24) against fp64 on the same bf16-rounded operands (one bf16
+    rounding of the output) and against the gathering kernel (DETR_HIP_STEM_ROWS=2), which sums the same products in
+    another order: <= 1 bf16 ulp apart on a small fraction of the outputs.  Shapes: ragged last tile, several tiles per row,
+    several images, an image narrower than one tile."""
+    torch.manual_seed(N + H + W)
+    img = _bf(torch.randn(N, H, W, 3))
+    w = _bf(torch.randn(7, 7, 3, 64) / 12.0)
+    shift = torch.randn(64, dtype=torch.float64)
+    z = F.conv2d(F.pad(img.permute(0, 3, 1, 2), (3, 3, 3, 3)), w.permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
+    Ho, Wo = z.shape[1], z.shape[2]
+    ref = torch.relu(z + shift)
+    imgd, ws, sd = g(img.float()), g(w.float().reshape(147, 64)), g(shift.float())
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("DETR_HIP_STEM_ROWS", mode)
+        y = torch.full((N, Ho, Wo, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.stem_conv(0, imgd, ws, y, N, H, W, Ho, Wo, bias=sd, act=1, compute=1)
+        torch.cuda.synchronize()
+        outs[mode] = y.float().cpu().double()
+    monkeypatch.delenv("DETR_HIP_STEM_ROWS")
+    rows, gather = outs["0"], outs["2"]
+    scale = float(ref.abs().max())
+    err = (rows - ref).abs()
+    assert float((err / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.1, "row-staged stem: more than one bf16 rounding from fp64"
+    diff = (rows - gather).abs()
+    assert float((diff > 0).double().mean()) < 5e-3, float((diff > 0).double().mean())
+    assert float((diff / (gather.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
+
+
 def test_linear_helpers(hip):
     torch.manual_seed(5)
     M, K, N = 420, 256, 92
