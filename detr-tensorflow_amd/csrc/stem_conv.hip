@@ -396,6 +396,111 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
     epilogue<BM, BN, 2, 2>(acc, reinterpret_cast<float *>(smem_raw), dw, 64, STEM_K, 64, k0, 0, wm, wn, lane, wave, a.e);
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient on bf16 activations with the input rows staged once (see stem_fwd_rows_bf16_kernel): a persistent
+// workgroup accumulates ALL 176 padded kernel rows x 64 channels (12 MFMA tiles, 3 per wave) over units of 32 consecutive
+// output pixels.  Per unit the 7 x 69-pixel input rows are staged as P[row][207] and dy[32][64] as a transpose-read image;
+// the A^T fragment of kernel row k' = (kh, j) -- 8 consecutive output pixels m -- is 8 two-byte LDS reads at a 12-byte
+// stride (P[kh][6 m + j]), no index arithmetic.  The gathering kernel above needs 3 workgroups (64 k each) x 8 scalar global
+// gathers per thread and unit for the same operand (rocprofv3: 322 us at B = 8, 800 x 1333, 1.1 TB/s).
+// Every workgroup writes its partial [147][64] slab; the caller reduces them (launch_splitk_reduce).
+// ------------------------------------------------------------------------------------------------
+constexpr int SW_TW = 32;
+constexpr int SW_PE = (2 * SW_TW + 5) * 3;         // 207
+constexpr int SW_PLD = 216;                        // >= 6 * 31 + 24, the tail stays zero
+
+struct StemWgradRowsSmem {
+    unsigned short P[2][7][SW_PLD];
+    unsigned short D[2][32 * 64];
+};
+
+__global__ __launch_bounds__(GEMM_THREADS, 3) void stem_wgrad_rows_bf16_kernel(StemArgs a, int chunks, int nunits) {
+    __shared__ __attribute__((aligned(16))) StemWgradRowsSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave & 1, rb0 = wave >> 1;      // this wave: channel block cb, kernel-row blocks rb0, rb0 + 2, rb0 + 4
+    const int l31 = lane & 31, hi = lane >> 5;
+    BufSrc src, dsrc;
+    src.init(a.img, (long long)a.N * a.H * a.W * 3);
+    dsrc.init_bytes(a.dy, (long long)a.M * 64 * 2);
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    int aoff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int kp = (rb0 + 2 * i) * 32 + l31;
+        const int kh = kp / 24, j = kp - 24 * kh;
+        aoff[i] = (kh < 7 ? kh * SW_PLD + j : 6 * SW_PLD) + 48 * hi;      // (k' >= 168: rows nobody stores, any finite data)
+    }
+    const int e0c = tid < SW_PLD - 1 ? tid : SW_PLD - 1;
+    float rp[7];
+    uint2 rd[2];
+    auto unit_load = [&](int u, float (&rp)[7], uint2 (&rd)[2]) {       // u >= nunits: out-of-range offsets, no traffic
+        const int chunk = u % chunks;
+        const int r2 = u / chunks;                 // n * Ho + ho
+        const int ho = r2 % a.Ho, n = r2 / a.Ho;
+        const int wo0 = chunk * SW_TW;
+        const int fc0 = (2 * wo0 - 3) * 3;
+        const bool live = u < nunits;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int hin = 2 * ho - 3 + r;
+            const bool ok = live && hin >= 0 && hin < a.H && tid < SW_PE && fc0 + tid >= 0 && fc0 + tid < 3 * a.W;
+            rp[r] = src.ld1(ok ? (unsigned)((n * a.H + hin) * a.W * 3 + fc0 + tid) * 4u : BUF_OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            const int j = 4 * (v >> 6) + ((v >> 2) & 3);
+            const int col = 16 * ((v >> 4) & 3) + 4 * (v & 3);
+            const bool ok = live && wo0 + j < a.Wo;
+            rd[i] = dsrc.ld8(ok ? ((unsigned)(r2 * a.Wo + wo0 + j) * 64u + (unsigned)col) * 2u : BUF_OOB);
+        }
+    };
+    auto unit_store = [&](int buf, const float (&rp)[7], const uint2 (&rd)[2]) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) sm.P[buf][r][e0c] = (unsigned short)(pack_bf16(rp[r], 0.0f) & 0xFFFFu);   // tid >= 207: zeros into the tail
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = rd[i];
+    };
+    int u = blockIdx.x;
+    unit_load(u, rp, rd);
+    unit_store(0, rp, rd);
+    unit_load(u + gridDim.x, rp, rd);
+    __syncthreads();
+    int cur = 0;
+    for (; u < nunits; u += gridDim.x) {
+        unit_store(cur ^ 1, rp, rd);
+        unit_load(u + 2 * gridDim.x, rp, rd);
+        const unsigned short *P = &sm.P[cur][0][0];
+        const unsigned short(*D)[BF_LD] = reinterpret_cast<const unsigned short(*)[BF_LD]>(sm.D[cur]);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 fb = frag_tr<64>(D, cb * 32, st * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned short *pp = P + aoff[i] + st * 96;
+                const uint4 w = make_uint4((uint32_t)pp[0] | ((uint32_t)pp[6] << 16), (uint32_t)pp[12] | ((uint32_t)pp[18] << 16),
+                                           (uint32_t)pp[24] | ((uint32_t)pp[30] << 16), (uint32_t)pp[36] | ((uint32_t)pp[42] << 16));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), fb, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *ws = a.dw + (long long)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kp = (rb0 + 2 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int kh = kp / 24, j = kp - 24 * kh;
+            if (kh < 7 && j < 21) ws[(kh * 21 + j) * 64 + cb * 32 + l31] = acc[i][r];
+        }
+}
+
 }  // namespace detr
 
 using namespace detr;
@@ -440,6 +545,21 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
     // weight gradient: d->w = dy [M, 64], d->y = dw [147, 64] (accumulated: dw += alpha * scale[co] * sum)
     DETR_REQUIRE(!d->bias && d->act == 0, "stem conv wgrad: only scale/alpha epilogue");
     a.dy = d->w; a.dw = d->y;
+    {   // bf16 dy: the row-staging kernel with its own persistent grid (DETR_HIP_STEM_ROWS=2: the gathering kernel)
+        const int chunks = cdiv(a.Wo, SW_TW), nunits = a.N * a.Ho * chunks;
+        const int wgs = nunits < 768 ? nunits : 768;
+        const long long part = (long long)STEM_K * 64;
+        if (bf && d->w_dtype == 1 && d->workspace && aligned16(d->workspace) && d->workspace_bytes >= (long long)wgs * part * 4 &&
+            (long long)a.M * 64 * 2 <= BUF_MAX_BYTES && env_tile("DETR_HIP_STEM_ROWS") != 2) {
+            a.dw = d->workspace;
+            a.part_stride = part;
+            hipLaunchKernelGGL(stem_wgrad_rows_bf16_kernel, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, a, chunks, nunits);
+            DETR_LAUNCH_CHECK("stem conv wgrad (staged rows)");
+            launch_splitk_reduce(d->workspace, wgs, part, STEM_K, 64, d->y, 64, e.alpha, e.scale, s);
+            DETR_LAUNCH_CHECK("stem conv wgrad reduce");
+            return 0;
+        }
+    }
     int split = d->split > 0 ? d->split : 1;
     const int bk = bf ? BF_BK : GEMM_BK;
     int rps = cdiv(cdiv(a.M, split), bk) * bk;

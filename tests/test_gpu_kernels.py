@@ -356,6 +356,28 @@ def test_stem_conv_row_staged_forward(hip, monkeypatch, N, H, W):
     diff = (rows - gather).abs()
     assert float((diff > 0).double().mean()) < 5e-3, float((diff > 0).double().mean())
     assert float((diff / (gather.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
+    # weight gradient with a bf16 dy: the row-staging kernel (all 147 kernel rows per workgroup, persistent over units of 32
+    # pixels, per-workgroup slabs) against fp64 and against the gathering kernel
+    hip.ensure_workspace(DEV)
+    dy = _bf(torch.randn(N, Ho, Wo, 64))
+    bn = torch.rand(64, dtype=torch.float64) + 0.5
+    wref = torch.einsum("nhwk,nhwc->kc", F.unfold(F.pad(img.permute(0, 3, 1, 2), (3, 3, 3, 3)), 7, stride=2)
+                        .view(N, 3, 49, Ho, Wo).permute(0, 3, 4, 2, 1).reshape(N, Ho, Wo, 147), dy) * bn
+    dyd, bnd = g(dy.float()).to(torch.bfloat16), g(bn.float())
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("DETR_HIP_STEM_ROWS", mode)
+        pair = []
+        for rep in range(2):
+            dw = torch.zeros(147, 64, device=DEV)
+            hip.stem_conv(2, imgd, dyd, dw, N, H, W, Ho, Wo, scale=bnd, split=7, compute=1)
+            pair.append(dw)
+        assert torch.equal(pair[0], pair[1]), "stem weight gradient is not deterministic"
+        res[mode] = pair[0]
+    monkeypatch.delenv("DETR_HIP_STEM_ROWS")
+    close(res["0"], wref, rtol=3e-3, what="stem wgrad (staged rows, bf16 operands)")
+    close(res["2"], wref, rtol=3e-3, what="stem wgrad (gathering kernel, bf16 operands)")
+    close(res["0"], res["2"].double().cpu(), rtol=1e-4, what="stem wgrad: staged rows vs gathering kernel")
 
 
 def test_linear_helpers(hip):
