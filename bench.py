@@ -362,7 +362,7 @@ def main():
                             "workload": f"DETR-R50 {prec} forward (eval) + set loss 6 levels, batch {args.batch}, {args.height}x{args.width}",
                             "frac_of_mfma_peak": round(args.batch / d * FWD_GFLOP_PER_IMAGE / 1e3 /
                                                        (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS), 4)}
-            if prec == "fp32":       # C1: one 480x640 image, eval forward + post-processing (eval.py:41-45)
+            if True:                 # C1: one 480x640 image, eval forward + post-processing (eval.py:41-45), both precisions
                 img1 = torch.from_numpy(np.random.default_rng(7).normal(size=(1, 480, 640, 3)).astype(np.float32)).to(dev)
                 for _ in range(2):
                     get_model_inference(m(img1, training=False), 91)
@@ -372,8 +372,8 @@ def main():
                     get_model_inference(m(img1, training=False), 91)
                 torch.cuda.synchronize()
                 d1 = (time.perf_counter() - t) / 5
-                configs["c1_forward_480x640_fp32"] = {"value": round(1.0 / d1, 1), "unit": "images/sec", "latency_ms": round(d1 * 1e3, 3),
-                                                      "workload": "DETR-R50 fp32 eval forward + get_model_inference, ONE 480x640 image (58.3 GFLOP)"}
+                configs[f"c1_forward_480x640_{prec}"] = {"value": round(1.0 / d1, 1), "unit": "images/sec", "latency_ms": round(d1 * 1e3, 3),
+                                                         "workload": f"DETR-R50 {prec} eval forward + get_model_inference, ONE 480x640 image (58.3 GFLOP)"}
             m = None
             torch.cuda.empty_cache()
 
