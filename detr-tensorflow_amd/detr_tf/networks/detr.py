@@ -5,6 +5,8 @@ with fp32 NHWC images -- and returns the same output structure
 `{"pred_logits": [B,Q,C], "pred_boxes": [B,Q,4], "aux": [{...}] * (levels-1)}` (detr.py:190-204);
 underneath every layer is a HIP kernel launch of `engine.DetrEngine`.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -38,6 +40,7 @@ class DetrModel:
         self.headless = (not include_top) and nb_class is None
         self.name = "detr" if self.headless else "detr_finetuning"
         self.tf_backbone = bool(tf_backbone)
+        self.eval_graph, self._eval_graph, self._eval_seen = True, None, None     # hipGraph replay of the eval forward (_eval_forward)
         self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed,
                                  tf_backbone=tf_backbone)
         if precision not in ("fp32", "bf16"):
@@ -89,11 +92,38 @@ class DetrModel:
         self.engine.P.save(self._npz(path))
 
     # ---- forward ----------------------------------------------------------------------------
+    def _eval_forward(self, images):
+        """Eval-mode forward.  The launch sequence of a fixed input shape is static, so the second call with the same shape
+        (and the same weights version) records it as a hipGraph and later calls replay it: a single 480x640 image is ~300
+        launches whose host cost (ctypes, ~10 us each) exceeds their GPU time.  DETR_HIP_GRAPH=0 / model.eval_graph = False:
+        always eager.  Outputs are views of the engine's buffers either way (the caller clones)."""
+        eng = self.engine
+        if not (self.eval_graph and os.environ.get("DETR_HIP_GRAPH", "1") != "0" and images.is_cuda):
+            return eng.forward(images, training=False)
+        key = (tuple(images.shape), eng._weights_version, eng.compute)
+        g = self._eval_graph
+        if g is not None and g["key"] == key:
+            g["static"].copy_(images)
+            g["graph"].replay()
+            return g["out"]
+        if self._eval_seen != key:              # first sighting: eager (allocates the buffers, refreshes derived weight copies)
+            out = eng.forward(images, training=False)
+            self._eval_seen = (tuple(images.shape), eng._weights_version, eng.compute)
+            return out
+        static = g["static"] if g is not None and g["static"].shape == images.shape else torch.empty_like(images)
+        static.copy_(images)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = eng.forward(static, training=False)
+        self._eval_graph = dict(key=key, static=static, graph=graph, out=out)
+        graph.replay()
+        return out
+
     def __call__(self, images, training=False):
         if isinstance(images, np.ndarray):
             images = torch.from_numpy(images)
         images = images.to(device=self.device, dtype=torch.float32)
-        logits, boxes = self.engine.forward(images, training=training)
+        logits, boxes = self.engine.forward(images, training=True) if training else self._eval_forward(images)
         if self.headless:
             hs = self.engine._bufs["dec:hs"].view(self.engine.num_dec, images.shape[0], self.engine.Q, 256)
             return hs if training else hs.clone()

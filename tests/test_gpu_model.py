@@ -454,6 +454,34 @@ def test_c3_bf16_full_shape_forward_loss_vs_fp32_oracle(hip, c2_ref):
             assert abs(float(log[k]) - float(v)) <= 3e-3 * abs(float(v)) + 1e-5, (k, float(log[k]), float(v))
 
 
+def test_eval_forward_graph_replay_equals_eager(hip, small):
+    """model(images, training=False): the first call of a shape runs eagerly, the second records the launch sequence as a
+    hipGraph, later ones replay it; bit-identical outputs (the forward has no atomics), re-recorded when the weights change,
+    a new input is picked up through the static buffer, and model.eval_graph = False stays eager."""
+    from detr_tf.networks.detr import get_detr_model
+    model = get_detr_model(small["cfg"], include_top=True, dropout=0.0)
+    model.load_weights(small["params"])
+    x1 = torch.from_numpy(small["images"]).cuda()
+    x2 = x1.flip(0) * 0.5
+    model.eval_graph = False
+    e1, e2 = model(x1), model(x2)
+    model.eval_graph = True
+    outs = [model(x1) for _ in range(3)]                       # eager, record + replay, replay
+    assert model._eval_graph is not None
+    for o in outs:
+        assert torch.equal(o["pred_logits"], e1["pred_logits"]) and torch.equal(o["pred_boxes"], e1["pred_boxes"])
+        assert torch.equal(o["aux"][2]["pred_logits"], e1["aux"][2]["pred_logits"])
+    o2 = model(x2)                                             # same shape, new values: replay with the static input refreshed
+    assert torch.equal(o2["pred_logits"], e2["pred_logits"]) and torch.equal(o2["pred_boxes"], e2["pred_boxes"])
+    g_before = model._eval_graph["graph"]
+    params2 = {k: (v + 0.5 if k == "class_embed/bias" else v) for k, v in small["params"].items()}
+    model.load_weights(params2)                                # new weights version: eager once, then a fresh recording
+    n1, n2, n3 = model(x1), model(x1), model(x1)
+    assert model._eval_graph["graph"] is not g_before
+    assert torch.equal(n1["pred_logits"], n2["pred_logits"]) and torch.equal(n2["pred_logits"], n3["pred_logits"])
+    assert not torch.equal(n1["pred_logits"], e1["pred_logits"])
+
+
 def test_c1_single_480x640_image_forward_and_inference(hip):
     """BASELINE config C1 (eval.py:41-45): ONE 480x640 image through the eval-mode forward (feature map 15x20, L = 300)
     and get_model_inference in the three box formats (inference.py:68-95), against the oracle."""
