@@ -454,6 +454,36 @@ def test_c3_bf16_full_shape_forward_loss_vs_fp32_oracle(hip, c2_ref):
             assert abs(float(log[k]) - float(v)) <= 3e-3 * abs(float(v)) + 1e-5, (k, float(log[k]), float(v))
 
 
+def test_model_surface_summary_layers_save_load(hip, small, capsys, tmp_path):
+    """The Keras-model surface the reference's scripts touch (eval.py:26 / finetune_coco.py:37 `summary()`, optimizers.py:14-42
+    `layers` / `get_layer(name).trainable_variables`, `save_weights` / `load_weights`): layer names in forward order, parameter
+    counts that add up to the 41.5 M trainable scalars of DETR-R50, a ValueError for an unknown layer like Keras,
+    and a bit-exact weights round trip through the .npz file."""
+    model = small["model"]
+    model.summary()
+    text = capsys.readouterr().out
+    names = [l.name for l in model.layers]
+    assert names[0] in ("class_embed", "bbox_embed") or "transformer" in names          # reverse-forward parameter order
+    for n in ("transformer", "input_proj", "query_embed", "class_embed"):
+        assert n in names and n in text
+    total = sum(v.numel() for l in model.layers for v in l.trainable_variables)
+    assert total == sum(v.numel() for v in model.trainable_variables)
+    assert 41.0e6 < total < 42.0e6, total
+    assert f"{total:,}" in text
+    tr = model.get_layer("transformer")
+    assert 17.0e6 < sum(v.numel() for v in tr.trainable_variables) < 17.7e6           # 17.36 M (SURVEY a24)
+    with pytest.raises(ValueError):
+        model.get_layer("no_such_layer")
+    path = str(tmp_path / "w")
+    model.save_weights(path)
+    from detr_tf.networks.detr import get_detr_model
+    twin = get_detr_model(small["cfg"], include_top=True, dropout=0.0, weights=path + ".npz", seed=123)
+    for a, b in zip(model.trainable_variables, twin.trainable_variables):
+        assert torch.equal(a, b)
+    x = torch.from_numpy(small["images"]).cuda()
+    assert torch.equal(model(x)["pred_logits"], twin(x)["pred_logits"])
+
+
 def test_eval_forward_graph_replay_equals_eager(hip, small):
     """model(images, training=False): the first call of a shape runs eagerly, the second records the launch sequence as a
     hipGraph, later ones replay it; bit-identical outputs (the forward has no atomics), re-recorded when the weights change,
