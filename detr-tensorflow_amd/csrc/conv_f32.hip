@@ -441,7 +441,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN
     LoaderConvAb<BM, DGRAD, X16> la;
     la.init(a, m0, tid);
     // fwd weights: transpose-read image; W16: the kernel is already bf16 in memory (per-step weight shadow)
-    using LB = typename std::conditional<W16, typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN>>::type,
+    using LB = typename std::conditional<W16, typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN, true>>::type,
                                          typename std::conditional<DGRAD, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
     constexpr int NRB = LB::NREG;
     LB lb;

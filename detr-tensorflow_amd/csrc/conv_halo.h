@@ -152,7 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(Conv
         }
     };
     // ---- kernel loader: fwd [k = ci][n = co] (transpose-read image), dgrad [n = ci][k = co]
-    using LB = typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN>>::type;
+    using LB = typename std::conditional<DGRAD, LoaderKh<BN>, LoaderMNth<BN, true>>::type;
     constexpr int NRB = LB::NREG;
     LB lb;
     lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);

@@ -170,11 +170,17 @@ struct LoaderKh {
     }
 };
 
-// [k][mn], mn contiguous: transpose-read image, 8-byte units of 4 mn (same unit map as LoaderMNt)
-template <int BMN>
+// [k][mn], mn contiguous: transpose-read image, 8-byte units of 4 mn (same unit map as LoaderMNt).
+// WIDE (compile time -- a run-time switch around the requests would cost the operand pipelines their exact vmcnt waits,
+// measured +0.8 ms per step): a thread requests PAIRS of adjacent units, one 16-byte load and one ds_write_b128 instead of
+// two 8-byte ones; register 2i / 2i + 1 then hold units 2p / 2p + 1 of pair p = tid + 256 i.  Needs MN % 8 == 0, a row stride
+// % 8 == 0 and a tile origin % 8 == 0 (checked by the host dispatch); a caller that sums the registers per column group
+// (the fused bias gradient of gemm_bf16c_body) uses the narrow form: a pair spans two column groups.
+template <int BMN, bool WIDE = false>
 struct LoaderMNth {
     static constexpr int NB = BMN / 16;
     static constexpr int NU = BMN / 32;
+    static_assert(!WIDE || NU % 2 == 0, "wide units come in pairs");
     typedef uint2 Reg;
     static constexpr int NREG = NU;
     BufSrc src;
@@ -186,18 +192,36 @@ struct LoaderMNth {
         ld2b = (unsigned)(ld_ * 2); mn0 = mn0_; MN = MN_; tid = tid_;
     }
     __device__ __forceinline__ void load(int k0, int K, uint2 (&r)[NU], unsigned base = 0) const {
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int u = tid + 256 * i;
-            const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
-            const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
-            r[i] = src.ld8((k < K && col + 4 <= MN) ? base + (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB);
+            for (int i = 0; i < NU / 2; ++i) {
+                const int u = 2 * (tid + 256 * i);
+                const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+                const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+                const uint4 v = src.ld16((k < K && col + 8 <= MN) ? base + (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB);
+                r[2 * i] = make_uint2(v.x, v.y);
+                r[2 * i + 1] = make_uint2(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = tid + 256 * i;
+                const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+                const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+                r[i] = src.ld8((k < K && col + 4 <= MN) ? base + (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB);
+            }
         }
     }
     __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const uint2 (&r)[NU]) const {
         unsigned short *flat = &S[0][0];
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = r[i];
+            for (int i = 0; i < NU / 2; ++i)
+                *reinterpret_cast<uint4 *>(flat + (tid + 256 * i) * 8) = make_uint4(r[2 * i].x, r[2 * i].y, r[2 * i + 1].x, r[2 * i + 1].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) *reinterpret_cast<uint2 *>(flat + (tid + 256 * i) * 4) = r[i];
+        }
     }
 };
 

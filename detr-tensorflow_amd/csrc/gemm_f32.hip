@@ -30,9 +30,11 @@ struct GemmArgs {
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
 // one column group (4 consecutive rows m of A); the holders of a group are combined in a fixed order through LDS.
+// bf16_map: 0 = LoaderMN (fp32, K tile 16), 1 = LoaderMNt / narrow LoaderMNth unit map, 2 = WIDE LoaderMNth (two slots per
+// thread: registers 2i -> column group 4*ib + c, 2i + 1 -> 4*ib + c + 1)
 template <int BM, int NSLOT>
 __device__ __forceinline__ void rowsum_finish(const float4 (&rs)[NSLOT], float *lds, const GemmArgs &g, int m0, int split,
-                                              int tid, bool bf16_map) {
+                                              int tid, int bf16_map) {
     float4 *part = reinterpret_cast<float4 *>(lds);            // [NSLOT][256]
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) part[i * 256 + tid] = rs[i];
@@ -40,7 +42,15 @@ __device__ __forceinline__ void rowsum_finish(const float4 (&rs)[NSLOT], float *
     if (tid < BM) {
         const int cg = tid >> 2, comp = tid & 3;
         float sum = 0.0f;
-        if (bf16_map) {          // LoaderMNt: group 4*ib + c lives in threads c + 4*kr + 16*ib + 16*NB*h (kr < 4, h < 16/NB)
+        if (bf16_map == 2) {     // wide LoaderMNth: group 4*ib + c' lives in slot c' & 1 of threads (c' >> 1) + 2*kr + 8*ib + 8*NB*h
+            constexpr int NB = BM / 16;
+            const int ib = cg >> 2, cp = cg & 3;
+            const float *src = lds + ((cp & 1) * 256 + (cp >> 1) + 8 * ib) * 4 + comp;
+#pragma unroll
+            for (int h = 0; h < 32 / NB; ++h)
+#pragma unroll
+                for (int kr = 0; kr < 4; ++kr) sum += src[(2 * kr + 8 * NB * h) * 4];
+        } else if (bf16_map == 1) {          // LoaderMNt: group 4*ib + c lives in threads c + 4*kr + 16*ib + 16*NB*h (kr < 4, h < 16/NB)
             constexpr int NB = BM / 16;
             const float *src = lds + ((cg & 3) + 16 * (cg >> 2)) * 4 + comp;
 #pragma unroll
@@ -172,7 +182,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, c
         __syncthreads();
         cur ^= 1;
     }
-    if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, false);
+    if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, 0);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -214,10 +224,10 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     if (kt0 >= kt1) return;
 
     // MN-contiguous: transpose-read image.  A16: the A operand is bf16 in memory (bf16 activation storage)
-    using LA = typename std::conditional<A16, typename std::conditional<AK, LoaderKh<BM>, LoaderMNth<BM>>::type,
+    using LA = typename std::conditional<A16, typename std::conditional<AK, LoaderKh<BM>, LoaderMNth<BM, true>>::type,
                                          typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type>::type;
     // B16: the B operand is already bf16 in memory (per-step weight shadow): half the bytes, no conversion
-    using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN>, LoaderMNth<BN>>::type,
+    using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN>, LoaderMNth<BN, true>>::type,
                                          typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
     constexpr int NRA = LA::NREG;
     constexpr int NRB = LB::NREG;
@@ -233,16 +243,20 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bool do_rs = !AK && g.rowsum != nullptr && tn == 0;      // workgroup-uniform
-    float4 rs[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
-    auto rs_add = [&](const typename LA::Reg (&r)[NRA]) {     // every register of a thread belongs to the column group 4*ib + c of its tid
+    constexpr int NRS = (!AK && A16) ? 2 : 1;      // wide bf16 loader: a thread's even / odd registers belong to two column groups
+    float4 rs[NRS];
+#pragma unroll
+    for (int i = 0; i < NRS; ++i) rs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto rs_add = [&](const typename LA::Reg (&r)[NRA]) {     // fp32: every register of a thread belongs to the column group 4*ib + c of its tid
         if constexpr (!AK && !A16) {
 #pragma unroll
             for (int i = 0; i < NRA; ++i) { rs[0].x += r[i].x; rs[0].y += r[i].y; rs[0].z += r[i].z; rs[0].w += r[i].w; }
         } else if constexpr (!AK && A16) {      // bf16 storage (LoaderMNth: the same unit map as LoaderMNt, 4 bf16 = 4 consecutive rows m)
 #pragma unroll
             for (int i = 0; i < NRA; ++i) {
-                rs[0].x += bf16_bits_to_f32(r[i].x & 0xFFFFu); rs[0].y += __builtin_bit_cast(float, r[i].x & 0xFFFF0000u);
-                rs[0].z += bf16_bits_to_f32(r[i].y & 0xFFFFu); rs[0].w += __builtin_bit_cast(float, r[i].y & 0xFFFF0000u);
+                float4 &t = rs[i & 1];
+                t.x += bf16_bits_to_f32(r[i].x & 0xFFFFu); t.y += __builtin_bit_cast(float, r[i].x & 0xFFFF0000u);
+                t.z += bf16_bits_to_f32(r[i].y & 0xFFFFu); t.w += __builtin_bit_cast(float, r[i].y & 0xFFFF0000u);
             }
         }
     };
@@ -294,7 +308,7 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
         if (kt < kt1) iter(kt, 0, ra0, rb0);
     }
     __syncthreads();
-    if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, true);
+    if (do_rs) rowsum_finish<BM, NRS>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, (!AK && A16) ? 2 : 1);
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -560,6 +574,10 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
               (!d->mask || (aligned16(d->mask) && d->ldmask % 4 == 0));
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
+    DETR_REQUIRE(!(bf16c && d->a_dtype == 1 && !ak) || (d->lda % 8 == 0 && d->M % 8 == 0 && aligned16(d->A)),
+                 "gemm: an M-contiguous bf16 A operand needs lda %% 8 == 0, M %% 8 == 0 and a 16-byte aligned base (16-byte requests)");
+    DETR_REQUIRE(!(bf16c && d->b_dtype == 1 && !bk) || (d->ldb % 8 == 0 && d->N % 8 == 0 && aligned16(d->B)),
+                 "gemm: an N-contiguous bf16 B operand needs ldb %% 8 == 0, N %% 8 == 0 and a 16-byte aligned base (16-byte requests)");
     const long long part = (long long)d->M * d->N;
     const bool partial = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace) &&
                          d->workspace_bytes >= (long long)split * (part + (d->rowsum_a ? d->M : 0)) * 4;
