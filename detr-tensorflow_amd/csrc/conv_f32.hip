@@ -657,14 +657,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    typedef typename std::conditional<S16, uint2, float4>::type Reg;     // 4 channels of one pixel
+    // S16: 16-byte granules (8 channels of one pixel; two adjacent 8-byte units of the transpose-read images) -- 5 requests
+    // and 5 ds_write_b128 per thread and unit instead of 9 + 9 eight-byte ones; fp32 storage: float4 = 4 channels
+    typedef typename std::conditional<S16, uint4, float4>::type Reg;
+    constexpr int NRX = S16 ? 4 : 7, NRD = S16 ? 1 : 2;
     // two register sets: the operand pipeline is two units deep (see gemm_bf16c_body); requests past u_end take the
     // out-of-range offset and every unit is stored, so that the vmcnt waits in front of the LDS stores stay exact
-    Reg rx0[7], rd0[2], rx1[7], rd1[2];
+    Reg rx0[NRX], rd0[NRD], rx1[NRX], rd1[NRD];
     // units are requested strictly in order (u_begin, +1, +2, ...): (chunk, output row, image) are running counters
     // instead of three divisions per unit
     int it_chunk = u_begin % chunks, it_ho = (u_begin / chunks) % a.Ho, it_n = (u_begin / chunks) / a.Ho;
-    auto load_unit = [&](int u, Reg (&rx)[7], Reg (&rd)[2]) {
+    auto load_unit = [&](int u, Reg (&rx)[NRX], Reg (&rd)[NRD]) {
         const bool live = u < u_end;
         const int ho = it_ho, n = it_n;
         const int wo0 = it_chunk * 32;
@@ -675,44 +678,44 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
                 ++it_n;
             }
         }
-        // dy tile: LoaderMNt<64> map (row = pixel j, col = co)
+        // dy tile: LoaderMNt<64> map (row = pixel j, col = co); S16: unit pairs (2 v, 2 v + 1) = 8 channels
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int v = tid + 256 * i;
+        for (int i = 0; i < NRD; ++i) {
+            const int v = S16 ? 2 * tid : tid + 256 * i;
             const int j = 4 * (v >> 6) + ((v >> 2) & 3);
             const int col = 16 * ((v >> 4) & 3) + 4 * (v & 3);
             const bool ok = live && wo0 + j < a.Wo;
             const unsigned off = ((unsigned)((n * a.Ho + ho) * a.Wo + wo0 + j) * (unsigned)a.Co + (unsigned)(co0 + col)) * (S16 ? 2u : 4u);
-            if constexpr (S16) rd[i] = ds.ld8(ok ? off : BUF_OOB);
+            if constexpr (S16) rd[i] = ds.ld16(ok ? off : BUF_OOB);
             else rd[i] = ds.ld4(ok ? off : BUF_OOB);
         }
-        // input patch: slot v -> (patch pixel pp = v / 16 in [0, 102), float4 c4 = v % 16 of the 64 channels)
+        // input patch: slot v -> (patch pixel pp in [0, 102), channel granule): S16 8 granules of 8 channels, fp32 16 of 4
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NRX; ++i) {
             const int v = tid + 256 * i;
-            const int pp = v >> 4, c4 = v & 15;
+            const int pp = S16 ? v >> 3 : v >> 4, c4 = S16 ? 2 * (v & 7) : v & 15;
             const int kh = pp / 34, c = pp - kh * 34;
             const int hi = ho - 1 + kh, wi = wo0 - 1 + c;
             const bool ok = live && pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
             const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * (S16 ? 2u : 4u);
-            if constexpr (S16) rx[i] = xs.ld8(ok ? off : BUF_OOB);
+            if constexpr (S16) rx[i] = xs.ld16(ok ? off : BUF_OOB);
             else rx[i] = xs.ld4(ok ? off : BUF_OOB);
         }
     };
-    auto store_unit = [&](int buf, const Reg (&rx)[7], const Reg (&rd)[2]) {
+    auto store_unit = [&](int buf, const Reg (&rx)[NRX], const Reg (&rd)[NRD]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (S16) *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = rd[i];
+        for (int i = 0; i < NRD; ++i) {
+            if constexpr (S16) *reinterpret_cast<uint4 *>(&sm.D[buf][tid * 8]) = rd[i];
             else *reinterpret_cast<uint2 *>(&sm.D[buf][(tid + 256 * i) * 4]) = make_uint2(pack_bf16(rd[i].x, rd[i].y), pack_bf16(rd[i].z, rd[i].w));
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NRX; ++i) {
             const int v = tid + 256 * i;
-            const int pp = v >> 4, c4 = v & 15;
+            const int pp = S16 ? v >> 3 : v >> 4, c4 = S16 ? 2 * (v & 7) : v & 15;
             if (pp < 102) {
                 const int kh = pp / 34, c = pp - kh * 34;
                 const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (c & 3) * 16 + (c4 & 3) * 4;
-                if constexpr (S16) *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = rx[i];
+                if constexpr (S16) *reinterpret_cast<uint4 *>(&sm.X[buf][o]) = rx[i];
                 else *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
             }
         }
@@ -741,9 +744,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
     load_unit(u_begin + 2, rx1, rd1);
     lds_barrier();
     // one unit: the set `rp` holds unit u+1 (stored now, then refilled with unit u+3); LDS buffer cur holds unit u
-    auto iter = [&](const int u, const int cur, Reg (&rpx)[7], Reg (&rpd)[2]) {
+    auto iter = [&](const int u, const int cur, Reg (&rpx)[NRX], Reg (&rpd)[NRD]) {
         if constexpr ((DETR_ABLATE & 4) == 0) store_unit(cur ^ 1, rpx, rpd);
-        else { for (int i = 0; i < 7; ++i) ablate_keep(rpx[i]); for (int i = 0; i < 2; ++i) ablate_keep(rpd[i]); }
+        else { for (int i = 0; i < NRX; ++i) ablate_keep(rpx[i]); for (int i = 0; i < NRD; ++i) ablate_keep(rpd[i]); }
         if constexpr ((DETR_ABLATE & 2) == 0) load_unit(u + 3, rpx, rpd);
         const unsigned short *X = sm.X[cur];
         const unsigned short *D = sm.D[cur];
