@@ -481,7 +481,14 @@ def test_model_surface_summary_layers_save_load(hip, small, capsys, tmp_path):
     for a, b in zip(model.trainable_variables, twin.trainable_variables):
         assert torch.equal(a, b)
     x = torch.from_numpy(small["images"]).cuda()
-    assert torch.equal(model(x)["pred_logits"], twin(x)["pred_logits"])
+    # (the shared model may replay an eval graph recorded by an earlier test, with training steps in between: this comparison
+    #  caught hipMemsetAsync nodes replaying stale fill patterns -- detr_hip_memset_zero is a kernel now)
+    a, b = model(x)["pred_logits"], twin(x)["pred_logits"]
+    model.eval_graph = False
+    c = model(x)["pred_logits"]
+    model.eval_graph = True
+    assert torch.equal(a, c), f"graph replay differs from the eager forward by {float((a - c).abs().max()):.3e}"
+    assert torch.equal(b, c), f"reloaded twin differs by {float((b - c).abs().max()):.3e}"
 
 
 def test_eval_forward_graph_replay_equals_eager(hip, small):
