@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--mode", choices=["train", "fwdloss"], default="train")
+    ap.add_argument("--backbone", choices=["resnet50", "resnet101"], default="resnet50", help="BASELINE config C4 uses resnet101 at 1000x1333")
+    ap.add_argument("--queries", type=int, default=100, help="object queries (BASELINE config C5: 300 with --batch 16)")
     ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 accumulation (config C3)")
@@ -236,7 +238,8 @@ def main():
     use_graph = not args.no_graph
 
     def build(precision):
-        m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=precision)
+        m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=precision,
+                           backbone=args.backbone, num_queries=args.queries)
         o = setup_optimizers(m, cfg)
         if world > 1 or dist.is_initialized():
             # identical replicas: broadcast rank 0's parameters, then all-reduce gradients every step
@@ -397,8 +400,9 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"DETR-R50 {'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
-                                   f"{args.height}x{args.width}, batch {args.batch}/GPU, 100 queries, 92 logits, 6+6 layers, dropout {args.dropout}",
+            "config": {"workload": f"DETR-{'R101' if args.backbone == 'resnet101' else 'R50'} "
+                                   f"{'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
+                                   f"{args.height}x{args.width}, batch {args.batch}/GPU, {args.queries} queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)",
                        "launch": "hipGraph replay" if (use_graph and args.mode == "train") else "eager"},
             "loss": round(loss_val, 5),
