@@ -119,6 +119,9 @@ struct BufSrc {
     __device__ __forceinline__ uint4 ld16(unsigned voff) const {      // 16 raw bytes (8 bf16)
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
     }
+    __device__ __forceinline__ uint4 ld16_nt(unsigned voff) const {   // 16 raw bytes of a read-once stream: non-temporal (aux = 2)
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2));
+    }
     __device__ __forceinline__ uint2 ld8(unsigned voff) const {       // 8 raw bytes (4 bf16)
         return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
     }

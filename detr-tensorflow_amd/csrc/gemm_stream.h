@@ -40,6 +40,21 @@ struct StreamArgs {
     int q;                                         // workgroups per (XCD, column slice); grid = 8 * n_tiles * q
 };
 
+// Cache policy of the epilogue streams.  The residual and the mask are read exactly once by this kernel and by nobody
+// after it, so they are requested non-temporal (bit 0): in the step that is -0.2 ms (20.07 -> 19.85 ms), e.g. M534400 N256
+// K64 +res+mask 166 -> 146 us, because they stop evicting the A rows the other slices of the workgroup are about to re-read.
+// The output stores stay temporal (bit 1 off): the next kernel reads C, and non-temporal stores measured +-0 here and
+// +0.02 ms on the consumers.
+#ifndef DETR_STREAM_NT
+#define DETR_STREAM_NT 1
+#endif
+__device__ __forceinline__ uint4 stream_ld_ep(const BufSrc &src, unsigned off) {
+#if DETR_STREAM_NT & 1
+    return src.ld16_nt(off);
+#else
+    return src.ld16(off);
+#endif
+}
 constexpr int STREAM_LD = 68;                      // floats per staged row (64 + 4): conflict-free b128 writes and reads
 
 // SL = column slices (64 columns each) a workgroup owns: its 4 waves are SL slice owners x 4 / SL row walkers, and the SL
@@ -132,8 +147,8 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             const int row = r0 + it * 8 + erow;
             const unsigned colb = (unsigned)((n0 + ecg * 8) * 2);
             const bool ep_live = (DETR_ABLATE & 32) == 0;               // ablation bit 5: no residual / mask requests
-            if (RES) rres[it] = srcR.ld16((ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
-            if (MASK) rmsk[it] = srcM.ld16((ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            if (RES) rres[it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
+            if (MASK) rmsk[it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -185,10 +200,16 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
             }
-            if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f))      // ablation bit 6: no output stores
-                *reinterpret_cast<uint4 *>(a.C + (long long)row * a.ldc + n0 + ecg * 8) =
-                    make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]),
-                               f32_to_bf16_pair(v[6], v[7]));
+            if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f)) {    // ablation bit 6: no output stores
+                typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v ov = {f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7])};
+                u32x4v *dstp = reinterpret_cast<u32x4v *>(a.C + (long long)row * a.ldc + n0 + ecg * 8);
+#if DETR_STREAM_NT & 2
+                __builtin_nontemporal_store(ov, dstp);
+#else
+                *dstp = ov;
+#endif
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
