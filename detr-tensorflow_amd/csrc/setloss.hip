@@ -10,6 +10,7 @@
 // Compiled with -ffp-contract=off so that the box arithmetic rounds like the op-by-op reference.
 #include "common.h"
 #include <limits.h>
+#include <type_traits>
 
 namespace detr {
 
@@ -115,44 +116,92 @@ __global__ __launch_bounds__(256) void match_cost_kernel(SetLossArgs a, float *_
 // 16 lanes, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63 (the gfx9 wave64
 // reduction idiom); ~20 VALU ops instead of 12 dependent ds_bpermute round trips.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_min_step(double x) {
-    const double inf = (double)INFINITY;
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(inf), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(inf), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+__device__ __forceinline__ double dpp_min_step(double x, int &tlo, int &thi) {
+    // lanes this stage does not write (no DPP source, or outside ROW_MASK) keep what an earlier stage left in (thi, tlo):
+    // an older partial minimum of genuine elements, harmless for a minimum -- so no re-initialisation with +inf per stage
+    tlo = __builtin_amdgcn_update_dpp(tlo, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    thi = __builtin_amdgcn_update_dpp(thi, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
     // raw v_min_f64: the operands are never NaN here (the cost matrix is screened, +inf - finite stays +inf), so
     // the two v_max_f64 canonicalisations fmin() would add to every step of the dependent chain are dead weight
-    const double y = __hiloint2double(hi, lo);
+    const double y = __hiloint2double(thi, tlo);
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
 __device__ __forceinline__ double wave_min_f64_dpp(double x) {
-    x = dpp_min_step<0x111, 0xf>(x);   // row_shr:1
-    x = dpp_min_step<0x112, 0xf>(x);   // row_shr:2
-    x = dpp_min_step<0x114, 0xf>(x);   // row_shr:4
-    x = dpp_min_step<0x118, 0xf>(x);   // row_shr:8
-    x = dpp_min_step<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
-    x = dpp_min_step<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    int tlo = __double2loint(x), thi = __double2hiint(x);
+    x = dpp_min_step<0x111, 0xf>(x, tlo, thi);   // row_shr:1
+    x = dpp_min_step<0x112, 0xf>(x, tlo, thi);   // row_shr:2
+    x = dpp_min_step<0x114, 0xf>(x, tlo, thi);   // row_shr:4
+    x = dpp_min_step<0x118, 0xf>(x, tlo, thi);   // row_shr:8
+    x = dpp_min_step<0x142, 0xa>(x, tlo, thi);   // row_bcast:15 into rows 1 and 3
+    x = dpp_min_step<0x143, 0xc>(x, tlo, thi);   // row_bcast:31 into rows 2 and 3
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
     return __hiloint2double(hi, lo);
 }
 
-template <int MAXCPL>
+// CD: the transposed cost tile is held in LDS as doubles (Q <= 128: 99 x 129 x 8 B = 102 KB), which takes the
+// float -> double conversion out of every row scan.
+//
+// Shape of the search (LAPJV's SCAN / TODO form of the Dijkstra, same labels as SciPy's loop): a wave-wide minimum is
+// only taken when the set of live columns whose label EQUALS the current minimum (`todo`) is empty.  Measured with
+// s_memtime (DETR_ASSIGN_PROF builds, scripts/experiments/assign_probe.py) on the 99-target problems of the bench step:
+// the loop is bound by the latency of ONE wave's dependent instructions, ~880 cycles per scanned row when every row scan
+// is followed by a minimum + owner selection (6 DPP stages of 64-bit moves and v_min_f64, then ballots, v_readlane and the
+// SALU <-> VALU round trips between them), of which the row scan itself is ~100.  About half of all scanned columns are
+// exact ties with the current minimum (tight edges: reduced cost 0), so they are scanned straight from `todo` without
+// a reduction.  The column sets (live, todo, free) are wave-uniform 64-bit masks (one SGPR pair per slot), used directly
+// as lane conditions and picked from with s_ff1.
+// next column to scan: the lowest of the lowest non-empty slot of `todo` (any order is a valid Dijkstra order: all of them
+// carry the final label minVal).  One branch per slot, constant slot index inside it (no selects between SGPR pairs).
+template <int S, int N>
+struct AssignPick {
+    static __device__ __forceinline__ void run(unsigned long long (&todo)[N], unsigned long long (&live)[N],
+                                               const unsigned long long (&freecol)[N], const int (&row4col)[N], int &jstar,
+                                               int &r4, bool &isfree) {
+        if (S + 1 == N || todo[S]) {
+            const int l = ((int)__ffsll((long long)todo[S]) - 1) & 63;
+            const unsigned long long bit = 1ull << l;
+            todo[S] &= ~bit;
+            live[S] &= ~bit;
+            isfree = (freecol[S] & bit) != 0ull;
+            r4 = __builtin_amdgcn_readlane(row4col[S], l);
+            jstar = 64 * S + l;
+        } else {
+            AssignPick<(S + 1 < N ? S + 1 : S), N>::run(todo, live, freecol, row4col, jstar, r4, isfree);
+        }
+    }
+};
+
+#ifndef DETR_ASSIGN_PROF
+#define DETR_ASSIGN_PROF 0       // 1: s_memtime segment counters of the step loop, written over pred_for_tgt[0..15] (probe builds only)
+#endif
+#if DETR_ASSIGN_PROF
+#define ASSIGN_TICK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_last; prof_last = t_; } while (0)
+#else
+#define ASSIGN_TICK(k) do { } while (0)
+#endif
+template <int MAXCPL, bool CD>
 __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ cost, int Q, int ldc,
                                                     const float *__restrict__ t_bbox, int B, int R,
                                                     int *__restrict__ tgt_for_pred, int *__restrict__ pred_for_tgt,
                                                     int *__restrict__ status) {
+    using CT = typename std::conditional<CD, double, float>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int p = blockIdx.x, b = p % B, lane = threadIdx.x;
     const int nmax = (R + 1) & ~1;
     const int n = header_n(t_bbox, b, R);
     const int cpl = (Q + 63) >> 6;
-    const int Qs = cpl * 64 + 1;        // row stride of the transposed cost (odd: the column-wise staging writes spread
-                                        // over the banks); slot s of lane l sits at 64*s + l
-    double *u = reinterpret_cast<double *>(smem);
-    int *col4row = reinterpret_cast<int *>(u + nmax);
-    float *cT = reinterpret_cast<float *>(col4row + nmax);
+    const int Qs = CD ? MAXCPL * 64 + 1 : cpl * 64 + 1;   // row stride of the transposed cost (odd: the column-wise staging
+                                        // writes spread over the banks); slot s of lane l sits at 64*s + l
+    double *u0 = reinterpret_cast<double *>(smem);
+    int *col4row = reinterpret_cast<int *>(u0 + nmax);
+    CT *cT = reinterpret_cast<CT *>(col4row + nmax);
+    // CD: the row dual u[i] lives in the padding element at the end of cost row i, so one row scan addresses its three
+    // LDS reads from one base with immediate offsets
+    double *u = CD ? reinterpret_cast<double *>(cT) + (Qs - 1) : u0;
+    const int us = CD ? Qs : 1;
 
     for (int q = lane; q < Q; q += 64) tgt_for_pred[(long long)p * Q + q] = -1;
     for (int j = lane; j < ldc; j += 64) pred_for_tgt[(long long)p * ldc + j] = -1;
@@ -167,13 +216,14 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
     for (int idx = lane; idx < Q * n; idx += 64) {
         const int q = idx / n, j = idx - q * n;
         const float c = Cg[q * ldc + j];
-        cT[j * Qs + q] = c;
+        cT[j * Qs + q] = (CT)c;
         bad |= !(c == c) || (c == -INFINITY);
     }
-    if (Qs > Q)
-        for (int idx = lane; idx < (Qs - Q) * n; idx += 64) cT[(idx / (Qs - Q)) * Qs + Q + idx % (Qs - Q)] = 0.0f;
+    if (Qs > Q)                          // columns that do not exist cost +inf: their labels stay +inf without a lane test
+        for (int idx = lane; idx < (Qs - Q) * n; idx += 64) cT[(idx / (Qs - Q)) * Qs + Q + idx % (Qs - Q)] = (CT)INFINITY;
+    __syncthreads();
     for (int i = lane; i < n; i += 64) {
-        u[i] = 0.0;
+        u[i * us] = 0.0;
         col4row[i] = -1;
     }
     __syncthreads();
@@ -183,19 +233,24 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
     }
     double v[MAXCPL], spc[MAXCPL];
     int path[MAXCPL], row4col[MAXCPL];
+    unsigned long long exist[MAXCPL];   // wave-uniform: lanes whose column lane + 64 s exists
+    unsigned long long freecol[MAXCPL]; // wave-uniform: existing columns no row is matched to
 #pragma unroll
     for (int s = 0; s < MAXCPL; ++s) {
         v[s] = 0.0;
         spc[s] = INFINITY;
         path[s] = -1;
         row4col[s] = -1;
+        const int cnt = Q - 64 * s;
+        exist[s] = cnt >= 64 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));
+        freecol[s] = exist[s];
     }
     // Row-reduction start (the classic JV initialisation; SciPy starts from all-zero duals): u[i] = min_j c[i][j] keeps
     // every reduced cost >= 0 with v = 0, and a row whose minimum column is still free is matched to it at reduced
     // cost 0.  About two thirds of the rows of a 99 x 100 problem are settled here; the shortest-augmenting-path
     // phase below only runs for the rest.  The optimum (cost) is unchanged; tie-breaking may differ from SciPy's.
     for (int i = 0; i < n; ++i) {
-        const float *crow = cT + i * Qs;
+        const CT *crow = cT + i * Qs;
         double best = INFINITY;
         int bestj = INT_MAX;
 #pragma unroll
@@ -217,82 +272,100 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
         for (int s = 0; s < MAXCPL; ++s)
             if (s == owns) r4 = row4col[s];
         r4 = __builtin_amdgcn_readlane(r4, ownl);
-        if (lane == 0) u[i] = gmin;
+        if (lane == 0) u[i * us] = gmin;
         if (r4 == -1) {
 #pragma unroll
-            for (int s = 0; s < MAXCPL; ++s)
+            for (int s = 0; s < MAXCPL; ++s) {
                 if (s == owns && lane == ownl) row4col[s] = i;
+                if (s == owns) freecol[s] &= ~(1ull << ownl);
+            }
             if (lane == 0) col4row[i] = jstar;
         }
     }
     __syncthreads();
+#if DETR_ASSIGN_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_readcyclecounter();
+    const unsigned long long prof_t0 = prof_last;
+#endif
     bool infeasible = false;
     for (int cur = 0; cur < n; ++cur) {
         if (col4row[cur] != -1) continue;                  // matched by the row-reduction start
+        ASSIGN_TICK(5);
         double minVal = 0.0;
         int i = cur;
-        unsigned scmask = 0;
         int sink = -1;
+        unsigned long long live[MAXCPL], todo[MAXCPL];     // wave-uniform: existing columns not yet scanned; live columns
+                                                           // whose label equals minVal
 #pragma unroll
-        for (int s = 0; s < MAXCPL; ++s) spc[s] = INFINITY;
+        for (int s = 0; s < MAXCPL; ++s) {
+            spc[s] = INFINITY;
+            live[s] = exist[s];
+            todo[s] = 0ull;
+        }
         while (true) {
-            // One Dijkstra step, straight-line: both LDS reads (u[i] and the cost row, one float per slot) are issued
-            // together, the per-slot relaxations are selects, and the only branches are the two loop exits.
-            const double ui = u[i];
-            const float *crow = cT + i * Qs + lane;
-            float cf[MAXCPL];
+            ASSIGN_TICK(0);
+            // scan row i: both LDS reads (u[i] and one cost per slot) are issued together, the relaxations are selects;
+            // a column whose new label equals minVal (reduced cost 0) joins `todo`
+            const double ui = u[i * us];
+            const CT *crow = cT + i * Qs + lane;
+            CT cf[MAXCPL];
 #pragma unroll
-            for (int s = 0; s < MAXCPL; ++s) cf[s] = crow[64 * (s < cpl ? s : cpl - 1)];
-            double best = INFINITY;
-            int bestj = INT_MAX, bestr4 = 0;
+            for (int s = 0; s < MAXCPL; ++s) cf[s] = crow[CD ? 64 * s : 64 * (s < cpl ? s : cpl - 1)];
+            unsigned long long any_todo = 0ull;
 #pragma unroll
             for (int s = 0; s < MAXCPL; ++s) {
-                const int j = lane + 64 * s;
-                const bool valid = (j < Q) & !((scmask >> s) & 1u);
                 const double r = minVal + (double)cf[s] - ui - v[s];
-                const bool upd = valid & (r < spc[s]);
+                const unsigned long long um = __builtin_amdgcn_ballot_w64(r < spc[s]) & live[s];
+                const bool upd = __builtin_amdgcn_inverse_ballot_w64(um);
                 spc[s] = upd ? r : spc[s];
                 path[s] = upd ? i : path[s];
-                const bool fr = row4col[s] == -1, bfr = bestr4 == -1;
-                const bool take = valid & ((spc[s] < best) | ((spc[s] == best) & ((fr & !bfr) | ((fr == bfr) & (j < bestj)))));
-                best = take ? spc[s] : best;
-                bestj = take ? j : bestj;
-                bestr4 = take ? row4col[s] : bestr4;
+                todo[s] |= __builtin_amdgcn_ballot_w64(r == minVal) & um;
+                any_todo |= todo[s];
             }
-            // wave argmin: DPP min of the value, then a ballot picks the owner lane (free columns
-            // first, as SciPy's tie rule prefers a column that ends the search)
-            const double gmin = wave_min_f64_dpp(best);
-            minVal = gmin;
-            if (!(minVal < (double)INFINITY)) {
-                infeasible = true;
-                break;
+            ASSIGN_TICK(1);
+            if (any_todo == 0ull) {
+                // new level: exact minimum of the live labels, every live column that attains it goes to `todo`
+                double best = INFINITY;
+#pragma unroll
+                for (int s = 0; s < MAXCPL; ++s) {
+                    const bool lv = __builtin_amdgcn_inverse_ballot_w64(live[s]);
+                    const double c = lv ? spc[s] : (double)INFINITY;
+                    asm("v_min_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(c));
+                }
+                minVal = wave_min_f64_dpp(best);
+                // +inf (nothing reachable): scalar test on the high word; the pick below is void then and the loop ends
+                infeasible = (__double2hiint(minVal) & 0x7FFFFFFF) >= 0x7FF00000;
+#pragma unroll
+                for (int s = 0; s < MAXCPL; ++s) todo[s] = __builtin_amdgcn_ballot_w64(spc[s] == minVal) & live[s];
             }
-            const bool cand = (best == gmin);
-            const unsigned long long mfree = __ballot(cand & (bestr4 == -1));
-            const unsigned long long mall = __ballot(cand);
-            const int ownl = __ffsll((long long)(mfree ? mfree : mall)) - 1;
-            const int jstar = __builtin_amdgcn_readlane(bestj, ownl);
-            const int r4 = __builtin_amdgcn_readlane(bestr4, ownl);
-            if (lane == ownl) scmask |= 1u << (jstar >> 6);
-            if (r4 == -1) {
+            ASSIGN_TICK(2);
+            int jstar = 0, r4 = 0;
+            bool isfree = false;
+            AssignPick<0, MAXCPL>::run(todo, live, freecol, row4col, jstar, r4, isfree);
+            if (isfree | infeasible) {
                 sink = jstar;
                 break;
             }
             i = r4;
+            ASSIGN_TICK(3);
         }
         if (infeasible) break;
+        ASSIGN_TICK(4);
         // dual update (before the augmentation, with the old matching)
-        if (lane == 0) u[cur] += minVal;
+        if (lane == 0) u[cur * us] += minVal;
 #pragma unroll
         for (int s = 0; s < MAXCPL; ++s) {
-            if ((scmask >> s) & 1u) {
+            if (__builtin_amdgcn_inverse_ballot_w64(exist[s] & ~live[s])) {
                 const double d = minVal - spc[s];
                 v[s] -= d;
-                if (row4col[s] != -1) u[row4col[s]] += d;
+                if (row4col[s] != -1) u[row4col[s] * us] += d;
             }
         }
         __syncthreads();
         // augment along the alternating path that ends in `sink`
+#pragma unroll
+        for (int s = 0; s < MAXCPL; ++s)
+            if (s == (sink >> 6)) freecol[s] &= ~(1ull << (sink & 63));
         int j = sink;
         while (true) {
             const int ownl = j & 63, owns = j >> 6;
@@ -322,6 +395,13 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
         pred_for_tgt[(long long)p * ldc + i] = q;
         if (q >= 0) tgt_for_pred[(long long)p * Q + q] = i;
     }
+#if DETR_ASSIGN_PROF
+    __syncthreads();
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) pred_for_tgt[(long long)p * ldc + k] = (int)prof_acc[k];
+        pred_for_tgt[(long long)p * ldc + 6] = (int)(__builtin_readcyclecounter() - prof_t0);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,22 +618,25 @@ extern "C" int detr_hip_assign_f32(const float *cost, int32_t P, int32_t Q, int3
     DETR_REQUIRE(P > 0 && Q > 0 && Q <= SL_MAXQ && R > 1 && R <= SL_MAXR && ldc >= R - 1 && B > 0 && P % B == 0,
                  "assign: bad shape P=%d Q=%d ldc=%d B=%d R=%d", P, Q, ldc, B, R);
     const int nmax = (R + 1) & ~1;
-    const size_t smem = (size_t)nmax * 8 + (size_t)nmax * 4 + (size_t)(R - 1) * (size_t)((Q + 63) / 64 * 64 + 1) * 4;
+    const bool cd = Q <= 128 && (size_t)nmax * 12 + (size_t)(R - 1) * 129 * 8 <= 150 * 1024;   // cost tile as doubles, row stride 129
+    const size_t tile = (size_t)(R - 1) * (size_t)(cd ? 129 : (Q + 63) / 64 * 64 + 1);
+    const size_t smem = (size_t)nmax * 8 + (size_t)nmax * 4 + tile * (cd ? 8 : 4);
     hipStream_t s = (hipStream_t)stream;
     const int cpl = (Q + 63) / 64;
-#define DETR_ASSIGN_LAUNCH(MC)                                                                                       \
+#define DETR_ASSIGN_LAUNCH(MC, CD)                                                                                   \
     do {                                                                                                             \
         if (smem > 48 * 1024) {                                                                                      \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assign_kernel<MC>),                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(assign_kernel<MC, CD>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);               \
             DETR_REQUIRE(e == hipSuccess, "assign: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e)); \
         }                                                                                                            \
-        hipLaunchKernelGGL((assign_kernel<MC>), dim3(P), dim3(64), smem, s, cost, Q, ldc, t_bbox, B, R, tgt_for_pred, \
-                           pred_for_tgt, status);                                                                    \
+        hipLaunchKernelGGL((assign_kernel<MC, CD>), dim3(P), dim3(64), smem, s, cost, Q, ldc, t_bbox, B, R,          \
+                           tgt_for_pred, pred_for_tgt, status);                                                      \
     } while (0)
-    if (cpl <= 2) DETR_ASSIGN_LAUNCH(2);
-    else if (cpl <= 5) DETR_ASSIGN_LAUNCH(5);
-    else DETR_ASSIGN_LAUNCH(8);
+    if (cpl <= 2 && cd) DETR_ASSIGN_LAUNCH(2, true);
+    else if (cpl <= 2) DETR_ASSIGN_LAUNCH(2, false);
+    else if (cpl <= 5) DETR_ASSIGN_LAUNCH(5, false);
+    else DETR_ASSIGN_LAUNCH(8, false);
 #undef DETR_ASSIGN_LAUNCH
     DETR_LAUNCH_CHECK("assign");
     return 0;
