@@ -37,6 +37,7 @@ ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
 # bf16 STORAGE of the FFN hidden activation in precision="bf16" (bit-identical: it only feeds GEMM operands; DETR_HIP_H16=0 = fp32)
 H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
 DEFER_REDUCE = os.environ.get("DETR_HIP_DEFER_REDUCE", "1") != "0"     # queue the weight gradients' split-K reductions (A/B switch)
+WGRAD_STREAM = os.environ.get("DETR_HIP_WGRAD_STREAM", "1") != "0"      # backbone weight gradients on a second HIP stream (A/B switch)
 
 
 def mix32(x):
@@ -734,8 +735,55 @@ class DetrEngine:
                 hip.call("detr_hip_colsum_scaled", dz.data_ptr(), 1 if dz.dtype == torch.bfloat16 else 0, rows, cols, cols,
                          self.bn_scale[bn].data_ptr(), G[f"{conv}/bias"].data_ptr())
 
+        # Weight gradients of a block do not feed the data-gradient chain (g -> dz2 -> dz1 -> gx): with WGRAD_STREAM they are
+        # issued on a second stream, each behind an event of the main stream that follows its producer, so a chip-filling
+        # but HBM-bound data-gradient GEMM and an MFMA/LDS-bound weight gradient share the CUs (inside the captured graph the
+        # fork / join events become plain graph edges).  The scratch tensors the side stream reads (dz2, dz1: double-buffered
+        # by block parity; gx) are only overwritten after the side work that read them has been waited for.
+        ws_on = WGRAD_STREAM and feat.is_cuda
+        main = torch.cuda.current_stream() if ws_on else None
+        if ws_on and getattr(self, "_wg_stream", None) is None:
+            self._wg_stream = torch.cuda.Stream(device=feat.device)
+        wside = self._wg_stream if ws_on else None
+        side_done = {}
+
+        def on_side(fn):
+            if not ws_on:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            wside.wait_event(ev)
+            with torch.cuda.stream(wside):
+                fn()
+
+        def side_mark(bi):
+            if ws_on:
+                ev = torch.cuda.Event()
+                ev.record(wside)
+                side_done[bi] = ev
+
+        def side_wait(bi):
+            ev = side_done.pop(bi, None)
+            if ev is not None:
+                main.wait_event(ev)
+
+        def side_join():
+            if ws_on:
+                main.wait_stream(wside)
+                side_done.clear()
+
+        if ws_on and on_bucket:
+            _ob = on_bucket
+
+            def on_bucket(i, _ob=_ob):
+                side_join()                 # (also required before a graph segment is cut)
+                _ob(i)
+
         for bi in reversed(range(n_blocks)):
             m = self._block_meta[bi]
+            side_wait(bi + 2)
+            par = f":{bi & 1}" if ws_on else ""
             p, n, x, xs, x1, y1, y2 = m["p"], m["n"], m["x"], m["xs"], m["x1"], m["y1"], m["y2"]
             h, w, ho, wo, cin, d1, d2, stride = m["h"], m["w"], m["ho"], m["wo"], m["cin"], m["d1"], m["d2"], m["stride"]
             h1, w1, M1, s2 = m["h1"], m["w1"], m["M1"], m["s2"]
@@ -745,26 +793,37 @@ class DetrEngine:
             ws2 = self._bufs[f"{wk}:{n['conv2']}/kernel"]
             ws3 = self._bufs[f"{wk}:{n['conv3']}/kernel"]
             # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
-            self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
-            bias_grad(n["conv3"], n["bn3"], g, M_out, d2)
-            dz2 = self.buf(f"scratch:dz2:{d1}:{ho}", (B, ho, wo, d1), adt)
+            def wg3(g=g):
+                self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
+                bias_grad(n["conv3"], n["bn3"], g, M_out, d2)
+                if m["first"]:
+                    self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{n['down']}/kernel"], d2, scale=self.bn_scale[n["bnd"]])
+                    bias_grad(n["down"], n["bnd"], g, M_out, d2)
+            on_side(wg3)
+            dz2 = self.buf(f"scratch:dz2:{d1}:{ho}{par}", (B, ho, wo, d1), adt)
             hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
             # conv2 (3x3)
-            hip.conv3x3(2, y1, dz2, G[f"{n['conv2']}/kernel"], B, h1, w1, d1, ho, wo, d1, s2, scale=self.bn_scale[n["bn2"]])
-            bias_grad(n["conv2"], n["bn2"], dz2, M_out, d1)
-            dz1 = self.buf(f"scratch:dz1:{d1}:{h1}", (B, h1, w1, d1), adt)
+
+            def wg2():
+                hip.conv3x3(2, y1, dz2, G[f"{n['conv2']}/kernel"], B, h1, w1, d1, ho, wo, d1, s2, scale=self.bn_scale[n["bn2"]])
+                bias_grad(n["conv2"], n["bn2"], dz2, M_out, d1)
+            on_side(wg2)
+            dz1 = self.buf(f"scratch:dz1:{d1}:{h1}{par}", (B, h1, w1, d1), adt)
             hip.conv3x3(1, dz2, ws2, dz1, B, h1, w1, d1, ho, wo, d1, s2, mask=y1)
             # conv1
-            self._wgrad(cin, d1, M1, x1, cin, dz1, d1, G[f"{n['conv1']}/kernel"], d1, scale=self.bn_scale[n["bn1"]])
-            bias_grad(n["conv1"], n["bn1"], dz1, M1, d1)
+
+            def wg1():
+                self._wgrad(cin, d1, M1, x1, cin, dz1, d1, G[f"{n['conv1']}/kernel"], d1, scale=self.bn_scale[n["bn1"]])
+                bias_grad(n["conv1"], n["bn1"], dz1, M1, d1)
+            on_side(wg1)
+            side_mark(bi)
+            side_wait(bi + 1)               # gx of this parity was read (as g) by the side work of block bi + 1
             is_first_block = bi == 0
             gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin), adt)
             mask = None if is_first_block else x           # x = ReLU output of the previous block
             strided = m["first"] and stride == 2
             if m["first"]:
                 wsd = self._bufs[f"{wk}:{n['down']}/kernel"]
-                self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{n['down']}/kernel"], d2, scale=self.bn_scale[n["bnd"]])
-                bias_grad(n["down"], n["bnd"], g, M_out, d2)
             if tfb and strided:
                 # both branches read the subsampled input: d_xs = g @ Wd^T + dz1 @ W1^T (ReLU-masked at the sampled pixels),
                 # scattered back into the zero-filled full-resolution gradient
@@ -792,6 +851,7 @@ class DetrEngine:
                     on_bucket(1)
                 elif p == block_names(2, 0, tfb)["tag"]:
                     on_bucket(2)
+        side_join()
         # ---------------- stem ----------------
         stem, pool, amax = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax"))
         H1, W1 = stem.shape[1], stem.shape[2]
