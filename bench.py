@@ -12,7 +12,8 @@ as first-class fields (`fp32`).
 
 Prints ONE JSON line on rank 0:
   value / ms_per_step   K timed steps (barrier + synchronize on both sides, max over ranks).  The step is what training.fit
-                        runs: recorded once as a hipGraph and replayed (--no-graph: eager launches); the last
+                        runs, launched either as a recorded hipGraph (replayed) or eagerly on two HIP streams: --launch
+                        auto (default) times both inside the warm-up and keeps the faster (config.launch says which); the last
                         --event-steps timed steps run eagerly with HIP events around every GEMM / conv / attention launch.
   roofline              the dominant kernel family by total time, from those events (on the launch stream).
   step_roofline         SURVEY 8d's mixed roofline: sum over the instrumented launches of max(FLOPs / MFMA peak, bytes / HBM peak)
@@ -194,8 +195,11 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-parity-mode steps of a bf16 run")
     ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 measurements")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (default: the step is recorded once as a "
-                                                           "hipGraph and replayed, exactly as training.fit does)")
+    ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
+                    help="how a step reaches the GPU: graph = recorded once as hipGraph(s) and replayed (training.GraphedTrainStep), "
+                         "eager = one launch call per kernel on two HIP streams (training.train_step); auto (default) times "
+                         "3 steps of each inside the warm-up and keeps the faster one -- which one wins depends on the host")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--dist-backend", type=str, default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps (the last ones) whose launches carry HIP events")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
@@ -211,6 +215,7 @@ def main():
         raise SystemExit(subprocess.call(cmd))
 
     from detr_tf import _hip, parallel, training
+    from detr_tf import engine as engine_mod
     from detr_tf.inference import get_model_inference
     from detr_tf.loss.loss import get_losses
     from detr_tf.networks.detr import get_detr_model
@@ -235,7 +240,11 @@ def main():
     cfg.batch_size = args.batch
     cfg.target_batch = None
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
-    use_graph = not args.no_graph
+    if args.no_graph:
+        args.launch = "eager"
+    use_graph = args.launch != "eager"          # (auto: the recorded step exists, the choice is made after the warm-up)
+    launch = {"graph": use_graph, "probe": None}
+    wgrad_stream_default = engine_mod.WGRAD_STREAM
 
     def build(precision):
         m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=precision,
@@ -256,9 +265,12 @@ def main():
     tb, tc = torch.from_numpy(tb).to(dev), torch.from_numpy(tc).to(dev)
     model, opt, stepper = build(args.precision)
 
-    def step(i):
+    def step(i, single=False):
+        # HIP events around single launches: that step runs on ONE stream, so that a kernel's duration is its own (on two
+        # streams the events of co-running kernels overlap and every duration is stretched by its neighbour)
+        engine_mod.WGRAD_STREAM = wgrad_stream_default and _hip.PROFILER is None and not single
         if args.mode == "train":
-            if stepper is not None and _hip.PROFILER is None:      # (HIP events around single launches need the eager step)
+            if stepper is not None and launch["graph"] and _hip.PROFILER is None and not single:   # (HIP events around single launches need the eager step)
                 return stepper(images, tb, tc, i)[1]
             return training.train_step(model, images, tb, tc, opt, cfg, i)[1]
         out = model(images, training=False)
@@ -278,10 +290,27 @@ def main():
         return time.perf_counter() - t, last
 
     loss_first = None
+    if args.mode == "train" and not args.no_kernel_events:
+        loss_first = step(0, single=True).clone()   # (also allocates the single-stream scratch tensors of the event-instrumented step)
     for i in range(max(args.warmup, 2 if use_graph else 1)):     # graph mode: one eager step, then the recording pass
         last = step(i)
-        if i == 0:
+        if i == 0 and loss_first is None:
             loss_first = last.clone()      # device scalar: read after the timed region
+    if args.launch == "auto" and args.mode == "train":
+        # both launch paths are the product's (training.fit takes either); the recorded step wins when the host is slow or
+        # shared, the eager two-stream step when it is not (hipGraph replay serialises most of the second stream's work)
+        step(0)                                 # (the warm-up above ran the eager step and the recording pass)
+        tg, _ = timed(3)
+        launch["graph"] = False
+        step(0)
+        te, _ = timed(3)
+        tt = torch.tensor([tg, te], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tg, te = (float(v) for v in tt.tolist())
+        launch["graph"] = tg <= te
+        launch["probe"] = {"graph_ms": round(tg / 3 * 1e3, 3), "eager_ms": round(te / 3 * 1e3, 3)}
+        step(0)
     # HIP events around every GEMM / conv / attention launch (roofline leg) cost ~4 us of host time per event, so they are
     # recorded in the LAST `event_steps` timed steps only (which run eagerly); the other timed steps run uninstrumented.
     prof = None
@@ -404,7 +433,9 @@ def main():
                                    f"{'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, {args.queries} queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)",
-                       "launch": "hipGraph replay" if (use_graph and args.mode == "train") else "eager"},
+                       "launch": ("hipGraph replay" if (launch["graph"] and args.mode == "train") else "eager, 2 HIP streams")
+                                 + (f" (auto: graph {launch['probe']['graph_ms']} ms vs eager {launch['probe']['eager_ms']} ms per step)"
+                                    if launch["probe"] else "")},
             "loss": round(loss_val, 5),
             "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
             "fp32": fp32,

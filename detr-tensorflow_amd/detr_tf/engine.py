@@ -250,6 +250,38 @@ class DetrEngine:
         hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2,
                           y16=y16)
 
+    # ---- second stream for the weight gradients ---------------------------------------------------------------------
+    # A weight gradient feeds nothing but the bucket exchange / the optimiser, so with WGRAD_STREAM it is issued on a second
+    # HIP stream behind an event of the main stream that follows its producer (a graph edge when the step is captured) and
+    # shares the chip with the data-gradient chain: the decoder's 800-row kernels fill a fifth of the CUs, the backbone's
+    # HBM-bound data-gradient GEMMs leave the MFMA pipes idle.  The tensors such a launch reads are never rewritten within
+    # the same backward (_sx: one scratch tensor per site instead of one per shape), so the only joins are in front of a
+    # reduction flush, a bucket hand-over and the end of the backward.
+    def _side_begin(self, on):
+        self._side_on = bool(on)
+        if self._side_on:
+            self._side_main = torch.cuda.current_stream()
+            if getattr(self, "_wg_stream", None) is None:
+                self._wg_stream = torch.cuda.Stream(device=self._side_main.device)
+
+    def _side(self, fn):
+        if not getattr(self, "_side_on", False):
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(self._side_main)
+        self._wg_stream.wait_event(ev)
+        with torch.cuda.stream(self._wg_stream):
+            fn()
+
+    def _side_join(self):
+        if getattr(self, "_side_on", False):
+            self._side_main.wait_stream(self._wg_stream)
+
+    def _sx(self, site):
+        """Suffix that makes a scratch tensor private to one site while the second stream is in use."""
+        return f":{site}" if getattr(self, "_side_on", False) else ""
+
     def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None, want16=False):
         """Backward of _ln_fwd w.r.t. x (+ dx_add).  drop_site: also return dropout_bwd(dx) -- the gradient through the
         Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the same launch.
@@ -258,9 +290,9 @@ class DetrEngine:
         dx_drop = dx_drop16 = None
         if drop_site is not None:
             if want16:
-                dx_drop16 = self.buf(f"scratch:drop16:{dx.shape[0]}", dx.shape, torch.bfloat16)
+                dx_drop16 = self.buf(f"scratch:drop16:{dx.shape[0]}{self._sx(tag)}", dx.shape, torch.bfloat16)
             elif dp > 0.0:
-                dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}", dx.shape)
+                dx_drop = self.buf(f"scratch:drop:{dx.shape[0]}{self._sx(tag)}", dx.shape)
         hip.layernorm_bwd(dy, x, self.P.views[f"{pfx}/gamma"], self._bufs[f"{tag}:mean"], self._bufs[f"{tag}:rstd"], dx,
                           self.P.gviews[f"{pfx}/gamma"], self.P.gviews[f"{pfx}/beta"], dx_add=dx_add, dx_drop=dx_drop,
                           dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev, dx_drop16=dx_drop16,
@@ -301,16 +333,17 @@ class DetrEngine:
         QKV, O = self._bufs[f"{tag}:QKV"], self._bufs[f"{tag}:O"]
         dO = self.buf(f"scratch:dO:{B * T}", (B * T, D))
         hip.linear_dgrad(d_out, self._w(f"{pfx}/out_proj_kernel"), dO)
-        dQKV = self.buf(f"scratch:dQKV:{B * T}", (B * T, 3 * D))
+        dQKV = self.buf(f"scratch:dQKV:{B * T}{self._sx(tag)}", (B * T, 3 * D))
         delta = self.buf(f"scratch:delta:{B * T}", (B * HEADS, T))
         dp, _ = self._drop
         hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, self._bufs[f"{tag}:lse"], B, HEADS, T, T,
                       scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev,
                       d_o=dO, dq=dQKV[:, 0:D], dk=dQKV[:, D:2 * D], dv=dQKV[:, 2 * D:], delta=delta)
         # weight gradients (bias gradients fused: row sums of dy^T), one grouped launch
-        hip.gemm_group([hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"]),
-                        hip.linear_wgrad_call(dQKV[:, 0:2 * D], qk_in, gW[0:2 * D], bias_grad=gb[0:2 * D]),
-                        hip.linear_wgrad_call(dQKV[:, 2 * D:], v_in, gW[2 * D:], bias_grad=gb[2 * D:])])
+        self._side(lambda: hip.gemm_group([
+            hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"]),
+            hip.linear_wgrad_call(dQKV[:, 0:2 * D], qk_in, gW[0:2 * D], bias_grad=gb[0:2 * D]),
+            hip.linear_wgrad_call(dQKV[:, 2 * D:], v_in, gW[2 * D:], bias_grad=gb[2 * D:])]))
         calls = []
         if acc_qk is not None:
             calls.append(hip.linear_dgrad_call(dQKV[:, 0:2 * D], W[0:2 * D], acc_qk, residual=acc_qk))
@@ -344,12 +377,14 @@ class DetrEngine:
         G = self.P.gviews
         h = self._bufs[f"{tag}:h"]                 # post-ReLU, post-dropout hidden activation
         dp, _ = self._drop
-        dh = self.buf(f"scratch:dh:{h.shape[0]}:{int(self.ffn16)}", h.shape, torch.bfloat16 if self.ffn16 else torch.float32)
+        dh = self.buf(f"scratch:dh:{h.shape[0]}:{int(self.ffn16)}{self._sx(tag)}", h.shape,
+                      torch.bfloat16 if self.ffn16 else torch.float32)
         # (h > 0) is both the ReLU and the keep mask of the hidden dropout; its 1/(1-p) scale goes in alpha
         hip.linear_dgrad(d_y, self._w(f"{pfx}/linear2/kernel"), dh, mask=h, alpha=(1.0 / (1.0 - dp)) if dp > 0.0 else 1.0)
-        hip.gemm_group([hip.linear_wgrad_call(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"]),
-                        hip.linear_wgrad_call(dh, x16 if x16 is not None else x, G[f"{pfx}/linear1/kernel"],
-                                              bias_grad=G[f"{pfx}/linear1/bias"])])
+        self._side(lambda: hip.gemm_group([
+            hip.linear_wgrad_call(d_y, h, G[f"{pfx}/linear2/kernel"], bias_grad=G[f"{pfx}/linear2/bias"]),
+            hip.linear_wgrad_call(dh, x16 if x16 is not None else x, G[f"{pfx}/linear1/kernel"],
+                                  bias_grad=G[f"{pfx}/linear1/bias"])]))
         hip.linear_dgrad(dh, self._w(f"{pfx}/linear1/kernel"), dx, residual=d_f)
 
     # ---- layer-invariant decoder cross-attention K / V (transformer.py:221-223: memory is the same for every layer) ------
@@ -403,12 +438,20 @@ class DetrEngine:
             hip.begin_deferred_reduces(self.device)
             if on_bucket:
                 def cb(i):
+                    self._side_join()
                     hip.flush_reduces()
                     on_bucket(i)
+        elif on_bucket:
+            def cb(i):
+                self._side_join()
+                on_bucket(i)
+        self._side_begin(WGRAD_STREAM and d_logits.is_cuda)
         try:
             return self._backward_impl(d_logits, d_boxes, backbone, cb)
         finally:
             try:
+                self._side_join()
+                self._side_on = False
                 hip.flush_reduces(end=True)
             finally:
                 hip.COMPUTE_BF16 = 0
@@ -657,29 +700,30 @@ class DetrEngine:
             ds = 16 * (32 + i)
             d_t3 = self.buf("scratch:d_t3", (BQ, D))
             self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf", dx_add=d_next)
-            d_f = self.buf("scratch:d_f", (BQ, D))
+            d_f = self.buf(f"scratch:d_f{self._sx(tag)}", (BQ, D))
             d_y = self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5, want16=self.ffn16)
             d_t2 = self.buf("scratch:d_t2", (BQ, D))
             self._ffn_bwd(tag, pfx, d_y, d_f, t2, d_t2, x16=self._bufs.get(f"{tag}:t2h") if self.ffn16 else None)
-            d_a2 = self.buf("scratch:d_a2", (BQ, D))
+            d_a2 = self.buf(f"scratch:d_a2{self._sx(tag)}", (BQ, D))
             d_out = self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2", drop_site=ds + 3)
             # ---- cross attention
             Wc = self._w(f"{cp}/in_proj_kernel")
             Qc, Oc = self._bufs[f"{tag}:ca:Q"], self._bufs[f"{tag}:ca:O"]
             dO = self.buf(f"scratch:dO:{BQ}", (BQ, D))
             hip.linear_dgrad(d_out, self._w(f"{cp}/out_proj_kernel"), dO)
-            dQc = self.buf("scratch:dQc", (BQ, D))
+            dQc = self.buf(f"scratch:dQc{self._sx(tag)}", (BQ, D))
             delta = self.buf(f"scratch:delta:{BQ}", (B * HEADS, Q))
             hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, self._bufs[f"{tag}:ca:lse"],
                           B, HEADS, Q, L, scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev,
                           d_o=dO, dq=dQc, dk=dKV[:, i * D:(i + 1) * D], dv=dKV[:, (nd + i) * D:(nd + i + 1) * D], delta=delta)
-            hip.gemm_group([hip.linear_wgrad_call(d_out, Oc, G[f"{cp}/out_proj_kernel"], bias_grad=G[f"{cp}/out_proj_bias"]),
-                            hip.linear_wgrad_call(dQc, q2, G[f"{cp}/in_proj_kernel"][0:D], bias_grad=G[f"{cp}/in_proj_bias"][0:D])])
+            self._side(lambda d_out=d_out, Oc=Oc, dQc=dQc, q2=q2, cp=cp: hip.gemm_group([
+                hip.linear_wgrad_call(d_out, Oc, G[f"{cp}/out_proj_kernel"], bias_grad=G[f"{cp}/out_proj_bias"]),
+                hip.linear_wgrad_call(dQc, q2, G[f"{cp}/in_proj_kernel"][0:D], bias_grad=G[f"{cp}/in_proj_bias"][0:D])]))
             d_t1 = self.buf("scratch:d_t1", (BQ, D))
             # q2 = t1 + query_pos ; a2 = attn + t1: the q gradient goes to t1 (with the residual path) and to the query_pos sum
             hip.gemm_group([hip.linear_dgrad_call(dQc, Wc[0:D], acc_qpos, residual=acc_qpos),
                             hip.linear_dgrad_call(dQc, Wc[0:D], d_t1, residual=d_a2)])
-            d_a1 = self.buf("scratch:d_a1", (BQ, D))
+            d_a1 = self.buf(f"scratch:d_a1{self._sx(tag)}", (BQ, D))
             d_out = self._ln_bwd(d_t1, a1, f"{pfx}/norm1", d_a1, f"{tag}:ln1", drop_site=ds + 1)
             # ---- self attention: qin = tgt + query_pos feeds q and k, tgt feeds v and the residual
             d_tgt = self.buf(f"scratch:d_tgt{i & 1}", (BQ, D)) if i > 0 else None      # layer 0: tgt is the constant zero target
@@ -692,6 +736,7 @@ class DetrEngine:
         hip.zero_(ct["gb"])
         hip.gemm_group([hip.linear_wgrad_call(dKV[:, 0:nd * D], mem_pos, ct["gW"][0:nd * D], bias_grad=ct["gb"][0:nd * D]),
                         hip.linear_wgrad_call(dKV[:, nd * D:], memory, ct["gW"][nd * D:], bias_grad=ct["gb"][nd * D:])])
+        self._side_join()
         hip.flush_reduces()                            # the scatter reads the gathered gradient
         hip.multi_copy(ct["scatter"])
         d_mem = self.buf("scratch:d_mem", (B * L, D))
@@ -702,11 +747,11 @@ class DetrEngine:
             pfx, tag = f"transformer/encoder/layer_{i}", f"enc{i}"
             x_in = self._bufs[f"enc{i - 1}:x2"] if i > 0 else self._bufs["enc:src0"]
             qk, a, x1, f = (self._bufs[f"{tag}:{n}"] for n in ("qk", "a", "x1", "f"))
-            d_f = self.buf("scratch:e_d_f", (B * L, D))
+            d_f = self.buf(f"scratch:e_d_f{self._sx(tag)}", (B * L, D))
             d_y = self._ln_bwd(d_x, f, f"{pfx}/norm2", d_f, f"{tag}:ln2", drop_site=16 * i + 3, want16=self.ffn16)
             d_x1 = self.buf("scratch:e_d_x1", (B * L, D))
             self._ffn_bwd(tag, pfx, d_y, d_f, x1, d_x1, x16=self._bufs.get(f"{tag}:x1h") if self.ffn16 else None)
-            d_a = self.buf("scratch:e_d_a", (B * L, D))
+            d_a = self.buf(f"scratch:e_d_a{self._sx(tag)}", (B * L, D))
             d_out = self._ln_bwd(d_x1, a, f"{pfx}/norm1", d_a, f"{tag}:ln1", drop_site=16 * i + 1)
             d_xn = self.buf(f"scratch:e_d_x{i & 1}", (B * L, D))
             self._self_attn_bwd(f"{tag}:sa", f"{pfx}/self_attn", d_out, d_a, qk, x_in, B, L, d_xn, site=16 * i)
@@ -740,22 +785,10 @@ class DetrEngine:
         # but HBM-bound data-gradient GEMM and an MFMA/LDS-bound weight gradient share the CUs (inside the captured graph the
         # fork / join events become plain graph edges).  The scratch tensors the side stream reads (dz2, dz1: double-buffered
         # by block parity; gx) are only overwritten after the side work that read them has been waited for.
-        ws_on = WGRAD_STREAM and feat.is_cuda
-        main = torch.cuda.current_stream() if ws_on else None
-        if ws_on and getattr(self, "_wg_stream", None) is None:
-            self._wg_stream = torch.cuda.Stream(device=feat.device)
-        wside = self._wg_stream if ws_on else None
+        ws_on = self._side_on
+        main, wside = (self._side_main, self._wg_stream) if ws_on else (None, None)
         side_done = {}
-
-        def on_side(fn):
-            if not ws_on:
-                fn()
-                return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            wside.wait_event(ev)
-            with torch.cuda.stream(wside):
-                fn()
+        on_side = self._side
 
         def side_mark(bi):
             if ws_on:
@@ -767,18 +800,6 @@ class DetrEngine:
             ev = side_done.pop(bi, None)
             if ev is not None:
                 main.wait_event(ev)
-
-        def side_join():
-            if ws_on:
-                main.wait_stream(wside)
-                side_done.clear()
-
-        if ws_on and on_bucket:
-            _ob = on_bucket
-
-            def on_bucket(i, _ob=_ob):
-                side_join()                 # (also required before a graph segment is cut)
-                _ob(i)
 
         for bi in reversed(range(n_blocks)):
             m = self._block_meta[bi]
@@ -851,7 +872,7 @@ class DetrEngine:
                     on_bucket(1)
                 elif p == block_names(2, 0, tfb)["tag"]:
                     on_bucket(2)
-        side_join()
+        self._side_join()
         # ---------------- stem ----------------
         stem, pool, amax = (self._bufs[f"stem:{n}"] for n in ("out", "pool", "amax"))
         H1, W1 = stem.shape[1], stem.shape[2]
