@@ -248,6 +248,9 @@ def begin_deferred_reduces(device):
     DEFER, _defer_top, _defer_outs = [], 0, set()
 
 
+AFTER_FLUSH = None     # hook of the engine: orders its two launch streams after a flush
+
+
 def flush_reduces(end=False):
     """Reduce everything pending (bucket boundary / a consumer of the gradients / end of the backward pass): up to 16 slab
     sets per launch; the slabs become reusable."""
@@ -257,6 +260,8 @@ def flush_reduces(end=False):
     if DEFER:
         arr = (ReduceDesc * len(DEFER))(*DEFER)
         _check(load().detr_hip_splitk_reduce_many(arr, len(DEFER), _stream()), "detr_hip_splitk_reduce_many")
+        if AFTER_FLUSH is not None:
+            AFTER_FLUSH()              # (two launch streams: the recycled slabs must not be handed to the other one early)
     _defer_top, _defer_outs = 0, set()
     DEFER = None if end else []
 

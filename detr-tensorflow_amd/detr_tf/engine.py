@@ -259,10 +259,18 @@ class DetrEngine:
     # reduction flush, a bucket hand-over and the end of the backward.
     def _side_begin(self, on):
         self._side_on = bool(on)
+        hip.AFTER_FLUSH = self._side_sync if self._side_on else None
         if self._side_on:
             self._side_main = torch.cuda.current_stream()
             if getattr(self, "_wg_stream", None) is None:
                 self._wg_stream = torch.cuda.Stream(device=self._side_main.device)
+
+    def _side_sync(self):
+        """After a reduction flush the slab pool is recycled: whichever stream ran the flush, the other one must not write a
+        recycled slab before the flush has read it."""
+        if getattr(self, "_side_on", False):
+            self._side_main.wait_stream(self._wg_stream)
+            self._wg_stream.wait_stream(self._side_main)
 
     def _side(self, fn):
         if not getattr(self, "_side_on", False):
@@ -424,10 +432,15 @@ class DetrEngine:
             self._refresh_shadow()
         if self.tf_backbone and self._stale("bias_shift"):
             self._refresh_bias_shift()
+        self._side_begin(WGRAD_STREAM and images.is_cuda)
         try:
             return self._forward_impl(images, training)
         finally:
-            hip.COMPUTE_BF16 = 0
+            try:
+                self._side_join()
+            finally:
+                self._side_on = False
+                hip.COMPUTE_BF16 = 0
 
     def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
         hip.COMPUTE_BF16 = self.compute
@@ -445,7 +458,8 @@ class DetrEngine:
             def cb(i):
                 self._side_join()
                 on_bucket(i)
-        self._side_begin(WGRAD_STREAM and d_logits.is_cuda)
+        # (immediate split-K reductions share ONE slab workspace between all launches: single stream then)
+        self._side_begin(WGRAD_STREAM and DEFER_REDUCE and d_logits.is_cuda)
         try:
             return self._backward_impl(d_logits, d_boxes, backbone, cb)
         finally:
@@ -508,16 +522,20 @@ class DetrEngine:
                     x1, M1, h1, w1, s2 = xs, M_out, ho, wo, 1
                 else:                           # reference backbone (resnet_backbone.py:104-105): on the 3x3 conv
                     x1, M1, h1, w1, s2 = x, M_in, h, w, stride
+                if b == 0:
+                    # the projection shortcut only meets the main branch at conv3's residual operand: second stream
+                    # (an HBM-bound 1x1 GEMM next to the MFMA-bound 3x3 conv)
+                    idn = self.buf(f"{p}:idn", (B, ho, wo, d2), adt)
+                    self._side(lambda: self._conv1x1_fwd(xs, M_out, cin, d2, f"{n['down']}/kernel", n["bnd"], idn, act=0))
+                else:
+                    idn = x
                 y1 = self.buf(f"{p}:y1", (B, h1, w1, d1), adt)
                 self._conv1x1_fwd(x1, M1, cin, d1, f"{n['conv1']}/kernel", n["bn1"], y1)
                 y2 = self.buf(f"{p}:y2", (B, ho, wo, d1), adt)
                 hip.conv3x3(0, y1, self._scaled_kernel(f"{n['conv2']}/kernel", n["bn2"]), y2, B, h1, w1, d1, ho, wo, d1,
                             s2, bias=self.bn_shift[n["bn2"]], act=1)
                 if b == 0:
-                    idn = self.buf(f"{p}:idn", (B, ho, wo, d2), adt)
-                    self._conv1x1_fwd(xs, M_out, cin, d2, f"{n['down']}/kernel", n["bnd"], idn, act=0)
-                else:
-                    idn = x
+                    self._side_join()
                 out = self.buf(f"{p}:out", (B, ho, wo, d2), adt)
                 self._conv1x1_fwd(y2, M_out, d1, d2, f"{n['conv3']}/kernel", n["bn3"], out, residual=idn)
                 self._block_meta.append(dict(p=p, n=n, x=x, xs=xs, x1=x1, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, h1=h1, w1=w1,
@@ -568,8 +586,9 @@ class DetrEngine:
         if self._stale(f"cross:{self.compute}"):
             hip.multi_copy(ct["gather"])
         KV = self.buf("dec:KV", (B * L, 2 * nd * D))
-        hip.gemm_group([hip.linear_fwd_call(mem_pos, ct["Wkv"][0:nd * D], ct["bkv"][0:nd * D], KV[:, 0:nd * D]),
-                        hip.linear_fwd_call(memory, ct["Wkv"][nd * D:], ct["bkv"][nd * D:], KV[:, nd * D:])])
+        # (second stream: the first decoder self-attention block -- 800-row kernels -- does not need it)
+        self._side(lambda: hip.gemm_group([hip.linear_fwd_call(mem_pos, ct["Wkv"][0:nd * D], ct["bkv"][0:nd * D], KV[:, 0:nd * D]),
+                                           hip.linear_fwd_call(memory, ct["Wkv"][nd * D:], ct["bkv"][nd * D:], KV[:, nd * D:])]))
         qin = self.buf("dec0:qin", (B * Q, D))
         self._add_bcast(tgt, qpos, qin)                          # tgt + query_pos (:209); later layers: from LayerNorm 3
         for i in range(nd):
@@ -585,6 +604,8 @@ class DetrEngine:
             Wc, bc = self._w(f"{cp}/in_proj_kernel"), V[f"{cp}/in_proj_bias"]
             Qc = self.buf(f"{tag}:ca:Q", (B * Q, D))
             hip.linear_fwd(q2, Wc[0:D], bc[0:D], Qc)
+            if i == 0:
+                self._side_join()                                # K / V of all layers
             Oc = self.buf(f"{tag}:ca:O", (B * Q, D))
             lse = self.buf(f"{tag}:ca:lse", (B * HEADS, Q))
             hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, lse, B, HEADS, Q, L,
@@ -814,6 +835,25 @@ class DetrEngine:
             ws2 = self._bufs[f"{wk}:{n['conv2']}/kernel"]
             ws3 = self._bufs[f"{wk}:{n['conv3']}/kernel"]
             # conv3: g is the gradient w.r.t. (bn3(conv3(y2)) + identity), already ReLU-masked
+            strided = m["first"] and stride == 2
+            wsd = self._bufs[f"{wk}:{n['down']}/kernel"] if m["first"] else None
+            idg, idg_ready = g, None
+            if m["first"] and not (tfb and strided):
+                # data gradient of the projection shortcut: only the block's last GEMM reads it (as its residual operand)
+                idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
+
+                def dg_down(g=g, idg=idg):
+                    if strided:
+                        dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
+                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
+                        hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin // f32c, ho, wo)
+                    else:
+                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
+                on_side(dg_down)
+                if ws_on:
+                    idg_ready = torch.cuda.Event()
+                    idg_ready.record(wside)
+
             def wg3(g=g):
                 self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
                 bias_grad(n["conv3"], n["bn3"], g, M_out, d2)
@@ -842,9 +882,6 @@ class DetrEngine:
             is_first_block = bi == 0
             gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin), adt)
             mask = None if is_first_block else x           # x = ReLU output of the previous block
-            strided = m["first"] and stride == 2
-            if m["first"]:
-                wsd = self._bufs[f"{wk}:{n['down']}/kernel"]
             if tfb and strided:
                 # both branches read the subsampled input: d_xs = g @ Wd^T + dz1 @ W1^T (ReLU-masked at the sampled pixels),
                 # scattered back into the zero-filled full-resolution gradient
@@ -854,16 +891,8 @@ class DetrEngine:
                          mask=(None if is_first_block else xs), ldmask=(0 if is_first_block else cin))
                 hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), gx.data_ptr(), B, h, w, cin // f32c, ho, wo)
             else:
-                if m["first"]:
-                    idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
-                    if strided:
-                        dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
-                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
-                        hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin // f32c, ho, wo)
-                    else:
-                        hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
-                else:
-                    idg = g
+                if idg_ready is not None:
+                    main.wait_event(idg_ready)
                 hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
                          ldmask=(cin if mask is not None else 0))
             g = gx

@@ -157,7 +157,7 @@ def test_bench_forced_single_rank_rccl_path(hip):
     def run():
         return _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
                            str(_free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--height", "128",
-                           "--width", "160", "--no-cpu-baseline", "--no-fp32-leg", "--no-configs", "--no-kernel-events"],
+                           "--width", "160", "--no-cpu-baseline", "--no-fp32-leg", "--no-configs", "--no-kernel-events", "--launch", "graph"],
                           env_extra={"DETR_DP_FORCE": "1"})
     r = run()
     if r.returncode != 0 and any(l.startswith("{") for l in r.stdout.splitlines()):
