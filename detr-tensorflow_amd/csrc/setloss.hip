@@ -409,6 +409,14 @@ __global__ __launch_bounds__(64) void assign_kernel(const float *__restrict__ co
 //   sums[lv*8 + {0: sum w*CE, 1: sum w, 2: neg correct, 3: n_neg, 4: n_pos, 5: pos != bg, 6: pos correct}]
 //   sums[levels*8 + lv*2 + {0: sum L1, 1: sum (1-GIoU)}]
 // ------------------------------------------------------------------------------------------------
+// The cross-entropy normaliser sum(w) (loss.py:60-67: weight 0.1 on the background class, 1 elsewhere) is derived from the
+// two COUNTS, which float atomics accumulate exactly in any order, instead of being accumulated itself: 0.1f is not a dyadic
+// number, so the order of 4 waves x B images of atomic adds moved it by an ulp from run to run -- and every gradient with
+// it (two runs of the same step then differed by up to 1e-2 in bf16-stored activation gradients of the near-degenerate
+// random-init model).  With this the gradients are a deterministic function of the matching; only the REPORTED loss values
+// (sums of w*CE, L1, 1-GIoU) keep the atomics' last-bit noise.
+__device__ __forceinline__ float ce_weight_sum(const float *s) { return 0.1f * s[3] + s[4]; }
+
 __global__ __launch_bounds__(256) void set_loss_sums_kernel(SetLossArgs a, const int *__restrict__ tgt_for_pred,
                                                             float *__restrict__ sums) {
     const int p = blockIdx.x;
@@ -443,7 +451,6 @@ __global__ __launch_bounds__(256) void set_loss_sums_kernel(SetLossArgs a, const
             if (t < 0) {
                 const float ce = lse - row[a.background_class];
                 acc[0] += 0.1f * ce;
-                acc[1] += 0.1f;
                 acc[2] += (am == a.background_class) ? 1.f : 0.f;
                 acc[3] += 1.f;
             } else {
@@ -452,7 +459,6 @@ __global__ __launch_bounds__(256) void set_loss_sums_kernel(SetLossArgs a, const
                 // NaN like tf.nn.sparse_softmax_cross_entropy_with_logits on the GPU (the CPU op raises)
                 const float ce = (cls >= 0 && cls < a.C) ? lse - row[cls] : NAN;
                 acc[0] += ce;
-                acc[1] += 1.0f;
                 acc[4] += 1.f;
                 acc[5] += (am != a.background_class) ? 1.f : 0.f;
                 acc[6] += (am == cls) ? 1.f : 0.f;
@@ -481,7 +487,7 @@ __global__ void set_loss_finalize_kernel(const float *__restrict__ sums, int lev
         const int lv = (k == 0) ? levels - 1 : k - 1;
         const float *s = sums + lv * 8;
         const float *sb = sums + levels * 8 + lv * 2;
-        const float label = s[0] / s[1];
+        const float label = s[0] / ce_weight_sum(s);
         const float npos = s[4];
         const float giou = sb[1] / npos;
         const float l1 = sb[0] / npos;
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(256) void set_loss_grad_kernel(SetLossArgs a, const
     float *dlg = d_logits + lv * a.sL_l + b * a.sL_b;
     float *dbx = d_boxes + lv * a.sB_l + b * a.sB_b;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float sw = sums[lv * 8 + 1];
+    const float sw = ce_weight_sum(sums + lv * 8);
     const float npos = sums[lv * 8 + 4];
     for (int q = wave; q < a.Q; q += 4) {
         const float *row = lg + q * a.sL_q;

@@ -355,8 +355,10 @@ int detr_hip_assign_f32(const float *cost, int32_t P, int32_t Q, int32_t ldc, co
                         int32_t B, int32_t R, int32_t *tgt_for_pred, int32_t *pred_for_tgt,
                         int32_t *status, void *stream);
 /* K14: loss.py:37-96.  Three steps so that data-parallel ranks can all-reduce `sums` in between:
- *   sums [levels][8] = {sum w*CE, sum w, n_neg_correct, n_neg, n_pos, n_pos_not_bg, n_pos_correct, -}
- *                      {.. [7] unused};  box sums [levels][2] are stored at sums + levels*8:
+ *   sums [levels][8] = {sum w*CE, -, n_neg_correct, n_neg, n_pos, n_pos_not_bg, n_pos_correct, -}
+ *                      {.. [1], [7] unused: the normaliser sum w is derived as 0.1*n_neg + n_pos from the counts, which
+ *                      float atomics accumulate exactly in any order -- the gradients are then a deterministic function
+ *                      of the matching};  box sums [levels][2] are stored at sums + levels*8:
  *                      {sum L1, sum (1-GIoU)} ; all ACCUMULATED atomically (zero them first). */
 int detr_hip_set_loss_sums_f32(const detr_setloss_desc *d, const int32_t *tgt_for_pred, float *sums,
                                void *stream);

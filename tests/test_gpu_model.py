@@ -153,6 +153,38 @@ def test_backward_immediate_split_k_reductions_vs_oracle(hip, small, monkeypatch
     assert not bad, f"gradient mismatch with immediate reductions: {bad[:12]}"
 
 
+def test_second_launch_stream_does_not_change_the_step(hip, small, monkeypatch):
+    """engine.WGRAD_STREAM (default on): weight gradients, projection shortcuts and the decoder's shared K/V projection are
+    issued on a second HIP stream.  Outputs and gradients must equal the single-stream step BIT FOR BIT (every kernel of the
+    step is deterministic and the gradients do not depend on the order of the set-loss atomics, csrc/setloss.hip
+    ce_weight_sum) -- a missing fork / join edge or a scratch tensor rewritten under a running side launch shows up here
+    (repeated a few times: a race does not lose every run) -- in both precisions."""
+    from detr_tf import engine as E, training
+    from detr_tf.optimizers import setup_optimizers
+    model = small["model"]
+    opt = setup_optimizers(model, small["cfg"])
+    assert E.WGRAD_STREAM and E.DEFER_REDUCE
+    try:
+        for compute in (0, 1):
+            model.engine.compute = compute
+
+            def run():
+                out, total, _, _ = training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
+                torch.cuda.synchronize()
+                return out["pred_logits"].clone(), float(total), model.engine.P.grad.clone()
+            monkeypatch.setattr(E, "WGRAD_STREAM", False)
+            lg1, t1, g1 = run()
+            monkeypatch.setattr(E, "WGRAD_STREAM", True)
+            for rep in range(4):
+                lg2, t2, g2 = run()
+                assert torch.equal(lg1, lg2), f"compute {compute} rep {rep}: forward differs on two streams"
+                assert abs(t1 - t2) <= 1e-6 * abs(t1)          # (the reported loss sums are float atomics: last-bit noise)
+                nd = int((g1 != g2).sum())
+                assert nd == 0, f"compute {compute} rep {rep}: {nd} gradient entries differ on two streams"
+    finally:
+        model.engine.compute = 0
+
+
 def test_backward_small_shapes_vs_oracle(hip):
     """Same check on the reduced model / tiny feature map (3x4 tokens) used by the train-step test:
     exercises the partial-tile and split-free code paths of every backward kernel."""
