@@ -250,13 +250,16 @@ class DetrEngine:
         hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2,
                           y16=y16)
 
-    # ---- second stream for the weight gradients ---------------------------------------------------------------------
-    # A weight gradient feeds nothing but the bucket exchange / the optimiser, so with WGRAD_STREAM it is issued on a second
-    # HIP stream behind an event of the main stream that follows its producer (a graph edge when the step is captured) and
-    # shares the chip with the data-gradient chain: the decoder's 800-row kernels fill a fifth of the CUs, the backbone's
-    # HBM-bound data-gradient GEMMs leave the MFMA pipes idle.  The tensors such a launch reads are never rewritten within
-    # the same backward (_sx: one scratch tensor per site instead of one per shape), so the only joins are in front of a
-    # reduction flush, a bucket hand-over and the end of the backward.
+    # ---- second launch stream ----------------------------------------------------------------------------------------------
+    # Work that does not feed the critical chain is issued on a second HIP stream behind an event of the main stream that
+    # follows its producer (a graph edge when the pass is captured) and is joined where its result is read:
+    #   backward: every weight gradient (it feeds nothing but the bucket exchange / the optimiser) and the data gradient of a
+    #             stage's projection shortcut; forward: the projection shortcut and the decoder's shared K / V projection.
+    # They share the chip with the chain: the decoder's 800-row kernels fill a fifth of the CUs, the backbone's HBM-bound 1x1
+    # GEMMs leave the MFMA pipes idle.  The tensors a side launch reads are never rewritten within the same pass (_sx: one
+    # scratch tensor per site instead of one per shape; the backbone loop guards its recycled tensors with per-block events),
+    # so the only joins are in front of a reduction flush, a bucket hand-over, the consumer of a shortcut / of K, V, and the
+    # end of the pass.  Off (one stream): DETR_HIP_WGRAD_STREAM=0, and any backward with immediate split-K reductions.
     def _side_begin(self, on):
         self._side_on = bool(on)
         hip.AFTER_FLUSH = self._side_sync if self._side_on else None
