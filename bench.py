@@ -433,7 +433,7 @@ def main():
                                    f"{'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, {args.queries} queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)",
-                       "launch": ("hipGraph replay" if (launch["graph"] and args.mode == "train") else "eager, 2 HIP streams")
+                       "launch": ("hipGraph replay" if (launch["graph"] and args.mode == "train") else ("eager, 2 HIP streams" if wgrad_stream_default else "eager, 1 HIP stream"))
                                  + (f" (auto: graph {launch['probe']['graph_ms']} ms vs eager {launch['probe']['eager_ms']} ms per step)"
                                     if launch["probe"] else "")},
             "loss": round(loss_val, 5),
