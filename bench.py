@@ -129,7 +129,11 @@ def cpu_baseline(height, width, threads=0, budget_s=28.0):
 
 
 def family_tables(prof, ev_steps, precision):
-    """Per-family totals of the HIP-event records + the dominant family + SURVEY 8d's mixed roofline over the instrumented launches."""
+    """Per-family totals of the HIP-event records, the dominant family and SURVEY 8d's mixed roofline over the instrumented launches.
+    ONE grouping rule: a family is one kernel BODY with all its template instantiations pooled -- the tile GEMM engine
+    (`gemm_bf16c_kernel` / `gemm_f32_kernel`: every layout, storage type, tile size, plain and grouped launches), the streaming
+    GEMM, the 3x3 convolution per direction, the stem, attention forward / backward.  The dominant family is the one with the
+    largest pooled time."""
     fam = prof.summary()
     if not fam:
         return None, None
@@ -140,11 +144,15 @@ def family_tables(prof, ev_steps, precision):
         peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
         t_mfma = v["flops"] / (peak * 1e12) * 1e3
         t_hbm = v["bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3
-        mixed_ms += max(t_mfma, t_hbm)
+        # the family's own mixed roofline: every launch priced at max(its FLOPs / MFMA peak, its bytes / HBM peak)
+        t_mix = v.get("mixed_s", 0.0) * 1e3 if v.get("mixed_s") else max(t_mfma, t_hbm)
+        mixed_ms += t_mix
         cov_ms += v["ms"]
         rows[k] = {"ms_per_step": round(v["ms"] / ev_steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "launches_per_step": v["launches"] // ev_steps,
-                   "roofline_ms": round(max(t_mfma, t_hbm) / ev_steps, 3), "bound": "mfma" if t_mfma >= t_hbm else "hbm"}
+                   "roofline_ms": round(t_mix / ev_steps, 3), "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                   "frac_of_mfma_peak": round(t_mfma / v["ms"], 4), "frac_of_hbm_peak": round(t_hbm / v["ms"], 4),
+                   "frac_of_mixed_roofline": round(t_mix / v["ms"], 4)}
     dom = max(fam, key=lambda k: fam[k]["ms"])
     return (fam, dom, rows), {"mixed_ms": mixed_ms / ev_steps, "covered_ms": cov_ms / ev_steps}
 
@@ -164,11 +172,12 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
         if dom in tj.get("per_symbol", {}):
             traffic = round(tj["per_symbol"][dom]["traffic_bytes_per_launch"])
             traffic_src = f"profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
-    note = " (all K / layout / epilogue instantiations pooled)" if dom.startswith("gemm_stream") else " (tile sizes pooled)"
-    r = {"bound": bound, "kernel": "detr::" + dom + note,
+    r = {"bound": bound, "kernel": "detr::" + dom + " (every template instantiation of the kernel body pooled; plain + grouped launches)",
          "achieved": round(gbs, 1) if bound == "hbm" else round(tflops, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak_tf,
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
          "frac": round(gbs / PEAK_HBM_GBS if bound == "hbm" else tflops / peak_tf, 4),
+         "frac_mfma": round(tflops / peak_tf, 4), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+         "frac_mixed": rows[dom]["frac_of_mixed_roofline"],
          "traffic": traffic, "traffic_source": traffic_src,
          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
          "tflops": round(tflops, 2), "gbs": round(gbs, 1), "launches_per_step": d["launches"] // ev_steps,
@@ -242,8 +251,7 @@ def main():
     cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = True
     if args.no_graph:
         args.launch = "eager"
-    use_graph = args.launch != "eager"          # (auto: the recorded step exists, the choice is made after the warm-up)
-    launch = {"graph": use_graph, "probe": None}
+    # the launch path is the product's own: training.GraphedTrainStep(launch=...) is what training.fit() uses, with "auto" its default
     wgrad_stream_default = engine_mod.WGRAD_STREAM
 
     def build(precision):
@@ -257,7 +265,7 @@ def main():
                 dist.broadcast(raw, src=0)
             m.engine.fold_bn()
             m.dp = parallel.DataParallel(m.engine.P.grad, m.engine.P.bucket_bounds(), engine=m.engine)
-        return m, o, (training.GraphedTrainStep(m, o, cfg) if use_graph else None)
+        return m, o, training.GraphedTrainStep(m, o, cfg, launch=args.launch)
 
     rng = np.random.default_rng(1234 + rank)
     images = torch.from_numpy(rng.normal(size=(args.batch, args.height, args.width, 3)).astype(np.float32)).to(dev)
@@ -270,7 +278,7 @@ def main():
         # streams the events of co-running kernels overlap and every duration is stretched by its neighbour)
         engine_mod.WGRAD_STREAM = wgrad_stream_default and _hip.PROFILER is None and not single
         if args.mode == "train":
-            if stepper is not None and launch["graph"] and _hip.PROFILER is None and not single:   # (HIP events around single launches need the eager step)
+            if _hip.PROFILER is None and not single:   # (HIP events around single launches need the single-stream eager step)
                 return stepper(images, tb, tc, i)[1]
             return training.train_step(model, images, tb, tc, opt, cfg, i)[1]
         out = model(images, training=False)
@@ -292,31 +300,21 @@ def main():
     loss_first = None
     if args.mode == "train" and not args.no_kernel_events:
         loss_first = step(0, single=True).clone()   # (also allocates the single-stream scratch tensors of the event-instrumented step)
-    for i in range(max(args.warmup, 2 if use_graph else 1)):     # graph mode: one eager step, then the recording pass
+    # warm-up: at least until the stepper's launch path is final ("auto": eager step, recording pass, 3 timed replays, 3 timed
+    # eager steps -- all ordinary training steps; which path wins depends on the host, and the ranks agree through a MAX all-reduce)
+    for i in range(max(args.warmup, stepper.settle_calls if args.mode == "train" else 1)):
         last = step(i)
         if i == 0 and loss_first is None:
             loss_first = last.clone()      # device scalar: read after the timed region
-    if args.launch == "auto" and args.mode == "train":
-        # both launch paths are the product's (training.fit takes either); the recorded step wins when the host is slow or
-        # shared, the eager two-stream step when it is not (hipGraph replay serialises most of the second stream's work)
-        step(0)                                 # (the warm-up above ran the eager step and the recording pass)
-        tg, _ = timed(3)
-        launch["graph"] = False
-        step(0)
-        te, _ = timed(3)
-        tt = torch.tensor([tg, te], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        tg, te = (float(v) for v in tt.tolist())
-        launch["graph"] = tg <= te
-        launch["probe"] = {"graph_ms": round(tg / 3 * 1e3, 3), "eager_ms": round(te / 3 * 1e3, 3)}
-        step(0)
+    main_choice, main_probe = stepper.choice, stepper.probe
+    if model.dp is not None:
+        model.dp.enable_timing()               # HIP events around the bucket exchange: comm_ms / exposed_comm_ms of the timed steps
     # HIP events around every GEMM / conv / attention launch (roofline leg) cost ~4 us of host time per event, so they are
     # recorded in the LAST `event_steps` timed steps only (which run eagerly); the other timed steps run uninstrumented.
     prof = None
     ev_steps = 0 if (args.no_kernel_events or rank != 0 or args.mode != "train") else max(1, min(args.event_steps, args.steps))
     if ev_steps:
-        prof = _hip.KernelProfiler(prealloc=1400 * ev_steps)     # event objects exist before the timed region
+        prof = _hip.KernelProfiler(prealloc=1400 * ev_steps, f32=(args.precision == "fp32"))     # event objects exist before the timed region
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -327,6 +325,7 @@ def main():
     dt = time.perf_counter() - t0
     _hip.PROFILER = None
     loss_val = float(last)
+    dp_timing = model.dp.timing_summary() if model.dp is not None else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -339,7 +338,7 @@ def main():
     value_nodrop = None
     if args.mode == "train" and args.dropout > 0.0 and solo:
         model.engine.dropout_p = 0.0
-        for i in range(2):
+        for i in range(stepper.settle_calls):      # (a new step signature: the stepper records and probes again)
             step(i)
         d, _ = timed(3)
         value_nodrop = args.batch * 3 / d
@@ -357,19 +356,22 @@ def main():
         torch.cuda.empty_cache()
         model, opt, stepper = build("fp32")
         loss_first_fp32 = float(step(0))          # same weights, batch and dropout masks as the first bf16 step
-        step(1)
-        d, _ = timed(3, first=2)
-        fp32 = {"value": round(args.batch * 3 / d, 3), "unit": "images/sec", "ms_per_step": round(d / 3 * 1e3, 3), "steps": 3,
-                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)"}
+        for i in range(1, stepper.settle_calls):
+            step(i)
+        n32 = max(10, min(args.steps, 20))
+        d, _ = timed(n32, first=stepper.settle_calls)
+        fp32 = {"value": round(args.batch * n32 / d, 3), "unit": "images/sec", "ms_per_step": round(d / n32 * 1e3, 3), "steps": n32,
+                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
+                "launch": ("hipGraph replay" if stepper.choice == "graph" else "eager, 2 HIP streams"), "launch_probe": stepper.probe}
         if not args.no_kernel_events:
-            p32 = _hip.KernelProfiler(prealloc=1400)
+            p32 = _hip.KernelProfiler(prealloc=1400, f32=True)
             _hip.PROFILER = p32
             step(5)
             torch.cuda.synchronize()
             _hip.PROFILER = None
             (fam32, dom32, rows32), mix32 = family_tables(p32, 1, "fp32")
-            fp32["roofline"] = roofline_entry(fam32, dom32, rows32, 1, "fp32", "r02_traffic.json")
-            fp32["step_roofline"] = {"mixed_ms": round(mix32["mixed_ms"], 3), "frac": round(mix32["mixed_ms"] / (d / 3 * 1e3), 4)}
+            fp32["roofline"] = roofline_entry(fam32, dom32, rows32, 1, "fp32", "r03_traffic.json")
+            fp32["step_roofline"] = {"mixed_ms": round(mix32["mixed_ms"], 3), "frac": round(mix32["mixed_ms"] / (d / n32 * 1e3), 4)}
         if loss_first is not None:
             bf16_loss_dev = abs(float(loss_first) - loss_first_fp32) / abs(loss_first_fp32)
 
@@ -414,7 +416,7 @@ def main():
         if main_tables[0] is not None:
             (fam, dom, rows), mix = main_tables
             roofline = roofline_entry(fam, dom, rows, ev_steps, args.precision,
-                                      "r02_traffic_bf16.json" if args.precision == "bf16" else "r02_traffic.json")
+                                      "r02_traffic_bf16.json" if args.precision == "bf16" else "r03_traffic.json")
             step_roofline = {"what": "SURVEY 8d mixed roofline: sum over the instrumented GEMM / conv / attention launches of "
                                      "max(FLOPs / MFMA peak of the launch's dtype, algorithmic bytes / 8 TB/s)",
                              "mixed_ms": round(mix["mixed_ms"], 3), "instrumented_kernel_ms": round(mix["covered_ms"], 3),
@@ -433,9 +435,10 @@ def main():
                                    f"{'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, {args.queries} queries, 92 logits, 6+6 layers, dropout {args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "weights": "random init (seeded)",
-                       "launch": ("hipGraph replay" if (launch["graph"] and args.mode == "train") else ("eager, 2 HIP streams" if wgrad_stream_default else "eager, 1 HIP stream"))
-                                 + (f" (auto: graph {launch['probe']['graph_ms']} ms vs eager {launch['probe']['eager_ms']} ms per step)"
-                                    if launch["probe"] else "")},
+                       "launch": ("hipGraph replay" if (main_choice == "graph" and args.mode == "train") else ("eager, 2 HIP streams" if wgrad_stream_default else "eager, 1 HIP stream"))
+                                 + (f" (training.fit default 'auto' probe: graph {main_probe['graph_ms']} ms vs eager {main_probe['eager_ms']} ms per step)"
+                                    if main_probe else f" (--launch {args.launch})"),
+                       "launch_probe": main_probe},
             "loss": round(loss_val, 5),
             "images_per_sec_dropout_off": round(value_nodrop, 3) if value_nodrop else None,
             "fp32": fp32,
@@ -443,6 +446,11 @@ def main():
             "bf16_vs_fp32_loss_rel_dev_first_step": (float(f"{bf16_loss_dev:.3e}") if bf16_loss_dev is not None else None),
             "roofline": roofline, "step_roofline": step_roofline, "configs": configs,
         }
+        if dp_timing is not None:      # N > 1: the gradient exchange, from HIP events at each bucket hand-over / completion (rank 0)
+            res["comm_ms"] = dp_timing["comm_ms"]
+            res["exposed_comm_ms"] = dp_timing["exposed_comm_ms"]
+            res["ranks_seen"] = dp_timing["ranks_seen"]
+            res["comm"] = dp_timing
         if not args.no_cpu_baseline and solo:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.height, args.width, threads=args.cpu_threads)

@@ -163,7 +163,8 @@ class KernelProfiler:
     """Optional HIP-event timing of the GEMM-class launches (bench.py roofline leg): events are
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
-    def __init__(self, prealloc=0):
+    def __init__(self, prealloc=0, f32=False):
+        self.f32 = f32             # the whole pass runs the exact-f32 MFMA kernels (fp32 parity mode)
         self.records = []          # (family, flops, start_event, end_event, signature, bytes)
         # event objects are created (and recorded once, which instantiates the HIP event) BEFORE the timed region:
         # creating them per launch costs more host time than the record itself
@@ -203,11 +204,13 @@ class KernelProfiler:
         torch.cuda.synchronize()
         out = {}
         for fam, flops, e0, e1, _sig, nb in self.records:
-            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mixed_s": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
             d["bytes"] += nb
+            # this launch priced on the mixed roofline: max(FLOPs / MFMA peak of its arithmetic type, bytes / 8 TB/s)
+            d["mixed_s"] += max(flops / (157.3e12 if fam.startswith("gemm_f32") or self.f32 else 2.5e15), nb / 8.0e12)
         return out
 
 
@@ -277,6 +280,10 @@ def _defer_push(rds):
         for r in rds:
             arr = (ReduceDesc * 1)(r)
             _check(load().detr_hip_splitk_reduce_many(arr, 1, _stream()), "detr_hip_splitk_reduce_many")
+        if AFTER_FLUSH is not None:
+            # the flush above reset the slab cursor, but these reductions still READ slabs above it: order the two launch
+            # streams once more, so that the other stream is not handed an overlapping slab before they have run
+            AFTER_FLUSH()
         return
     DEFER.extend(rds)
     _defer_outs.update(outs)
@@ -378,16 +385,15 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
             rd = ReduceDesc()
             d.workspace, d.workspace_bytes = slab
             d.defer_out = ctypes.pointer(rd)
-    tf = lambda v: "true" if v else "false"      # family = the kernel symbol as rocprofv3 names it (tile sizes pooled)
-    fam = (f"gemm_bf16c_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}, {tf(d.a_dtype)}, {tf(d.b_dtype)}>" if d.compute == 1
-           else f"gemm_f32_kernel<{tf(a_kcontig)}, {tf(b_kcontig)}>")
+    # family = the kernel BODY (every template instantiation -- layouts, storage types, tile sizes, grouped launches -- pooled)
+    fam = "gemm_bf16c_kernel" if d.compute == 1 else "gemm_f32_kernel"
     # mirror of gemm_stream_eligible() in csrc/gemm_f32.hip: the short-K all-bf16 GEMMs run on the streaming kernel
     if (d.compute == 1 and d.a_dtype and d.b_dtype and d.c_dtype and a_kcontig and batch == 1 and split_k == 1 and rowsum_a is None
             and K in (64, 128, 256) and N % 64 == 0 and M >= 16384 and scale is None and alpha == 1.0 and dropout_p == 0.0
             and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or (d.m_dtype and ldmask % 8 == 0))
             and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"):
         fam = "gemm_stream_bf16_kernel"          # one kernel body; its K / layout / epilogue instantiations are pooled
-    sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} sk{split_k}"
+    sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} a16{d.a_dtype} b16{d.b_dtype} sk{split_k}"
            f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")
     nbytes = float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
                              + (residual.element_size() * M * N if residual is not None else 0)

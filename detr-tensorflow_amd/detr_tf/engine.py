@@ -94,10 +94,12 @@ class DetrEngine:
         self._stem = stem_names(self.tf_backbone)
         self._pairs = bn_conv_pairs(self.blocks, self.tf_backbone)
         self._bufs = {}
+        self.buf_generation = 0          # bumped whenever buf() replaces (frees) a buffer: recorded graphs of older generations are invalid
         self._pos_cache = {}
         self._shape = None
         self.bn_scale, self.bn_shift = {}, {}
         self._weights_version, self._built = 0, {}
+        self.P.on_change = self._params_changed   # ParamStore.load / load_dict: refold the frozen BN, bump the weights version
         self.fold_bn()
         self.compute = 0                 # 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA, fp32 storage (config C3)
         self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
@@ -110,17 +112,13 @@ class DetrEngine:
         self._cross = {}
         self._graph_replay = False       # True while a captured step is being recorded / replayed (training.GraphedTrainStep)
 
-    # Derived weight copies (BN-folded kernels, the bf16 shadow) are stamped with the weights version they were built
-    # from; `engine.weights_dirty = True` (optimizers.py after every apply, load_params, fold_bn) bumps the version, so
-    # a copy is rebuilt exactly when it is next needed -- also when fp32 and bf16 passes are interleaved.
-    @property
-    def weights_dirty(self):
-        return True
-
-    @weights_dirty.setter
-    def weights_dirty(self, value):
-        if value:
-            self._weights_version += 1
+    # Derived weight copies (BN-folded kernels, the bf16 shadow, the gathered cross-attention weights) are stamped with the
+    # weights version they were built from.  EVERY mutation of the parameters bumps the version -- the optimiser after an
+    # apply, fold_bn, and ParamStore.load / load_dict themselves (through the store's on_change hook), so a direct
+    # `engine.P.load(...)` cannot leave a recorded eval graph or a bf16 shadow stale -- and a copy is rebuilt exactly when
+    # it is next needed, also when fp32 and bf16 passes are interleaved.
+    def bump_weights_version(self):
+        self._weights_version += 1
 
     def _stale(self, key):
         if self._built.get(key) == self._weights_version:
@@ -139,13 +137,23 @@ class DetrEngine:
 
     # ---- buffers ------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
+        """Named device buffer of the static memory plan.  A request with another shape / dtype REPLACES the buffer (the
+        old storage is freed: alternating train / validation shapes do not add up) and bumps `buf_generation`; every
+        recorded hipGraph remembers the generation it was captured at and is dropped when it no longer matches
+        (training.GraphedTrainStep, DetrModel._eval_forward) -- a replay would write through the freed addresses."""
         key = name
         t = self._bufs.get(key)
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            if t is not None:
+                self.buf_generation += 1
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self._bufs[key] = t
         return t
+
+    def buffer_bytes(self):
+        """Bytes held by the named buffers (activations, scratch, derived weight copies)."""
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
     def fold_bn(self):
         """custom_layers.py:21-23: scale = w * rsqrt(var + eps), shift = b - mean * scale (frozen)."""
@@ -158,7 +166,7 @@ class DetrEngine:
             self.bn_scale[p] = sc
             # a conv bias under the frozen BN moves into the shift: scale*(conv + b) + shift0 (rebuilt by _refresh_bias_shift)
             self.bn_shift[p] = self.buf(f"bnshift_eff:{p}", (c,)) if self.tf_backbone else sh
-        self.weights_dirty = True
+        self.bump_weights_version()
         self._fold_table = None
         self._shift_table = None
 
@@ -173,10 +181,11 @@ class DetrEngine:
             self._shift_table = torch.tensor(rows, dtype=torch.int64).to(self.device)
         hip.call("detr_hip_fma_vec_group", self._shift_table.data_ptr(), self._shift_table.shape[0])
 
-    def load_params(self, params):
-        missing = self.P.load_dict(params)
+    def _params_changed(self):
         self.fold_bn()
-        return missing
+
+    def load_params(self, params):
+        return self.P.load_dict(params)       # (the store's on_change hook refolds the frozen BN and bumps the weights version)
 
     def _w(self, name):
         """Weight OPERAND of a GEMM: the fp32 tensor, or -- while the bf16-compute kernels are active -- its bf16 shadow
@@ -544,7 +553,6 @@ class DetrEngine:
                 self._block_meta.append(dict(p=p, n=n, x=x, xs=xs, x1=x1, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, h1=h1, w1=w1,
                                              M1=M1, s2=s2, cin=cin, d1=d1, d2=d2, stride=stride, first=(b == 0)))
                 x, h, w, cin = out, ho, wo, d2
-        self.weights_dirty = False
         feat, Hf, Wf = x, h, w
         L = Hf * Wf
         self._feat_meta = (feat, Hf, Wf, L)

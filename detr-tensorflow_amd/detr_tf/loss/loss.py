@@ -92,6 +92,18 @@ def _prep_targets(t_bbox, t_class, device):
     return tb, tc
 
 
+def log_from_losses(vals):
+    """The reference's log dict (loss.py:23-30: main level first, then aux 0..n-1 with suffixes) as 0-d views of ONE
+    [levels, 6] tensor -- the caller passes a fresh clone, so a step's log never aliases the next step's."""
+    Lv = vals.shape[0]
+    log = {}
+    for lv in [Lv - 1] + list(range(Lv - 1)):
+        suffix = "" if lv == Lv - 1 else f"_{lv}"
+        for k, name in enumerate(LOSS_NAMES):
+            log[name + suffix] = vals[lv, k]
+    return log
+
+
 def get_losses(m_outputs, t_bbox, t_class, config):
     """loss.py:22-34.  Returns (total_loss 0-d tensor, dict name -> 0-d tensor)."""
     lg, bx = _stack_levels(m_outputs)
@@ -106,13 +118,7 @@ def get_losses(m_outputs, t_bbox, t_class, config):
         # (hungarian_matching.py:29); the device matcher records a status per problem instead of stopping the step
         if bool((sl.matcher.status != 0).any()):
             raise ValueError("cost matrix is infeasible or contains invalid numeric entries")
-    vals = losses.clone()
-    log = {}
-    order = [Lv - 1] + list(range(Lv - 1))                   # main first, then aux 0..n-1 (loss.py:23-30)
-    for lv in order:
-        suffix = "" if lv == Lv - 1 else f"_{lv}"
-        for k, name in enumerate(LOSS_NAMES):
-            log[name + suffix] = vals[lv, k]
+    log = log_from_losses(losses.clone())
     total_loss = total.clone()[0]
     if hasattr(m_outputs, "set_loss"):
         m_outputs.set_loss = sl

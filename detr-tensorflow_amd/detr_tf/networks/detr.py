@@ -84,9 +84,8 @@ class DetrModel:
         return path if path.endswith(".npz") else path + ".npz"      # np.savez appends the suffix: keep save / load symmetric
 
     def load_weights(self, path_or_dict):
-        missing = self.engine.P.load(self._npz(path_or_dict)) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
-        self.engine.fold_bn()
-        return missing
+        # (ParamStore.load / load_dict notify the engine: frozen-BN refold + weights-version bump)
+        return self.engine.P.load(self._npz(path_or_dict)) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
 
     def save_weights(self, path):
         self.engine.P.save(self._npz(path))
@@ -102,20 +101,25 @@ class DetrModel:
             return eng.forward(images, training=False)
         key = (tuple(images.shape), eng._weights_version, eng.compute)
         g = self._eval_graph
-        if g is not None and g["key"] == key:
+        # a graph addresses the engine's buffers as they were at capture: any later re-allocation (a forward of another
+        # shape in between) makes it unusable -- engine.buf_generation tells
+        if g is not None and g["key"] == key and g["gen"] == eng.buf_generation:
             g["static"].copy_(images)
             g["graph"].replay()
             return g["out"]
-        if self._eval_seen != key:              # first sighting: eager (allocates the buffers, refreshes derived weight copies)
+        if g is not None and g["gen"] != eng.buf_generation:
+            self._eval_graph = g = None
+        if self._eval_seen != (key, eng.buf_generation):
+            # first sighting of this shape with these buffers: eager (allocates the buffers, refreshes derived weight copies)
             out = eng.forward(images, training=False)
-            self._eval_seen = (tuple(images.shape), eng._weights_version, eng.compute)
+            self._eval_seen = ((tuple(images.shape), eng._weights_version, eng.compute), eng.buf_generation)
             return out
         static = g["static"] if g is not None and g["static"].shape == images.shape else torch.empty_like(images)
         static.copy_(images)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = eng.forward(static, training=False)
-        self._eval_graph = dict(key=key, static=static, graph=graph, out=out)
+        self._eval_graph = dict(key=key, static=static, graph=graph, out=out, gen=eng.buf_generation)
         graph.replay()
         return out
 

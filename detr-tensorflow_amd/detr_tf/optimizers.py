@@ -61,7 +61,7 @@ class GroupAdam:
         if not hyper_ready:
             self.set_step_hyper()
         if self.engine is not None:
-            self.engine.weights_dirty = True
+            self.engine.bump_weights_version()
         if self.n_chunks == 0:
             return
         hip.call("detr_hip_sumsq_segments_f32", grad_flat.data_ptr(), self.chunk_tensor.data_ptr(),
@@ -148,4 +148,4 @@ def aggregate_grad_and_apply(name, optimizers, gradients, step, config):
 def model_dirty(optimizers):
     eng = optimizers.get("_engine")
     if eng is not None:
-        eng.weights_dirty = True
+        eng.bump_weights_version()

@@ -54,6 +54,44 @@ class DataParallel:
         self.works = []
         self.cuda = grad_flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.timing = None               # enable_timing(): HIP events around every bucket exchange (bench.py --gpus N)
+
+    # ---- instrumentation: how much of the exchange is hidden behind the backward ------------------------------------------
+    def enable_timing(self, on=True):
+        """Record, per step, one HIP event pair around every bucket all-reduce (on the communication stream) and one around
+        the compute stream's wait in finish().  timing_summary() then reports, averaged over the recorded steps:
+        comm_ms (sum of the collectives' durations), exposed_comm_ms (what the compute stream actually waited at the end of
+        the backward = communication NOT hidden by overlap) and the per-bucket hand-over -> done latencies."""
+        self.timing = {"steps": [], "cur": []} if (on and self.cuda and self.active) else None
+
+    def _ev(self, stream):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def timing_summary(self):
+        t = self.timing
+        if not t or not t["steps"]:
+            return None
+        torch.cuda.synchronize()
+        comm = exposed = 0.0
+        per_bucket = {}
+        for buckets, w0, w1 in t["steps"]:
+            exposed += w0.elapsed_time(w1)
+            for i, handed, b0, b1 in buckets:
+                d = b0.elapsed_time(b1)
+                comm += d
+                pb = per_bucket.setdefault(i, [0.0, 0.0, 0])
+                pb[0] += d
+                pb[1] += handed.elapsed_time(b1)
+                pb[2] += 1
+        n = len(t["steps"])
+        return {"steps": n, "comm_ms": round(comm / n, 3), "exposed_comm_ms": round(exposed / n, 3),
+                "hidden_frac": round(1.0 - exposed / comm, 4) if comm > 0 else None,
+                "buckets": [{"bucket": i, "mbytes": round((self.bounds[i][1] - self.bounds[i][0]) * 4 / 1e6, 1),
+                             "allreduce_ms": round(v[0] / v[2], 3), "handover_to_done_ms": round(v[1] / v[2], 3)}
+                            for i, v in sorted(per_bucket.items())],
+                "ranks_seen": self.world}
 
     def reduce_sums(self, sums):
         """All-reduce of the loss normalisers (tiny, on the compute stream)."""
@@ -69,16 +107,30 @@ class DataParallel:
             return
         view = self.grad[lo:hi]
         if self.cuda:
+            handed = self._ev(torch.cuda.current_stream()) if self.timing is not None else None
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                b0 = self._ev(self.comm_stream) if handed is not None else None
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if handed is not None:
+                    # RCCL enqueues the collective on this stream: the event behind it marks its completion (a host-side
+                    # transport such as gloo completes in finish(): the end event is re-recorded there)
+                    self.timing["cur"].append([i, handed, b0, self._ev(self.comm_stream)])
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket."""
-        for w in self.works:
+        timing = self.timing is not None and self.cuda and bool(self.works)
+        w0 = self._ev(torch.cuda.current_stream()) if timing else None
+        host_side = dist.is_initialized() and dist.get_backend(self.group) != "nccl"
+        for k, w in enumerate(self.works):
             w.wait()
+            if timing and host_side and k < len(self.timing["cur"]):
+                self.timing["cur"][k][3] = self._ev(self.comm_stream)
         self.works = []
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timing:
+            self.timing["steps"].append((self.timing["cur"], w0, self._ev(torch.cuda.current_stream())))
+            self.timing["cur"] = []

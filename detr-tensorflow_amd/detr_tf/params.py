@@ -179,6 +179,7 @@ class ParamStore:
         self.views = {k: self.flat[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
         self.gviews = {k: self.grad[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
         self.flat16, self.views16 = None, None      # bf16 shadow of `flat` (bf16 compute mode; refreshed by the engine)
+        self.on_change = None            # called after every mutation of the parameters (the engine's weights-version bump)
         # frozen BN raw vectors [4, C] per layer: weight, bias, running_mean, running_var
         self.bn_raw = {p: torch.zeros(4, c, dtype=torch.float32, device=device) for p, c in self.bn.items()}
         for p in self.bn_raw:
@@ -237,6 +238,8 @@ class ParamStore:
                     self.bn_raw[p][i].copy_(torch.as_tensor(np.asarray(params[f"{p}/{leaf}"]), dtype=torch.float32))
                 else:
                     missing.append(f"{p}/{leaf}")
+        if self.on_change is not None:
+            self.on_change()
         return missing
 
     def state_dict(self):

@@ -12,7 +12,7 @@ import time
 import torch
 
 from . import _hip as hip
-from .loss.loss import get_losses
+from .loss.loss import get_losses, log_from_losses
 from .optimizers import GROUPS, aggregate_grad_and_apply, gather_gradient
 
 PRINT_EVERY_TRAIN = 100         # training.py:57
@@ -87,27 +87,47 @@ class _Segments:
 
 
 class GraphedTrainStep:
-    """train_step() for a fixed batch shape, recorded once as hipGraph(s) and replayed.
+    """train_step() for a fixed batch shape, with the launch path chosen by `launch`:
+
+      "graph"  the step is recorded once as hipGraph(s) and replayed;
+      "eager"  one launch call per kernel on two HIP streams (train_step);
+      "auto"   (default of `fit`) both: after the eager warm-up step and the recording pass, PROBE_STEPS steps of each are
+               timed (they are ordinary training steps) and the faster path is kept -- which one wins depends on the host:
+               replay is one call per step but hipGraph serialises most of the second stream's work, the eager step keeps
+               the overlap but needs a host that issues ~600 launches in < 19 ms.  Data-parallel ranks agree through a MAX
+               all-reduce of the two timings.  `choice` / `probe` say what was decided (bench.py prints them).
 
     The first `eager_steps` calls run eagerly (they also allocate every buffer of the static memory plan); the next call
     records the launch sequence -- forward, set loss, backward into one graph (cut at the data-parallel exchange points
-    when training on several GPUs), clip + Adam of the three groups into another -- and from then on a step is: copy the
-    batch into the static input buffers, write the new dropout seed / Adam step sizes to device memory, replay.
-    A new batch shape (or set of trained groups) is recorded afresh after one eager step; gradient accumulation runs eagerly."""
+    when training on several GPUs), clip + Adam of the three groups into another -- and from then on a replayed step is:
+    copy the batch into the static input buffers, write the new dropout seed / Adam step sizes to device memory, replay.
+    A new batch shape (or set of trained groups), and any re-allocation of an engine buffer since the recording (a forward
+    of another shape in between: engine.buf_generation), drop the recording: one eager step, then a new one.  Gradient
+    accumulation and `config.check_matching` (a host synchronisation inside the loss) run eagerly.
+    Every call returns FRESH loss / log tensors (clones of the static ones), like the eager path and the reference."""
 
-    def __init__(self, model, optimizers, config, eager_steps=1):
+    PROBE_STEPS = 3
+
+    def __init__(self, model, optimizers, config, eager_steps=1, launch="graph"):
+        assert launch in ("graph", "eager", "auto")
         self.model, self.optimizers, self.config = model, optimizers, config
         self.eager_steps = max(1, int(eager_steps))
+        self.launch = launch
         self.calls = 0
         self.key = None
         self.step_graph = self.apply_graph = None
         self.static = None
         self.result = None
+        self._gen = -1
+        self.choice = "eager" if launch == "eager" else "graph"       # the path steady-state steps take
+        self.probe = None                                              # {"graph_ms", "eager_ms"} once "auto" has decided
+        self._probe_t = {}
 
     def _signature(self, images, t_bbox, t_class):
         c = self.config
         return (tuple(images.shape), tuple(t_bbox.shape), bool(c.train_backbone), bool(c.train_transformers),
-                bool(c.train_nlayers), int(c.background_class), self.model.engine.compute, float(self.model.engine.dropout_p))
+                bool(c.train_nlayers), int(c.background_class), self.model.engine.compute, float(self.model.engine.dropout_p),
+                bool(getattr(c, "check_matching", False)))
 
     def _capture(self, images, t_bbox, t_class):
         model, opts, cfg = self.model, self.optimizers, self.config
@@ -122,7 +142,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         eng._graph_replay = True
-        eng.weights_dirty = True            # the derived weight copies are rebuilt inside the recorded step, as in every eager step
+        eng.bump_weights_version()          # the derived weight copies are rebuilt inside the recorded step, as in every eager step
         prev_hooks = None
         try:
             with torch.cuda.stream(side):
@@ -152,7 +172,8 @@ class GraphedTrainStep:
             eng._graph_replay = False
         torch.cuda.current_stream().wait_stream(side)
         self.step_graph, self.apply_graph = seg, app
-        self.result = (m_outputs, total_loss, log)
+        self.result = (m_outputs, m_outputs.set_loss)
+        self._gen = eng.buf_generation
 
     def _load_inputs(self, images, t_bbox, t_class):
         st_img, st_tb, st_tc = self.static
@@ -164,15 +185,8 @@ class GraphedTrainStep:
         if not (tc.is_cuda and tc.data_ptr() == st_tc.data_ptr()):
             st_tc.copy_(tc.reshape(st_tc.shape), non_blocking=True)
 
-    def __call__(self, images, t_bbox, t_class, epoch_step):
+    def _replay(self, images, t_bbox, t_class):
         cfg, model = self.config, self.model
-        key = self._signature(images, t_bbox, t_class)
-        if key != self.key:                 # new batch shape / trained groups / precision: eager warm-up, then record again
-            self.key, self.calls = key, 0
-            self.step_graph = self.apply_graph = self.result = None
-        self.calls += 1
-        if _gradient_aggregate(cfg) > 1 or self.calls <= self.eager_steps:
-            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         if self.step_graph is None:
             self._capture(images, t_bbox, t_class)
         else:
@@ -191,18 +205,83 @@ class GraphedTrainStep:
             self.apply_graph.replay()
         finally:
             eng._graph_replay = False
-        eng.weights_dirty = True                                   # the parameters moved: derived copies are stale for eager passes
-        m_outputs, total_loss, log = self.result
+        eng.bump_weights_version()                                 # the parameters moved: derived copies are stale for eager passes
+        m_outputs, sl = self.result
+        # fresh tensors per step (two small device copies): a caller that keeps per-step losses must not end up with N
+        # aliases of the static tensors the graph writes
+        log = log_from_losses(sl.losses.clone())
+        total_loss = sl.total.clone()[0]
         for name in GROUPS:
             log[f"{name}_lr"] = self.optimizers[f"{name}_optimizer"].learning_rate()
         return m_outputs, total_loss, log
 
+    def _decide(self):
+        tg, te = self._probe_t["graph"], self._probe_t["eager"]
+        dp = self.model.dp
+        if dp is not None and getattr(dp, "active", False):
+            import torch.distributed as dist
+            tt = torch.tensor([tg, te], dtype=torch.float64, device=self.model.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tg, te = (float(v) for v in tt.tolist())
+        self.choice = "graph" if tg <= te else "eager"
+        n = self.PROBE_STEPS
+        self.probe = {"graph_ms": round(tg / n * 1e3, 3), "eager_ms": round(te / n * 1e3, 3)}
 
-def _use_graph(config):
+    def __call__(self, images, t_bbox, t_class, epoch_step):
+        cfg, model = self.config, self.model
+        eng = model.engine
+        key = self._signature(images, t_bbox, t_class)
+        stale = self.step_graph is not None and self._gen != eng.buf_generation
+        if key != self.key or stale:        # new batch shape / trained groups / precision, or the recorded buffers are gone
+            self.key, self.calls = key, 0
+            self.step_graph = self.apply_graph = self.result = None
+            self.probe, self._probe_t = None, {}
+            self.choice = "eager" if self.launch == "eager" else "graph"
+        self.calls += 1
+        eager_only = (self.launch == "eager" or _gradient_aggregate(cfg) > 1 or bool(getattr(cfg, "check_matching", False)))
+        if eager_only or self.calls <= self.eager_steps:
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
+        if self.launch != "auto" or self.probe is not None:
+            if self.choice == "graph":
+                return self._replay(images, t_bbox, t_class)
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
+        # ---- "auto", still probing: call eager_steps + 1 records, then PROBE_STEPS timed replays, then PROBE_STEPS timed eager steps
+        i = self.calls - self.eager_steps - 1          # 0 = the recording pass
+        n = self.PROBE_STEPS
+        if i == 0:
+            return self._replay(images, t_bbox, t_class)
+        phase = "graph" if i <= n else "eager"
+        first, last = (i - 1) % n == 0, (i - 1) % n == n - 1
+        if first:
+            torch.cuda.synchronize()
+            self._probe_t[phase] = time.perf_counter()
+        out = self._replay(images, t_bbox, t_class) if phase == "graph" else \
+            train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
+        if last:
+            torch.cuda.synchronize()
+            self._probe_t[phase] = time.perf_counter() - self._probe_t[phase]
+            if phase == "eager":
+                self._decide()
+        return out
+
+    @property
+    def settle_calls(self):
+        """Calls after which the launch path is final (bench.py warms up at least this long)."""
+        return self.eager_steps + 1 + (2 * self.PROBE_STEPS if self.launch == "auto" else 0)
+
+
+def _launch_mode(config):
+    """How `fit` launches a step: config.launch ("auto" | "graph" | "eager") if set; else the legacy switches config.use_graph /
+    env DETR_HIP_GRAPH (0 = eager, 1 = graph); else "auto"."""
+    mode = getattr(config, "launch", None)
+    if mode in ("auto", "graph", "eager"):
+        return mode
     flag = getattr(config, "use_graph", None)
+    if flag is None and os.environ.get("DETR_HIP_GRAPH") is not None:
+        flag = os.environ["DETR_HIP_GRAPH"] != "0"
     if flag is None:
-        flag = os.environ.get("DETR_HIP_GRAPH", "1") != "0"
-    return bool(flag)
+        return "auto"
+    return "graph" if flag else "eager"
 
 
 def _console(prefix, log, elapsed):
@@ -228,16 +307,16 @@ class _Stopwatch:
 
 def fit(model, train_dt, optimizers, config, epoch_nb, class_names):
     """Train the model for one epoch (training.py:35-65); same console line every 100 steps, `config.global_step`
-    advanced once per batch.  `config.use_graph` (default on, env DETR_HIP_GRAPH=0 disables) replays the step as a hipGraph."""
-    stepper = optimizers.get("_graphed_step") if _use_graph(config) else None
-    if _use_graph(config) and stepper is None:
-        stepper = optimizers["_graphed_step"] = GraphedTrainStep(model, optimizers, config)
+    advanced once per batch.  Launch path: `config.launch` = "auto" (default: GraphedTrainStep probes hipGraph replay against the
+    eager two-stream step during the first steps and keeps the faster), "graph" or "eager" (legacy: config.use_graph /
+    DETR_HIP_GRAPH=0|1)."""
+    mode = _launch_mode(config)
+    stepper = optimizers.get("_graphed_step")
+    if stepper is None or stepper.launch != mode or stepper.model is not model:
+        stepper = optimizers["_graphed_step"] = GraphedTrainStep(model, optimizers, config, launch=mode)
     watch = _Stopwatch(reset=True)
     for epoch_step, (images, t_bbox, t_class) in enumerate(train_dt):
-        if stepper is not None:
-            m_outputs, total_loss, log = stepper(images, t_bbox, t_class, epoch_step)
-        else:
-            m_outputs, total_loss, log = train_step(model, images, t_bbox, t_class, optimizers, config, epoch_step)
+        m_outputs, total_loss, log = stepper(images, t_bbox, t_class, epoch_step)
         if epoch_step % PRINT_EVERY_TRAIN == 0:
             print(_console(f"Epoch: [{epoch_nb}], \t Step: [{epoch_step}]", log, watch.lap()))
         config.global_step += 1

@@ -40,11 +40,11 @@ if len(sys.argv) >= 4:
             f = v.get("FETCH_SIZE", (0, 0)); w = v.get("WRITE_SIZE", (0, 0))
             n += max(f[0], w[0]); fetch += f[1]; write += w[1]
     def fold(name):
-        """rocprofv3 kernel name -> the family name detr_tf/_hip.py reports (tile sizes pooled, grouped launches folded into
-        their base kernel, every instantiation of the streaming kernel pooled)."""
-        m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group)?_kernel<\d+, \d+, \d+, \d+, ([^>]*)>", name)
+        """rocprofv3 kernel name -> the family name detr_tf/_hip.py reports: one kernel BODY with every template instantiation
+        pooled (layouts, storage types, tile sizes; grouped launches folded into their base kernel)."""
+        m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group)?_kernel<", name)
         if m:
-            return f"{m.group(1)}_kernel<{m.group(2)}>"
+            return f"{m.group(1)}_kernel"
         if "detr::gemm_stream_bf16_kernel" in name:
             return "gemm_stream_bf16_kernel"
         return None

@@ -312,7 +312,7 @@ def test_interleaved_fp32_and_bf16_passes_rebuild_their_weight_copies(hip):
         training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], 0, cfg)
     a32 = fwd(0)                      # fp32 pass first: must not leave the bf16 copies looking fresh
     a16 = fwd(1)
-    eng.weights_dirty = True          # force every derived copy to be rebuilt
+    eng.bump_weights_version()          # force every derived copy to be rebuilt
     b16, b32 = fwd(1), fwd(0)
     torch.cuda.synchronize()
     assert torch.equal(a16, b16) and torch.equal(a32, b32)

@@ -140,7 +140,7 @@ def test_graph_replay_equals_eager_steps(hip, precision):
         for src, dst in ((m_e.engine.P.flat, m_g.engine.P.flat), (m_e.engine.P.adam_m, m_g.engine.P.adam_m),
                          (m_e.engine.P.adam_v, m_g.engine.P.adam_v)):
             dst.copy_(src)
-        m_g.engine.weights_dirty = True
+        m_g.engine.bump_weights_version()
         before = m_e.engine.P.flat.clone()
         out_e, tot_e, log_e = training.train_step(m_e, im, tb, tc, o_e, cfg_e, i)
         lg_e = out_e["pred_logits"].clone()
