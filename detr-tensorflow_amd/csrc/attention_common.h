@@ -86,7 +86,7 @@ static int attn_from_desc(const detr_attn_desc *d, int bwd, AttnArgs &a) {
 // waves per workgroup: 4 waves (128 rows) amortise the K/V tile loads best, but the grid must still balance over
 // 256 CUs -- below ~8 workgroups per CU the 2-wave kernels (twice the workgroups) win.  DETR_HIP_ATTN_WAVES forces.
 static int attn_waves(int rows, int bh) {
-    const int force = env_tile("DETR_HIP_ATTN_WAVES");
+    const int force = tune(T_ATTN_WAVES);
     if (force == 2 || force == 4) return force;
     return ((long long)cdiv(rows, 128) * bh < 2048) ? 2 : 4;
 }

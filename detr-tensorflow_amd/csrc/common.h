@@ -68,11 +68,27 @@ __device__ __forceinline__ void lds_barrier() {
 }
 #endif
 
-// tuning hook: integer environment variable (0 when unset)
-static inline int env_tile(const char *name) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : 0;
-}
+// Tuning hooks: the integer environment variables DETR_HIP_<NAME> (0 when unset).  They are read ONCE, when the library is
+// loaded -- never on the launch path (getenv is not safe against a concurrent setenv, and a launch should not cost a dozen
+// environment scans) -- and again only on an explicit detr_hip_reload_tuning() (tests / tuning scripts that change a
+// variable inside the process).
+enum TuneKey {
+    T_GEMM_TILE,
+    T_SPLIT_XCD,
+    T_GEMM_STREAM,
+    T_GEMM_GROUP,
+    T_STREAM_SL,
+    T_CONV_HALO,
+    T_CONV_TILE,
+    T_DGRAD_S2_CLASSES,
+    T_WGRAD_FUSED,
+    T_WGRAD_FUSED_WGS,
+    T_WGRAD_TILE,
+    T_STEM_ROWS,
+    T_ATTN_WAVES,
+    T_COUNT
+};
+int tune(TuneKey k);
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

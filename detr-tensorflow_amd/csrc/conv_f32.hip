@@ -1107,22 +1107,39 @@ static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     else hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
 }
 
+// row splits of the per-tap weight gradient (tiles = (Ci / BM) * (Co / BN) output tiles per tap) and of the fused nine-tap one
+static int wgrad_split_plan(int M, int tiles, int split, int &rps) {
+    if (split <= 0) {
+        split = cdiv(1536, tiles * 9);
+        const int max_split = cdiv(M, 256);
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    rps = cdiv(M, split);
+    rps = ((rps + BF_BK - 1) / BF_BK) * BF_BK;       // multiple of both K tiles (16 and 32)
+    return cdiv(M, rps);
+}
+static int wgrad_fused_split_plan(int units, int tiles, int split, int &ups) {
+    if (split <= 0) {
+        int wgs = tune(T_WGRAD_FUSED_WGS);      // tuning hook: target workgroup count (512 measured best: 2 per CU)
+        if (wgs <= 2) wgs = 512;
+        split = cdiv(wgs, tiles);
+    }
+    if (split > units) split = units;
+    if (split < 1) split = 1;
+    ups = cdiv(units, split);
+    return cdiv(units, ups);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false) {
     ConvWgradArgs a = a0;
     a.tiles_m = cdiv(a.Ci, BM);
     a.tiles_n = cdiv(a.Co, BN);
     const int tiles = a.tiles_m * a.tiles_n;
-    if (split <= 0) {
-        split = cdiv(1536, tiles * 9);
-        const int max_split = cdiv(a.M, 256);
-        if (split > max_split) split = max_split;
-        if (split < 1) split = 1;
-    }
-    int rps = cdiv(a.M, split);
-    rps = ((rps + BF_BK - 1) / BF_BK) * BF_BK;       // multiple of both K tiles (16 and 32)
+    int rps;
+    split = wgrad_split_plan(a.M, tiles, split, rps);
     a.rows_per_split = rps;
-    split = cdiv(a.M, rps);
     const long long part = 9LL * a.Ci * a.Co;
     const bool partial = split > 1 && ws && aligned16(ws) && ws_bytes >= (long long)split * part * 4;
     float *dw_final = a.dw;
@@ -1153,15 +1170,8 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
     const int tiles = a.tiles_m * a.tiles_n;
     const int chunks = cdiv(a.Wo, 32);
     const int units = a.N * a.Ho * chunks;
-    if (split <= 0) {
-        int wgs = env_tile("DETR_HIP_WGRAD_FUSED_WGS");      // tuning hook: target workgroup count (512 measured best: 2 per CU)
-        if (wgs <= 2) wgs = 512;
-        split = cdiv(wgs, tiles);
-    }
-    if (split > units) split = units;
-    if (split < 1) split = 1;
-    const int ups = cdiv(units, split);
-    split = cdiv(units, ups);
+    int ups;
+    split = wgrad_fused_split_plan(units, tiles, split, ups);
     const long long part = 9LL * a.Ci * a.Co;
     const bool partial = split > 1 && ws && aligned16(ws) && ws_bytes >= (long long)split * part * 4;
     float *dw_final = a.dw;
@@ -1186,6 +1196,27 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
 }  // namespace detr
 
 using namespace detr;
+
+static bool wgrad_is_fused(const detr_conv3x3_desc *d) {
+    const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
+    return bf && d->stride == 1 && d->pad == 1 && d->Ci % 64 == 0 && d->Co % 64 == 0 && tune(T_WGRAD_FUSED) != 2;
+}
+
+extern "C" int64_t detr_hip_workspace_bytes_conv3x3(const detr_conv3x3_desc *d, int32_t mode) {
+    if (!d || d->N <= 0 || d->Ci <= 0 || d->Co <= 0) return -1;
+    if (mode != 2) return 0;                       // forward / input gradient: no scratch
+    const long long part = 9LL * d->Ci * d->Co;
+    int split, aux;
+    if (wgrad_is_fused(d)) {
+        split = wgrad_fused_split_plan(d->N * d->Ho * cdiv(d->Wo, 32), (d->Ci / 64) * (d->Co / 64), d->split, aux);
+    } else {
+        const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
+        const int wforce = bf ? 0 : tune(T_WGRAD_TILE);
+        const int t = (wforce == 3) ? 64 : ((wforce == 1 || (d->Ci >= 128 && d->Co >= 128)) ? 128 : 64);
+        split = wgrad_split_plan(d->N * d->Ho * d->Wo, cdiv(d->Ci, t) * cdiv(d->Co, t), d->split, aux);
+    }
+    return split > 1 ? (int64_t)split * part * 4 : 0;
+}
 
 extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream) {
     DETR_REQUIRE(d != nullptr, "conv3x3: null descriptor");
@@ -1226,7 +1257,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         e.atomic = 1; e.ldr = 0; e.ldmask = 0;
         a.e = e;
         const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
-        if (bf && d->stride == 1 && d->pad == 1 && d->Ci % 64 == 0 && d->Co % 64 == 0 && env_tile("DETR_HIP_WGRAD_FUSED") != 2) {
+        if (wgrad_is_fused(d)) {
             launch_wgrad_fused(a, d->split, d->workspace, d->workspace_bytes, s);
             DETR_LAUNCH_CHECK("conv3x3 wgrad bf16 (fused taps)");
             return 0;
@@ -1237,7 +1268,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
             DETR_LAUNCH_CHECK("conv3x3 wgrad bf16");
             return 0;
         }
-        const int wforce = env_tile("DETR_HIP_WGRAD_TILE");
+        const int wforce = tune(T_WGRAD_TILE);
         if (wforce == 3) launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         else if (wforce == 1) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
         else if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
@@ -1272,13 +1303,13 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     // 256-pixel tile does not reduce there.
     if (d->compute == 1 && d->stride == 1 && d->pad == 1 && a.w16 && a.x16 && e.c16 && a.Cs % 32 == 0 && a.Cd % 64 == 0 &&
         a.Cd <= 256 && (!d->mask || e.m16) && !d->residual && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) &&
-        env_tile("DETR_HIP_CONV_HALO") != 2) {
+        tune(T_CONV_HALO) != 2) {
         if (a.Cd >= 128) { if (launch_conv_halo<128>(a, dgrad, s)) return -1; }
         else if (launch_conv_halo<64>(a, dgrad, s)) return -1;
         DETR_LAUNCH_CHECK("conv3x3 (halo)");
         return 0;
     }
-    const int force = env_tile("DETR_HIP_CONV_TILE");     // tuning hook; 0 = heuristic
+    const int force = tune(T_CONV_TILE);     // tuning hook; 0 = heuristic
     auto launch = [&](const ConvArgs &c) {
         const long long big = (long long)cdiv(c.M, 128) * cdiv(c.Cd, 128);
         if (d->compute == 1 && c.Cs % 32 == 0 && c.Cd % 32 == 0) {
@@ -1289,7 +1320,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         else if (force == 2) launch_conv<128, 64, 2, 2>(c, dgrad, s);
         else launch_conv<64, 64, 2, 2>(c, dgrad, s);   // 64x64 measured best on every backbone shape (profiles/tune_r1.txt)
     };
-    if (dgrad && d->stride == 2 && env_tile("DETR_HIP_DGRAD_S2_CLASSES") != 2) {
+    if (dgrad && d->stride == 2 && tune(T_DGRAD_S2_CLASSES) != 2) {
         // one launch per destination-pixel parity class: 1 + 2 + 2 + 4 tap-GEMMs instead of 9 with 3/4 of the rows masked
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {

@@ -504,19 +504,33 @@ struct GemmPlan {
     const detr_gemm_desc *d;
 };
 
+// split count a GEMM really runs with: no empty splits (recomputed from the K tiles each split gets)
+static int gemm_effective_split(const detr_gemm_desc *d) {
+    int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > 1) {
+        const int nkt = cdiv(d->K, d->compute == 1 ? BF_BK : GEMM_BK);
+        const int per = cdiv(nkt, split);
+        split = cdiv(nkt, per);
+    }
+    return split;
+}
+
+extern "C" int64_t detr_hip_workspace_bytes_gemm(const detr_gemm_desc *d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return -1;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    const int split = gemm_effective_split(d);
+    if (split <= 1 || batch != 1) return 0;          // (batched split-K accumulates with atomics: no scratch)
+    return (int64_t)split * ((int64_t)d->M * d->N + (d->rowsum_a ? d->M : 0)) * 4;
+}
+
 static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     DETR_REQUIRE(d != nullptr, "gemm: null descriptor");
     DETR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
     DETR_REQUIRE(d->A && d->B && d->C, "gemm: null operand");
     const int batch = d->batch > 0 ? d->batch : 1;
     const int inner = d->batch_inner > 0 ? d->batch_inner : 1;
-    int split = d->split_k > 1 ? d->split_k : 1;
     const bool bf16c = d->compute == 1;
-    if (split > 1) {   // no empty splits: recompute the effective count from the K tiles each split gets
-        const int nkt = cdiv(d->K, bf16c ? BF_BK : GEMM_BK);
-        const int per = cdiv(nkt, split);
-        split = cdiv(nkt, per);
-    }
+    int split = gemm_effective_split(d);
     if (split > 1) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0,
                      "gemm: split_k allows only scale/alpha in the epilogue");
@@ -587,7 +601,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     g.rowsum_partial = 0;
     g.b16 = d->b_dtype == 1;
     g.a16 = d->a_dtype == 1;
-    g.split_xcd = env_tile("DETR_HIP_SPLIT_XCD") != 2;
+    g.split_xcd = tune(T_SPLIT_XCD) != 2;
     EpiArgs final_e = g.e;
     if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;
@@ -603,7 +617,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
         }
     }
     // tile selection
-    const int force = env_tile("DETR_HIP_GEMM_TILE");     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
+    const int force = tune(T_GEMM_TILE);     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
     int tile = 0;
     if (bf16c) {
         // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
@@ -643,7 +657,7 @@ static bool gemm_stream_eligible(const GemmPlan &p) {
     if (!(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C))) return false;
     const long long span = (long long)(d->M - 1) * (d->ldr > d->ldmask ? d->ldr : d->ldmask) + d->N;
     if (span * 2 > BUF_MAX_BYTES) return false;
-    return env_tile("DETR_HIP_GEMM_STREAM") != 2;
+    return tune(T_GEMM_STREAM) != 2;
 }
 
 static void gemm_stream_launch(const GemmPlan &p, hipStream_t s) {
@@ -728,7 +742,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         for (int i = 0; i < m; ++i)
             if (gemm_prepare(descs + done + i, p[i])) return -1;
         // one launch needs ONE kernel variant: 64x64 tiles, same layouts / storage types, no batch; members may differ in shape
-        bool same = m > 1 && env_tile("DETR_HIP_GEMM_GROUP") != 2;
+        bool same = m > 1 && tune(T_GEMM_GROUP) != 2;
         for (int i = 0; i < m && same; ++i)
             same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
                    p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&

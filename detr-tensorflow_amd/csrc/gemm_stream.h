@@ -288,7 +288,7 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
     // (in the step, HIP events: K = 256 without a residual / mask epilogue is SLOWER with 2 slices -- 102 KB of LDS, one workgroup per
     //  CU: M133600 N512 0.091 -> 0.120 ms -- so K = 256 groups only the epilogue-heavy form)
     int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : ((a.res && a.mask && a.N <= 512) ? 2 : 1));
-    const int force = env_tile("DETR_HIP_STREAM_SL");
+    const int force = tune(T_STREAM_SL);
     if (force == 1 || force == 2 || force == 4) sl = force;
     while (sl > 1 && (a.N % (64 * sl) != 0 || (int)sizeof(StreamSmem<K, 1>) + (sl - 1) * 64 * (K + 8) * 2 > 160 * 1024)) sl >>= 1;
     if (sl == 4) {

@@ -327,6 +327,11 @@ extern "C" int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream
     return 0;
 }
 
+extern "C" int64_t detr_hip_workspace_bytes_layernorm(const detr_layernorm_desc *d) {
+    if (!d || d->rows <= 0 || d->C <= 0) return -1;
+    return (int64_t)min(cdiv(d->rows, 8), 512) * 2 * d->C * 4;       // per-block gamma / beta partials of the backward
+}
+
 extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream) {
     DETR_REQUIRE(d && d->dy && d->x && d->gamma && d->mean && d->rstd && d->dx && d->dgamma && d->dbeta, "layernorm bwd: null operand");
     const int C = d->C, rows = d->rows;

@@ -505,6 +505,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void stem_wgrad_rows_bf16_kernel(S
 
 using namespace detr;
 
+extern "C" int64_t detr_hip_workspace_bytes_stem(const detr_stem_desc *d, int32_t mode) {
+    if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return -1;
+    if (mode != 2) return 0;
+    const long long part = (long long)STEM_K * 64;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    if (d->compute == 1 && d->w_dtype == 1 && M * 64 * 2 <= BUF_MAX_BYTES && tune(T_STEM_ROWS) != 2) {
+        const int nunits = d->N * d->Ho * cdiv(d->Wo, SW_TW);        // the row-staging kernel: one partial per workgroup
+        return (int64_t)(nunits < 768 ? nunits : 768) * part * 4;
+    }
+    int split = d->split > 0 ? d->split : 1;
+    const int bk = d->compute == 1 ? BF_BK : GEMM_BK;
+    const int rps = cdiv(cdiv(M, split), bk) * bk;
+    split = cdiv(M, rps);
+    return split > 1 ? (int64_t)split * part * 4 : 0;
+}
+
 extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, void *stream) {
     DETR_REQUIRE(d != nullptr, "stem conv: null descriptor");
     DETR_REQUIRE(mode == 0 || mode == 2, "stem conv: mode %d (0 = forward, 2 = weight gradient)", mode);
@@ -530,7 +546,7 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
         dim3 grid((unsigned)cdiv(a.M, 64));
         // bf16 output, folded scale: the row-staging kernel (DETR_HIP_STEM_ROWS=2: the gathering kernel)
         if (bf && e.c16 && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) && (!d->bias || aligned16(d->bias)) &&
-            env_tile("DETR_HIP_STEM_ROWS") != 2) {
+            tune(T_STEM_ROWS) != 2) {
             const int tiles_w = cdiv(a.Wo, SR_TW), ntiles = a.N * a.Ho * tiles_w;
             const int wgs = ntiles < 768 ? ntiles : 768;
             hipLaunchKernelGGL(stem_fwd_rows_bf16_kernel, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, a, tiles_w, ntiles);
@@ -550,7 +566,7 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
         const int wgs = nunits < 768 ? nunits : 768;
         const long long part = (long long)STEM_K * 64;
         if (bf && d->w_dtype == 1 && d->workspace && aligned16(d->workspace) && d->workspace_bytes >= (long long)wgs * part * 4 &&
-            (long long)a.M * 64 * 2 <= BUF_MAX_BYTES && env_tile("DETR_HIP_STEM_ROWS") != 2) {
+            (long long)a.M * 64 * 2 <= BUF_MAX_BYTES && tune(T_STEM_ROWS) != 2) {
             a.dw = d->workspace;
             a.part_stride = part;
             hipLaunchKernelGGL(stem_wgrad_rows_bf16_kernel, dim3((unsigned)wgs), dim3(GEMM_THREADS), 0, s, a, chunks, nunits);

@@ -108,6 +108,8 @@ class SetLossDesc(Structure):
 # name -> argtypes (every function returns int)
 _SIGNATURES = {
     "detr_hip_abi_version": [],
+    "detr_hip_reload_tuning": [],
+    "detr_hip_struct_layout": [c_int32, POINTER(c_int32), c_int32],
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_gemm_group_f32": [POINTER(GemmDesc), c_int32, c_void_p],
@@ -154,7 +156,17 @@ _SIGNATURES = {
     "detr_hip_axpy_f32": [f32p, f32p, c_float, c_int64, c_void_p],
     "detr_hip_set_floats8_f32": [f32p] + [c_float] * 8 + [c_void_p],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["detr_hip_last_error"])
+# scratch sizing queries (return int64 bytes)
+_SIGNATURES_I64 = {
+    "detr_hip_workspace_bytes_gemm": [POINTER(GemmDesc)],
+    "detr_hip_workspace_bytes_conv3x3": [POINTER(Conv3x3Desc), c_int32],
+    "detr_hip_workspace_bytes_stem": [POINTER(StemDesc), c_int32],
+    "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
+ABI_VERSION = 4
+# order of detr_hip_struct_layout's `which`
+LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 
 _lib = None
 
@@ -225,30 +237,73 @@ COMPUTE_BF16 = 0      # default compute mode of gemm / conv3x3: 0 = exact fp32 M
 WORKSPACE = None      # fp32 scratch tensor for the deterministic split-K reductions (set by the engine)
 
 
-def ensure_workspace(device, floats=64 * 1024 * 1024):
-    """One shared 256 MB scratch buffer: all launches are ordered on one stream, so sharing is safe."""
-    global WORKSPACE
-    if WORKSPACE is None or WORKSPACE.device != torch.device(device) or WORKSPACE.numel() < floats:
+WS_GENERATION = 0     # bumped whenever the shared scratch is replaced: recorded hipGraphs that address the old one are stale
+_WS_RETIRED = []      # outgrown scratch tensors: kept until the next backward pass begins (launches on either stream may still read them)
+_DEVICE = None
+
+
+def ensure_workspace(device, floats=2 * 1024 * 1024):
+    """Shared scratch of the immediate (non-queued) deterministic split reductions: starts small and grows to what the
+    launches ask for (need_workspace; sizes come from detr_hip_workspace_bytes_*), instead of a fixed 256 MB."""
+    global WORKSPACE, _DEVICE, WS_GENERATION
+    _DEVICE = torch.device(device)
+    if WORKSPACE is None or WORKSPACE.device != _DEVICE or WORKSPACE.numel() < floats:
+        if WORKSPACE is not None:
+            _WS_RETIRED.append(WORKSPACE)
+            WS_GENERATION += 1
         WORKSPACE = torch.empty(floats, dtype=torch.float32, device=device)
     return WORKSPACE
 
 
+def need_workspace(nbytes):
+    """Grow the shared scratch to at least nbytes (geometric steps; only ever happens in the first passes over a shape --
+    a recorded hipGraph replays shapes an eager pass has already sized)."""
+    if WORKSPACE is not None and nbytes > WORKSPACE.numel() * 4:
+        ensure_workspace(WORKSPACE.device, max((int(nbytes) + 3) // 4, WORKSPACE.numel() * 3 // 2))
+    return WORKSPACE
+
+
+def workspace_bytes_held():
+    """Scratch currently held by this module (shared workspace + slab pool of the queued reductions)."""
+    n = WORKSPACE.numel() * 4 if WORKSPACE is not None else 0
+    return n + sum(t.numel() * 4 for t in _DEFER_CHUNKS) + sum(t.numel() * 4 for t in _WS_RETIRED)
+
+
+_WS_NEED = {}
+
+
+def _ws_query(fn, key, *args):
+    """detr_hip_workspace_bytes_* through a per-shape cache (one ctypes call per distinct shape, none per launch)."""
+    v = _WS_NEED.get(key)
+    if v is None:
+        v = int(getattr(load(), fn)(*args))
+        if v < 0:
+            raise RuntimeError(f"{fn} rejected the descriptor: {load().detr_hip_last_error().decode()}")
+        _WS_NEED[key] = v
+    return v
+
+
 DEFER_LIMIT = int(os.environ.get("DETR_HIP_DEFER_MB", "512")) * 1024 * 1024     # pending slab bytes that trigger a flush
+DEFER_CHUNK = 64 * 1024 * 1024     # the slab pool grows in chunks of this size (a larger slab gets a chunk of its own)
+_DEFER_CHUNKS = []                 # device tensors; a flush rewinds the cursor to chunk 0, nothing is freed
+_defer_chunk_i = 0
 
 
 def ensure_defer_workspace(device):
-    """Slab pool of the queued split-K reductions: twice the flush threshold (a launch may overshoot it by its own slabs)."""
-    global DEFER_WS
-    nbytes = 2 * DEFER_LIMIT
-    if DEFER_WS is None or DEFER_WS.device != torch.device(device) or DEFER_WS.numel() * 4 < nbytes:
-        DEFER_WS = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-    return DEFER_WS
+    """Slab pool of the queued split-K reductions.  It used to be 2 x DEFER_LIMIT = 1 GB up front; it now grows by 64 MB chunks
+    to the high-water mark of what one backward pass queues between two flushes (sized by the shapes actually run)."""
+    global _DEVICE
+    _DEVICE = torch.device(device)
+    if _DEFER_CHUNKS and _DEFER_CHUNKS[0].device != _DEVICE:
+        _DEFER_CHUNKS.clear()
+    return _DEFER_CHUNKS
 
 
 def begin_deferred_reduces(device):
-    global DEFER, _defer_top, _defer_outs
+    global DEFER, _defer_top, _defer_outs, _defer_chunk_i, _defer_pending
     ensure_defer_workspace(device)
-    DEFER, _defer_top, _defer_outs = [], 0, set()
+    del _WS_RETIRED[:]          # everything the previous pass launched has been ordered before this point on the main stream
+    DEFER, _defer_top, _defer_outs, _defer_chunk_i, _defer_pending = [], 0, set(), 0, 0
 
 
 AFTER_FLUSH = None     # hook of the engine: orders its two launch streams after a flush
@@ -257,7 +312,7 @@ AFTER_FLUSH = None     # hook of the engine: orders its two launch streams after
 def flush_reduces(end=False):
     """Reduce everything pending (bucket boundary / a consumer of the gradients / end of the backward pass): up to 16 slab
     sets per launch; the slabs become reusable."""
-    global DEFER, _defer_top, _defer_outs
+    global DEFER, _defer_top, _defer_outs, _defer_chunk_i, _defer_pending
     if DEFER is None:
         return
     if DEFER:
@@ -265,7 +320,7 @@ def flush_reduces(end=False):
         _check(load().detr_hip_splitk_reduce_many(arr, len(DEFER), _stream()), "detr_hip_splitk_reduce_many")
         if AFTER_FLUSH is not None:
             AFTER_FLUSH()              # (two launch streams: the recycled slabs must not be handed to the other one early)
-    _defer_top, _defer_outs = 0, set()
+    _defer_top, _defer_outs, _defer_chunk_i, _defer_pending = 0, set(), 0, 0
     DEFER = None if end else []
 
 
@@ -287,18 +342,28 @@ def _defer_push(rds):
         return
     DEFER.extend(rds)
     _defer_outs.update(outs)
-    if _defer_top >= DEFER_LIMIT:
+    if _defer_pending >= DEFER_LIMIT:
         flush_reduces()
 
 
+_defer_pending = 0
+
+
 def _defer_slab(nbytes):
-    """256-byte aligned share of DEFER_WS, or None when it is full (the caller then reduces immediately)."""
-    global _defer_top
-    nbytes = (nbytes + 255) & ~255
-    if _defer_top + nbytes > DEFER_WS.numel() * 4:
-        return None
-    ptr_ = DEFER_WS.data_ptr() + _defer_top
+    """256-byte aligned slab of the pool for one queued reduction: bump allocation over the chunk list (a flush rewinds it)."""
+    global _defer_top, _defer_chunk_i, _defer_pending
+    nbytes = (int(nbytes) + 255) & ~255
+    while True:
+        if _defer_chunk_i >= len(_DEFER_CHUNKS):
+            _DEFER_CHUNKS.append(torch.empty(max(DEFER_CHUNK, nbytes) // 4, dtype=torch.float32, device=_DEVICE))
+        chunk = _DEFER_CHUNKS[_defer_chunk_i]
+        if _defer_top + nbytes <= chunk.numel() * 4:
+            break
+        _defer_chunk_i += 1
+        _defer_top = 0
+    ptr_ = chunk.data_ptr() + _defer_top
     _defer_top += nbytes
+    _defer_pending += nbytes
     return ptr_, nbytes
 
 
@@ -315,10 +380,44 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int32
+    for name, argtypes in _SIGNATURES_I64.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int64
     lib.detr_hip_last_error.argtypes = []
     lib.detr_hip_last_error.restype = ctypes.c_char_p
+    if lib.detr_hip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.detr_hip_abi_version()}, this binding speaks {ABI_VERSION}: rebuild the library")
+    check_struct_layouts(lib)
     _lib = lib
     return lib
+
+
+def struct_layout_mirror(S):
+    """[sizeof, offsetof(field 0), ...] of a ctypes mirror, in declaration order."""
+    return [ctypes.sizeof(S)] + [getattr(S, f[0]).offset for f in S._fields_]
+
+
+def check_struct_layouts(lib):
+    """The descriptor structs are mirrored by hand above: compare every size / field offset with what the library was
+    compiled with (detr_hip_struct_layout) -- a drifted mirror would silently scramble arguments."""
+    for which, S in enumerate(LAYOUT_STRUCTS):
+        want = struct_layout_mirror(S)
+        buf = (c_int32 * 96)()
+        n = lib.detr_hip_struct_layout(which, buf, 96)
+        got = list(buf[:max(n, 0)])
+        if n != len(want) or got != want:
+            raise RuntimeError(f"ctypes mirror of struct {which} ({S.__name__}) does not match {LIB_PATH}: library {got}, mirror {want}")
+
+
+def set_tuning(name, value):
+    """Set (value=None: unset) a DETR_HIP_<NAME> tuning variable of the LIBRARY and have it re-read: the library reads its
+    tuning variables once at load time, never on the launch path."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    _check(load().detr_hip_reload_tuning(), "detr_hip_reload_tuning")
 
 
 def _stream():
@@ -369,6 +468,10 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     d.dropout_step = ptr(dropout_step)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
     d.rowsum_a, d.rowsum_alpha = ptr(rowsum_a), rowsum_alpha
+    if workspace is None and WORKSPACE is not None and split_k > 1 and batch == 1 and DEFER is None:
+        # immediate deterministic split-K: the shared scratch must hold every member's slabs (upper bound of
+        # detr_hip_workspace_bytes_gemm: the library may run fewer, never more, splits than requested)
+        need_workspace(split_k * (M * N + (M if rowsum_a is not None else 0)) * 4 * (ws_slice[1] if ws_slice else 1))
     ws = workspace if workspace is not None else WORKSPACE
     if ws is None:
         d.workspace, d.workspace_bytes = None, 0
@@ -505,8 +608,11 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     d.alpha = alpha
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split
-    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    if mode == 2 and WORKSPACE is not None:      # weight gradient: per-split partial kernels, sized by the library
+        need_workspace(_ws_query("detr_hip_workspace_bytes_conv3x3", ("conv", N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad, split, d.compute, d.x_dtype),
+                                 byref(d), mode))
+    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
     if ev0 is not None:
@@ -531,8 +637,10 @@ def stem_conv(mode, img, w, y, N, H, W, Ho, Wo, *, alpha=1.0, scale=None, bias=N
     d.act, d.split = act, split
     d.w_dtype = 1 if (mode == 2 and w.dtype == torch.bfloat16) else 0       # bf16 activation storage: dy / the output
     d.y_dtype = 1 if (mode == 0 and y.dtype == torch.bfloat16) else 0
-    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    if mode == 2 and WORKSPACE is not None:
+        need_workspace(_ws_query("detr_hip_workspace_bytes_stem", ("stem", N, H, W, Ho, Wo, split, d.compute, d.w_dtype), byref(d), mode))
+    d.workspace, d.workspace_bytes = (WORKSPACE.data_ptr(), WORKSPACE.numel() * 4) if WORKSPACE is not None else (None, 0)
     ev0 = PROFILER.begin() if PROFILER is not None else None
     _check(load().detr_hip_stem_conv7x7_f32(byref(d), mode, _stream()), "detr_hip_stem_conv7x7_f32")
     if ev0 is not None:
@@ -606,11 +714,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, d
     d.rows, d.C = x.shape[0], x.shape[1]
     d.dy, d.x, d.gamma, d.mean, d.rstd = dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     d.dx, d.dgamma, d.dbeta = dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+    ln_need = _ws_query("detr_hip_workspace_bytes_layernorm", ("ln", d.rows, d.C), byref(d))
     if WORKSPACE is not None:                                       # deterministic gamma / beta reduction
+        need_workspace(ln_need)
         d.workspace, d.workspace_bytes = WORKSPACE.data_ptr(), WORKSPACE.numel() * 4
     blocks = None
     if DEFER is not None and defer:  # queue the gamma / beta finish with the split-K reductions (the optimiser is their only reader)
-        slab = _defer_slab(512 * 2 * d.C * 4)
+        slab = _defer_slab(ln_need)
         if slab is not None:
             blocks = c_int32(0)
             d.workspace, d.workspace_bytes = slab

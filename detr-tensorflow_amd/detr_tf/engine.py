@@ -94,7 +94,7 @@ class DetrEngine:
         self._stem = stem_names(self.tf_backbone)
         self._pairs = bn_conv_pairs(self.blocks, self.tf_backbone)
         self._bufs = {}
-        self.buf_generation = 0          # bumped whenever buf() replaces (frees) a buffer: recorded graphs of older generations are invalid
+        self._buf_gen = 0                # bumped whenever buf() replaces (frees) a buffer: recorded graphs of older generations are invalid
         self._pos_cache = {}
         self._shape = None
         self.bn_scale, self.bn_shift = {}, {}
@@ -146,10 +146,16 @@ class DetrEngine:
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             if t is not None:
-                self.buf_generation += 1
+                self._buf_gen += 1
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self._bufs[key] = t
         return t
+
+    @property
+    def buf_generation(self):
+        """Changes whenever device memory a recorded hipGraph may address has been replaced: an engine buffer (buf) or the
+        binding's shared split-reduction scratch (hip.need_workspace)."""
+        return self._buf_gen + hip.WS_GENERATION
 
     def buffer_bytes(self):
         """Bytes held by the named buffers (activations, scratch, derived weight copies)."""

@@ -21,17 +21,27 @@
 #ifndef DETR_HIP_H
 #define DETR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 3
+#define DETR_HIP_ABI_VERSION 4
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
-/* hipMemsetAsync wrapper (zero-fill of accumulators) */
+/* The integer tuning variables DETR_HIP_<NAME> (A/B switches of the kernel dispatch; all default 0 = the measured heuristic) are
+ * read from the environment ONCE, when the library is loaded -- never on the launch path.  A process that changes one afterwards
+ * (tests, tuning scripts) calls this to have it re-read. */
+int detr_hip_reload_tuning(void);
+/* ABI self-check for hand-written mirrors of the descriptor structs below (ctypes / cgo / JNI): for struct `which`
+ * (0 detr_reduce_desc, 1 detr_gemm_desc, 2 detr_conv3x3_desc, 3 detr_stem_desc, 4 detr_layernorm_desc, 5 detr_attn_desc,
+ * 6 detr_setloss_desc, 7 detr_input_desc, 8 detr_postprocess_desc) writes out[0] = sizeof, out[1..] = offsetof of every field in
+ * declaration order, and returns the number of values (negative: unknown struct). */
+int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap);
+/* zero fill of accumulators (an ordinary kernel: a captured hipMemsetAsync node did not replay reliably) */
 int detr_hip_memset_zero(void *ptr, size_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -433,6 +443,16 @@ int detr_hip_set_floats8_f32(float *dst, float v0, float v1, float v2, float v3,
                              float v7, void *stream);
 /* acc[i] += a * g[i] (gradient accumulation optimizers.py:157) */
 int detr_hip_axpy_f32(float *acc, const float *g, float a, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scratch sizing: the number of bytes `workspace` must hold for the call described by the descriptor to take its
+ * DETERMINISTIC split-reduction path (0 = the call needs no scratch; negative = malformed descriptor).  Pointers inside the
+ * descriptor are not dereferenced; only shapes, split counts, dtypes and (gemm) whether rowsum_a is set are read.  The same
+ * value is what a deferred reduction (detr_gemm_desc.defer_out / detr_layernorm_desc.defer_blocks_out) needs as its private slab. */
+int64_t detr_hip_workspace_bytes_gemm(const detr_gemm_desc *d);
+int64_t detr_hip_workspace_bytes_conv3x3(const detr_conv3x3_desc *d, int32_t mode);
+int64_t detr_hip_workspace_bytes_stem(const detr_stem_desc *d, int32_t mode);
+int64_t detr_hip_workspace_bytes_layernorm(const detr_layernorm_desc *d);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,147 @@
+"""The BASELINE.json configurations at their OWN sizes (`configs_untested`).
+
+  C3  DETR-R50 bf16 training step, B=8, 800x1333: the bf16 step against the fp32 step of the SAME HIP path (same weights, batch
+      and dropout masks -- precision is the only difference): loss, matched index sets (flips counted), every gradient tensor.
+  C4  DETR-R101, 1000x1333: bf16 forward + set loss against the fp32 oracle (B=2), and the bf16 training step at B=8
+      against the fp32 HIP step.
+  C5  DETR-R50, 300 queries + 5 aux losses, B=16, 800x1333: properties of the training step (every assignment problem solved,
+      matched count = number of targets, finite loss and gradients) and bf16 against fp32.
+The oracle is the checker only where it finishes in seconds (C4 forward at B=2); at full batch the fp32 HIP path -- itself
+pinned to the oracle at 1e-3 by test_gpu_model.py at C2's full size -- is the reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(train=True):
+    from detr_tf.training_config import TrainingConfig
+    cfg = TrainingConfig()
+    cfg.background_class = 91
+    cfg.train_backbone = cfg.train_transformers = cfg.train_nlayers = train
+    cfg.target_batch = None
+    return cfg
+
+
+def _step(precision, params, images, t_bbox, t_class, *, backbone="resnet50", num_queries=100, dropout=0.1):
+    """One training-mode step (forward, set loss, backward; no optimiser apply) -> loss, log, matching, flat gradient (CPU)."""
+    from detr_tf import training
+    from detr_tf.networks.detr import get_detr_model
+    from detr_tf.optimizers import setup_optimizers
+    cfg = _cfg()
+    model = get_detr_model(cfg, include_top=True, backbone=backbone, num_queries=num_queries, dropout=dropout, precision=precision)
+    assert not model.load_weights(params)
+    opt = setup_optimizers(model, cfg)
+    out, total, log, _ = training.run_train_step(model, images, t_bbox, t_class, opt, cfg)
+    torch.cuda.synchronize()
+    m = out.set_loss.matcher
+    res = dict(total=float(total), log={k: float(v) for k, v in log.items() if torch.is_tensor(v)},
+               status=m.status.cpu().numpy().copy(), pred_for_tgt=m.pred_for_tgt.cpu().numpy().copy(),
+               tgt_for_pred=m.tgt_for_pred.cpu().numpy().copy(), grad=model.engine.P.grad.cpu().clone(),
+               offsets=dict(model.engine.P.offsets), logits=out["pred_logits"].cpu().clone(), boxes=out["pred_boxes"].cpu().clone())
+    del model, opt, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_max, p90_max):
+    """bf16 step `b16` against the fp32 step `a32` of the same path.  Returns the report dict (also printed)."""
+    B = t_bbox.shape[0]
+    n = t_bbox[:, 0, 0].astype(int)
+    assert (a32["status"] == 0).all() and (b16["status"] == 0).all(), "an assignment problem was not solved"
+    flips = matched = 0
+    for lv in range(levels):
+        for b in range(B):
+            p = lv * B + b
+            for res in (a32, b16):
+                sel = res["tgt_for_pred"][p] >= 0
+                assert int(sel.sum()) == n[b], (tag, lv, b, int(sel.sum()), n[b])          # matched count = number of targets
+                assert len(set(res["pred_for_tgt"][p, :n[b]].tolist())) == n[b]            # ... one distinct query each
+            flips += int((a32["pred_for_tgt"][p, :n[b]] != b16["pred_for_tgt"][p, :n[b]]).sum())
+            matched += int(n[b])
+    dloss = abs(a32["total"] - b16["total"]) / abs(a32["total"])
+    l2 = []
+    for name, (o, cnt) in a32["offsets"].items():
+        ga, gb = a32["grad"][o:o + cnt].double(), b16["grad"][o:o + cnt].double()
+        assert torch.isfinite(gb).all(), name
+        if float(ga.norm()) > 1e-10:
+            l2.append((float((ga - gb).norm() / ga.norm()), name))
+    l2.sort(reverse=True)
+    vals = np.array([v for v, _ in l2])
+    rep = dict(tag=tag, loss_fp32=a32["total"], loss_bf16=b16["total"], loss_rel=dloss, flips=flips, matched=matched,
+               grad_median=float(np.median(vals)), grad_p90=float(np.quantile(vals, 0.9)), grad_worst=l2[:6])
+    print(f"[{tag}] bf16 vs fp32 HIP step: loss {a32['total']:.5f} / {b16['total']:.5f} (rel {dloss:.2e}); matching flips {flips} of "
+          f"{matched}; gradient rel-L2 median {rep['grad_median']:.3f} p90 {rep['grad_p90']:.3f}; worst {l2[:6]}")
+    assert np.isfinite(b16["total"]) and dloss <= loss_tol, rep
+    assert flips <= flip_frac_max * matched, rep
+    assert rep["grad_median"] <= median_max and rep["grad_p90"] <= p90_max, rep
+    return rep
+
+
+def test_c3_bf16_train_step_vs_fp32_step_at_b8_800x1333(hip):
+    """C3 at its own shape: per-tensor gradient agreement of the bf16 step with the fp32 step (same path, same masks)."""
+    from oracle import detr_ref as R, set_loss_ref as L
+    params = R.make_params(0)
+    images = np.random.default_rng(1234).normal(size=(8, 800, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(8, seed=1235)
+    a32 = _step("fp32", params, images, t_bbox, t_class)
+    b16 = _step("bf16", params, images, t_bbox, t_class)
+    # exceptions named by test_bf16_compute_mode_deviation_from_fp32_oracle: cancellation-dominated tensors (query_embed, the
+    # zero-gradient q / k projections of decoder layer 0) sit far above the median; they are in the report, not in the bounds
+    _compare(a32, b16, t_bbox, 6, "C3 R50 B8 800x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.10, p90_max=0.60)
+
+
+def test_c4_r101_bf16_forward_loss_vs_fp32_oracle_at_1000x1333(hip):
+    """C4's backbone and input size in C3/C4's compute mode: bf16 forward + set loss against the fp32 ORACLE (B=2)."""
+    from detr_tf.loss.loss import get_losses
+    from detr_tf.networks.detr import get_detr_model
+    from oracle import detr_ref as R, set_loss_ref as L
+    cfg = _cfg(train=False)
+    params = R.make_params(7, blocks=R.RESNET101_BLOCKS)
+    images = np.random.default_rng(8).normal(size=(2, 1000, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(2, seed=9, force_full=False)
+    model = get_detr_model(cfg, include_top=True, backbone="resnet101", dropout=0.0, precision="bf16")
+    assert not model.load_weights(params)
+    out = model(images, training=False)
+    total, log = get_losses(out, t_bbox, t_class, cfg)
+    P = R.to_torch(params)
+    with torch.no_grad():
+        refs = [R.detr_forward(torch.from_numpy(images[b:b + 1]), P, blocks=R.RESNET101_BLOCKS) for b in range(2)]
+    ref = {"pred_logits": torch.cat([r["pred_logits"] for r in refs]), "pred_boxes": torch.cat([r["pred_boxes"] for r in refs]),
+           "aux": [{"pred_logits": torch.cat([r["aux"][i]["pred_logits"] for r in refs]),
+                    "pred_boxes": torch.cat([r["aux"][i]["pred_boxes"] for r in refs])} for i in range(5)]}
+    ref_total, _ = L.get_losses(ref, torch.from_numpy(t_bbox), torch.from_numpy(t_class), 91)
+    dl = float((out["pred_logits"].cpu() - ref["pred_logits"]).abs().max() / ref["pred_logits"].abs().max())
+    db = float((out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max() / ref["pred_boxes"].abs().max())
+    dloss = abs(float(total) - float(ref_total)) / abs(float(ref_total))
+    print(f"[C4 R101 1000x1333 bf16 vs fp32 oracle] loss {dloss:.2e} logits {dl:.2e} boxes {db:.2e}")
+    assert tuple(out["pred_logits"].shape) == (2, 100, 92)
+    assert dloss <= 1e-3, (float(total), float(ref_total))
+    assert dl < 2e-2 and db < 2e-2, (dl, db)
+
+
+def test_c4_r101_bf16_train_step_at_b8_1000x1333(hip):
+    """C4 at its own batch and size: the bf16 training step against the fp32 step of the same path."""
+    from oracle import detr_ref as R, set_loss_ref as L
+    params = R.make_params(7, blocks=R.RESNET101_BLOCKS)
+    images = np.random.default_rng(18).normal(size=(8, 1000, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(8, seed=19)
+    a32 = _step("fp32", params, images, t_bbox, t_class, backbone="resnet101")
+    b16 = _step("bf16", params, images, t_bbox, t_class, backbone="resnet101")
+    _compare(a32, b16, t_bbox, 6, "C4 R101 B8 1000x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.12, p90_max=0.70)
+
+
+def test_c5_300_queries_b16_800x1333_train_step(hip):
+    """C5 at its own shape (B=16, 800x1333, 300 queries, 5 aux losses, one image forced to 99 targets): 96 assignment problems
+    of 300 x n solved (status 0, one distinct query per target), finite loss / gradients, bf16 against fp32."""
+    from oracle import detr_ref as R, set_loss_ref as L
+    params = R.make_params(43, num_queries=300)
+    images = np.random.default_rng(44).normal(size=(16, 800, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(16, seed=45)
+    a32 = _step("fp32", params, images, t_bbox, t_class, num_queries=300)
+    assert a32["logits"].shape == (16, 300, 92) and np.isfinite(a32["total"])
+    assert torch.isfinite(a32["grad"]).all() and float(a32["grad"].abs().max()) > 0
+    assert float(a32["boxes"].min()) >= 0.0 and float(a32["boxes"].max()) <= 1.0
+    b16 = _step("bf16", params, images, t_bbox, t_class, num_queries=300)
+    _compare(a32, b16, t_bbox, 6, "C5 R50 Q300 B16 800x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.12, p90_max=0.70)

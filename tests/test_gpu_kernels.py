@@ -18,6 +18,19 @@ def g(t):
     return t.to(DEV).contiguous()
 
 
+@pytest.fixture(autouse=True)
+def _reset_library_tuning():
+    """The library reads its DETR_HIP_* tuning variables once (at load) and on detr_hip_reload_tuning(): a test that switches
+    one through hip.set_tuning() must not leak it into the next test."""
+    import os
+    yield
+    from detr_tf import _hip
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_GEMM_DMA")
+              if k in os.environ]
+    for k in leaked:
+        _hip.set_tuning(k, None)
+
+
 def close(a, b, rtol=2e-5, atol=None, what=""):
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
@@ -343,12 +356,12 @@ def test_stem_conv_row_staged_forward(hip, monkeypatch, N, H, W):
     imgd, ws, sd = g(img.float()), g(w.float().reshape(147, 64)), g(shift.float())
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("DETR_HIP_STEM_ROWS", mode)
+        hip.set_tuning("DETR_HIP_STEM_ROWS", mode)
         y = torch.full((N, Ho, Wo, 64), 7.0, device=DEV, dtype=torch.bfloat16)
         hip.stem_conv(0, imgd, ws, y, N, H, W, Ho, Wo, bias=sd, act=1, compute=1)
         torch.cuda.synchronize()
         outs[mode] = y.float().cpu().double()
-    monkeypatch.delenv("DETR_HIP_STEM_ROWS")
+    hip.set_tuning("DETR_HIP_STEM_ROWS", None)
     rows, gather = outs["0"], outs["2"]
     scale = float(ref.abs().max())
     err = (rows - ref).abs()
@@ -366,7 +379,7 @@ def test_stem_conv_row_staged_forward(hip, monkeypatch, N, H, W):
     dyd, bnd = g(dy.float()).to(torch.bfloat16), g(bn.float())
     res = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("DETR_HIP_STEM_ROWS", mode)
+        hip.set_tuning("DETR_HIP_STEM_ROWS", mode)
         pair = []
         for rep in range(2):
             dw = torch.zeros(147, 64, device=DEV)
@@ -374,7 +387,7 @@ def test_stem_conv_row_staged_forward(hip, monkeypatch, N, H, W):
             pair.append(dw)
         assert torch.equal(pair[0], pair[1]), "stem weight gradient is not deterministic"
         res[mode] = pair[0]
-    monkeypatch.delenv("DETR_HIP_STEM_ROWS")
+    hip.set_tuning("DETR_HIP_STEM_ROWS", None)
     close(res["0"], wref, rtol=3e-3, what="stem wgrad (staged rows, bf16 operands)")
     close(res["2"], wref, rtol=3e-3, what="stem wgrad (gathering kernel, bf16 operands)")
     close(res["0"], res["2"].double().cpu(), rtol=1e-4, what="stem wgrad: staged rows vs gathering kernel")
@@ -1017,7 +1030,7 @@ def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stri
     hip.ensure_workspace(DEV)
     # (the stride-1 all-bf16 calls would take the halo-staged kernel, which sums the taps in another order: it has its own
     #  test below; this one pins the storage-type identity of the tile kernel)
-    monkeypatch.setenv("DETR_HIP_CONV_HALO", "2")
+    hip.set_tuning("DETR_HIP_CONV_HALO", "2")      # (reset by the autouse fixture _reset_library_tuning)
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     b16 = lambda t: t.to(torch.bfloat16)
     x, dy = g(_bf(torch.randn(N, H, W, Ci)).float()), g(_bf(torch.randn(N, Ho, Wo, Co)).float())
@@ -1072,14 +1085,14 @@ def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C):
     xd, dyd, wd, md, sd = b16(x), b16(dy), b16(w), b16(msk), g(shift.float())
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("DETR_HIP_CONV_HALO", mode)
+        hip.set_tuning("DETR_HIP_CONV_HALO", mode)
         y = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
         dx = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
         hip.conv3x3(0, xd, wd, y, N, H, W, C, H, W, C, 1, bias=sd, act=1, compute=1)
         hip.conv3x3(1, dyd, wd, dx, N, H, W, C, H, W, C, 1, mask=md, compute=1)
         torch.cuda.synchronize()
         outs[mode] = (y.float().cpu().double(), dx.float().cpu().double())
-    monkeypatch.delenv("DETR_HIP_CONV_HALO")
+    hip.set_tuning("DETR_HIP_CONV_HALO", None)
     for what, halo, tile, ref in (("forward", outs["0"][0], outs["2"][0], ref_y), ("dgrad", outs["0"][1], outs["2"][1], ref_dx)):
         scale = float(ref.abs().max())
         assert scale > 0
@@ -1278,14 +1291,14 @@ def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
     Ad, Bd, rd, md, bd = b16(A), b16(Bm), b16(res), b16(msk), g(bias.float())
     outs = []
     for mode in ("0", "2"):
-        os.environ["DETR_HIP_GEMM_STREAM"] = mode
+        hip.set_tuning("DETR_HIP_GEMM_STREAM", mode)
         try:
             C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
             hip.gemm(M, N, K, Ad, K, 1, Bd, K if bk else N, bk, C, N, bias=bd, residual=rd if use_res else None, ldr=N if use_res else 0,
                      mask=md if use_mask else None, ldmask=N if use_mask else 0, act=act, compute=1)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("DETR_HIP_GEMM_STREAM", None)
+            hip.set_tuning("DETR_HIP_GEMM_STREAM", None)
         outs.append(C.float().cpu().double())
     stream, generic = outs
     scale = float(ref.abs().max())

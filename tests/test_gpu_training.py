@@ -212,3 +212,88 @@ def test_setup_optimizers_alone_keeps_derived_weights_fresh(hip):
     want = (w * eng.bn_scale["backbone/layer1/0/bn1"]).to(torch.bfloat16).float()
     assert torch.equal(ws16, want)
     assert abs(float(total2) - l0) > 1e-3 * abs(l0)
+
+
+def test_eval_graph_survives_a_forward_of_another_shape(hip):
+    """eval shapes A, A (recorded), B (eager: re-allocates every activation buffer), A again.  The recorded
+    graph of A addresses freed buffers by then -- it must be dropped (engine.buf_generation), not replayed: the outputs of
+    every A call equal a fresh eager model's."""
+    cfg = _cfg()
+    model = _model(cfg, dropout=0.0)
+    ref = _model(_cfg(), dropout=0.0)
+    ref.eval_graph = False
+    a = torch.from_numpy(_batches(1, seed=2)[0][0]).cuda()
+    b = torch.from_numpy(_batches(1, seed=3, H=64, W=160)[0][0]).cuda()
+    want_a = ref(a, training=False)["pred_logits"].clone()
+    want_b = ref(b, training=False)["pred_logits"].clone()
+    seq = [(a, want_a), (a, want_a), (a, want_a), (b, want_b), (a, want_a), (a, want_a), (a, want_a), (b, want_b), (b, want_b), (a, want_a)]
+    gens = []
+    for i, (x, want) in enumerate(seq):
+        got = model(x, training=False)["pred_logits"]
+        gens.append(model.engine.buf_generation)
+        assert torch.equal(got, want), (i, float((got - want).abs().max()))
+    assert model._eval_graph is not None                      # the graph path was exercised ...
+    assert gens[3] > gens[2] and gens[4] > gens[3]            # ... and the buffers really were re-allocated in between
+
+
+def test_train_graph_is_rerecorded_after_an_eval_of_another_shape(hip):
+    """ADVICE r2 (high), training side: graph steps at shape A, an eval forward at shape B (the engine re-allocates), graph
+    steps at A again -- compared step by step with an eager model that sees the same sequence."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    cfg_g, cfg_e = _cfg(), _cfg()
+    m_g, m_e = _model(cfg_g, dropout=0.0), _model(cfg_e, dropout=0.0)
+    o_g, o_e = setup_optimizers(m_g, cfg_g), setup_optimizers(m_e, cfg_e)
+    stepper = training.GraphedTrainStep(m_g, o_g, cfg_g)
+    data = _batches(6, seed=11)
+    other = torch.from_numpy(_batches(1, seed=12, H=64, W=160)[0][0]).cuda()
+    kept = []
+    for i, (im, tb, tc) in enumerate(data):
+        if i == 3:
+            assert stepper.step_graph is not None
+            gen = m_g.engine.buf_generation
+            ev_g = m_g(other, training=False)["pred_logits"]
+            ev_e = m_e(other, training=False)["pred_logits"]
+            assert m_g.engine.buf_generation > gen
+            assert float((ev_g - ev_e).abs().max()) <= 1e-4 * float(ev_e.abs().max())
+        # both models start every step from the same state (see test_graph_replay_equals_eager_steps)
+        for src, dst in ((m_e.engine.P.flat, m_g.engine.P.flat), (m_e.engine.P.adam_m, m_g.engine.P.adam_m),
+                         (m_e.engine.P.adam_v, m_g.engine.P.adam_v)):
+            dst.copy_(src)
+        m_g.engine.bump_weights_version()
+        before = m_e.engine.P.flat.clone()
+        _, tot_g, log_g = stepper(im, tb, tc, i)
+        _, tot_e, log_e = training.train_step(m_e, im, tb, tc, o_e, cfg_e, i)
+        kept.append((tot_g, log_g["label_cost"]))
+        assert abs(float(tot_g) - float(tot_e)) <= 1e-5 * abs(float(tot_e)), (i, float(tot_g), float(tot_e))
+        de, dg = m_e.engine.P.flat - before, m_g.engine.P.flat - before
+        assert float((de - dg).norm()) <= 2e-2 * float(de.norm()), (i, float((de - dg).norm()) / float(de.norm()))
+    assert stepper.step_graph is not None and stepper.calls == 3          # dropped at step 3, eager, re-recorded, replayed
+    # ADVICE r2 (low): every step hands out FRESH loss tensors -- a kept history is not N aliases of the last step
+    vals = [float(t) for t, _ in kept]
+    assert len(set(vals)) == len(vals) and len({t.data_ptr() for t, _ in kept}) == len(kept)
+
+
+def test_auto_launch_probe_settles_and_check_matching_runs_eagerly(hip, capsys):
+    """training.fit's default launch path ("auto"): eager step, recording pass, 3 timed replays, 3 timed eager steps, then ONE
+    path for the rest of the run; `config.check_matching` (a host synchronisation inside the loss) never records a graph."""
+    from detr_tf import training
+    from detr_tf.optimizers import setup_optimizers
+    cfg = _cfg()
+    assert training._launch_mode(cfg) == "auto"
+    model = _model(cfg, dropout=0.1)
+    opt = setup_optimizers(model, cfg)
+    one = _batches(1, seed=21)[0]
+    training.fit(model, [one] * 10, opt, cfg, epoch_nb=0, class_names=[])
+    st = opt["_graphed_step"]
+    assert st.launch == "auto" and st.calls == 10 and st.settle_calls == 8
+    assert st.probe is not None and st.choice in ("graph", "eager")
+    assert st.probe["graph_ms"] > 0 and st.probe["eager_ms"] > 0
+    assert (st.choice == "graph") == (st.probe["graph_ms"] <= st.probe["eager_ms"])
+    assert opt["backbone_optimizer"].iterations == 10 and cfg.global_step == 10
+    cfg2 = _cfg()
+    cfg2.check_matching = True
+    m2 = _model(cfg2, dropout=0.0)
+    o2 = setup_optimizers(m2, cfg2)
+    training.fit(m2, [one] * 4, o2, cfg2, epoch_nb=0, class_names=[])
+    assert o2["_graphed_step"].step_graph is None and o2["backbone_optimizer"].iterations == 4

@@ -178,4 +178,85 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in detr_hip.h but not exported"
     assert sorted(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.detr_hip_abi_version() == 3
+    assert lib.detr_hip_abi_version() == _hip.ABI_VERSION == 4
+
+
+def _hip_lib():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "detr-tensorflow_amd"))
+    from detr_tf import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _hip, _hip.load()
+
+
+def test_ctypes_mirrors_match_the_library_struct_layouts():
+    """Boundary hygiene: every descriptor struct mirrored by hand in detr_tf/_hip.py has the size and the
+    field offsets the library was compiled with (detr_hip_struct_layout); a deliberately drifted mirror is caught."""
+    import ctypes
+    _hip, lib = _hip_lib()
+    for which, S in enumerate(_hip.LAYOUT_STRUCTS):
+        buf = (ctypes.c_int32 * 96)()
+        n = lib.detr_hip_struct_layout(which, buf, 96)
+        assert n == 1 + len(S._fields_), (S.__name__, n)
+        assert list(buf[:n]) == _hip.struct_layout_mirror(S), S.__name__
+    assert lib.detr_hip_struct_layout(99, (ctypes.c_int32 * 4)(), 4) < 0
+
+    class Drifted(ctypes.Structure):          # detr_reduce_desc with `rows` widened: every later offset moves
+        _fields_ = [(n, (ctypes.c_int64 if n == "rows" else t)) for n, t in _hip.ReduceDesc._fields_]
+    buf = (ctypes.c_int32 * 96)()
+    n = lib.detr_hip_struct_layout(0, buf, 96)
+    assert list(buf[:n]) != _hip.struct_layout_mirror(Drifted)
+
+
+def test_workspace_bytes_queries_and_tuning_reload():
+    """detr_hip_workspace_bytes_* (SURVEY 8b): pure host arithmetic on the descriptors (no GPU): a split-K GEMM needs
+    effective_splits * (M*N [+ M with a fused bias gradient]) floats, forward convs none, the nine-tap weight gradient
+    splits * 9*Ci*Co floats; the tuning variables are re-read only by detr_hip_reload_tuning()."""
+    from ctypes import byref
+    _hip, lib = _hip_lib()
+    d = _hip.GemmDesc()
+    d.M, d.N, d.K, d.batch, d.split_k, d.compute = 256, 1024, 33600, 1, 32, 1
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 32 * 256 * 1024 * 4
+    d.rowsum_a = 16                                  # (any non-null pointer: never dereferenced)
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 32 * (256 * 1024 + 256) * 4
+    d.rowsum_a, d.split_k = None, 1
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 0
+    d.split_k, d.K = 1000, 64 * 32                   # more splits than K tiles: the library runs 64
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 64 * 256 * 1024 * 4
+    d.M = 0
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) < 0
+    c = _hip.Conv3x3Desc()
+    c.N, c.Hi, c.Wi, c.Ci, c.Ho, c.Wo, c.Co, c.stride, c.pad, c.compute = 8, 50, 84, 256, 50, 84, 256, 1, 1, 1
+    assert lib.detr_hip_workspace_bytes_conv3x3(byref(c), 0) == 0 and lib.detr_hip_workspace_bytes_conv3x3(byref(c), 1) == 0
+    fused = lib.detr_hip_workspace_bytes_conv3x3(byref(c), 2)
+    assert fused == 32 * 9 * 256 * 256 * 4           # fused nine-tap kernel: 512 workgroups over 16 (ci, co) tiles
+    os.environ["DETR_HIP_WGRAD_FUSED"] = "2"
+    try:
+        assert lib.detr_hip_workspace_bytes_conv3x3(byref(c), 2) == fused        # not re-read on the call path ...
+        assert lib.detr_hip_reload_tuning() == 0
+        per_tap = lib.detr_hip_workspace_bytes_conv3x3(byref(c), 2)              # ... only on request
+        assert per_tap != fused and per_tap % (9 * 256 * 256 * 4) == 0
+    finally:
+        os.environ.pop("DETR_HIP_WGRAD_FUSED", None)
+        lib.detr_hip_reload_tuning()
+    st = _hip.StemDesc()
+    st.N, st.H, st.W, st.Ho, st.Wo, st.compute, st.w_dtype, st.split = 8, 800, 1333, 400, 667, 1, 1, 512
+    assert lib.detr_hip_workspace_bytes_stem(byref(st), 0) == 0
+    assert lib.detr_hip_workspace_bytes_stem(byref(st), 2) == 768 * 147 * 64 * 4
+    ln = _hip.LayerNormDesc()
+    ln.rows, ln.C = 8400, 256
+    assert lib.detr_hip_workspace_bytes_layernorm(byref(ln)) == 512 * 2 * 256 * 4
+
+
+def test_host_side_of_the_c_abi_under_address_sanitizer():
+    """SURVEY section 5 stance: the host side of the boundary (descriptor validation, planning, scratch-size queries, layout
+    self-check) built with -fsanitize=address and driven by tests/host_abi_check.c (plain C, no GPU): every rejection path
+    returns a negative code without touching memory it was not given; ASan aborts on any stack / heap error."""
+    import subprocess
+    pkg = os.path.join(ROOT, "detr-tensorflow_amd")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    r = subprocess.run(["make", "-C", pkg, "-j", str(os.cpu_count() or 2), "asan-check"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "host_abi_check: 0 failed expectation(s)" in r.stdout
