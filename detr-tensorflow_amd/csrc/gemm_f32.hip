@@ -650,8 +650,11 @@ static bool gemm_stream_eligible(const GemmPlan &p) {
     const detr_gemm_desc *d = p.d;
     const GemmArgs &g = p.g;
     if (!(p.bf16c && g.a16 && g.b16 && g.e.c16 && p.ak && p.batch == 1 && p.split == 1 && !g.rowsum)) return false;
-    if (!((d->K == 64 || d->K == 128 || d->K == 256) && d->N % 64 == 0 && d->M >= 16384)) return false;
-    if (d->scale || d->alpha != 1.0f || d->dropout_p > 0.0f || !(d->act == 0 || d->act == 1)) return false;
+    // M >= 16384: the backbone's 1x1 convolutions; the transformer's K = 256 FFN GEMMs (M = B*L = 8400: linear1 forward with its
+    // fused dropout, the input gradient of linear2 with alpha = 1/(1-p) and the ReLU / dropout mask) take it from M >= 4096
+    const bool ext = d->alpha != 1.0f || d->dropout_p > 0.0f;
+    if (!((d->K == 64 || d->K == 128 || d->K == 256) && d->N % 64 == 0 && d->M >= ((d->K == 256 && d->N >= 1024) ? 4096 : 16384))) return false;
+    if (d->scale || (ext && d->K != 256) || !(d->act == 0 || d->act == 1)) return false;
     if (d->residual && !(g.e.r16 && d->ldr % 8 == 0 && aligned16(d->residual))) return false;
     if (d->mask && !(g.e.m16 && d->ldmask % 8 == 0 && aligned16(d->mask))) return false;
     if (!(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C))) return false;
@@ -671,6 +674,8 @@ static void gemm_stream_launch(const GemmPlan &p, hipStream_t s) {
     a.mask = reinterpret_cast<const unsigned short *>(d->mask); a.ldm = d->ldmask;
     a.bias = d->bias;
     a.act = d->act;
+    a.alpha = d->alpha;
+    a.drop_scale = p.g.e.drop_scale; a.drop_thresh = p.g.e.drop_thresh; a.drop_seed = p.g.e.drop_seed; a.drop_step = p.g.e.drop_step;
     a.n_tiles = a.row_tiles = a.q = 0;
     if (d->K == 64) launch_gemm_stream<64>(a, p.bk, s);
     else if (d->K == 128) launch_gemm_stream<128>(a, p.bk, s);

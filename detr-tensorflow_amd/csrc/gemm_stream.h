@@ -38,6 +38,12 @@ struct StreamArgs {
     int n_tiles;                                   // N / 64
     int row_tiles;                                 // cdiv(M, 32)
     int q;                                         // workgroups per (XCD, column slice); grid = 8 * n_tiles * q
+    // EXT instantiations only (the transformer's K = 256 FFN GEMMs): v = (acc + bias) * alpha, keyed dropout after the
+    // activation (no residual) or before the residual add -- the positions of gemm_core.h epi_one
+    float alpha;
+    float drop_scale;                              // 1 / (1 - p), 0 = no dropout
+    uint32_t drop_thresh, drop_seed;
+    const uint32_t *drop_step;
 };
 
 // Cache policy of the epilogue streams.  The residual and the mask are read exactly once by this kernel and by nobody
@@ -82,7 +88,7 @@ struct StreamOcc {
     static constexpr int VALUE = (3 * BYTES <= 160 * 1024) ? 3 : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
 };
 
-template <int K, bool BKC, bool RES, bool MASK, int SL = 1>
+template <int K, bool BKC, bool RES, bool MASK, int SL = 1, bool EXT = false>
 __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
     constexpr int WPS = 4 / SL;                    // row walkers (waves per slice) of a workgroup
     constexpr int KC = (K > 128) ? 128 : K;       // A rows are held in registers one K chunk (<= 128) at a time
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     if (MASK) srcM.init_bytes(a.mask, ((long long)(a.M - 1) * a.ldm + a.N) * 2);
     float *stage = &sm.stage[wave][0][0];
     const unsigned a_lane = (unsigned)(h * 16);    // byte offset of this lane's 8 k values inside a 16-k step
+    const uint32_t dkey = (EXT && a.drop_scale != 0.0f) ? drop_key(a.drop_seed, a.drop_step) : 0u;
 
     auto load_a = [&](int rt, int chunk, uint4 (&f)[KK]) {
         const int row = rt * 32 + l31;
@@ -184,6 +191,24 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += bias[i];
+            bool keep[8];
+            if constexpr (EXT) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= a.alpha;
+                if (a.drop_scale != 0.0f) {        // one hash per element pair (common.h); this lane's 8 columns start at an even index
+                    const unsigned long long pair0 = ((unsigned long long)row * (unsigned long long)a.N + (unsigned)(n0 + ecg * 8)) >> 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t hh = drop_hash(dkey, pair0 + j);
+                        keep[2 * j] = (hh & 0xFFFFu) >= a.drop_thresh;
+                        keep[2 * j + 1] = (hh >> 16) >= a.drop_thresh;
+                    }
+                    if (RES) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
+                    }
+                }
+            }
             if (RES) {
                 float r[8];
                 stream_unpack8(rres[it], r);
@@ -193,6 +218,12 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             if (a.act == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            if constexpr (EXT) {
+                if (!RES && a.drop_scale != 0.0f) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
+                }
             }
             if (MASK) {
                 float m[8];
@@ -253,7 +284,7 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 }
 
 // Host side: eligibility is decided by the caller (gemm_f32.hip); here the slice grouping and the grid.
-template <int K, int SL>
+template <int K, int SL, bool EXT = false>
 static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s) {
     a.n_tiles = a.N / (64 * SL);
     a.row_tiles = (a.M + 31) / 32;
@@ -265,7 +296,7 @@ static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s) {
     a.q = q;
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
-#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL>), grid, dim3(256), 0, s, a)
+#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT>), grid, dim3(256), 0, s, a)
     if (bkc) {
         if (r && m) DETR_STREAM_LAUNCH(true, true, true);
         else if (r) DETR_STREAM_LAUNCH(true, true, false);
@@ -287,6 +318,10 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
     // +res +mask 116 -> 95 (SL 4), M133600 N512 K256 144 -> 126 (SL 2); M33600 N1024 K256 stays at SL 1 (52 vs 57 us)
     // (in the step, HIP events: K = 256 without a residual / mask epilogue is SLOWER with 2 slices -- 102 KB of LDS, one workgroup per
     //  CU: M133600 N512 0.091 -> 0.120 ms -- so K = 256 groups only the epilogue-heavy form)
+    if (a.alpha != 1.0f || a.drop_scale != 0.0f) {      // the extended epilogue exists for K = 256, one slice per workgroup
+        if constexpr (K == 256) launch_gemm_stream_sl<256, 1, true>(a, bkc, s);
+        return;
+    }
     int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : ((a.res && a.mask && a.N <= 512) ? 2 : 1));
     const int force = tune(T_STREAM_SL);
     if (force == 1 || force == 2 || force == 4) sl = force;

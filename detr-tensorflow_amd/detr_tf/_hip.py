@@ -492,7 +492,8 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     fam = "gemm_bf16c_kernel" if d.compute == 1 else "gemm_f32_kernel"
     # mirror of gemm_stream_eligible() in csrc/gemm_f32.hip: the short-K all-bf16 GEMMs run on the streaming kernel
     if (d.compute == 1 and d.a_dtype and d.b_dtype and d.c_dtype and a_kcontig and batch == 1 and split_k == 1 and rowsum_a is None
-            and K in (64, 128, 256) and N % 64 == 0 and M >= 16384 and scale is None and alpha == 1.0 and dropout_p == 0.0
+            and K in (64, 128, 256) and N % 64 == 0 and M >= (4096 if (K == 256 and N >= 1024) else 16384) and scale is None
+            and (K == 256 or (alpha == 1.0 and dropout_p == 0.0))
             and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or (d.m_dtype and ldmask % 8 == 0))
             and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"):
         fam = "gemm_stream_bf16_kernel"          # one kernel body; its K / layout / epilogue instantiations are pooled

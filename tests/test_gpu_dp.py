@@ -171,7 +171,7 @@ def test_bench_forced_single_rank_rccl_path(hip):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and np.isfinite(j["loss"]) and j["value"] > 0
-    assert j["config"]["launch"] == "hipGraph replay" and j["config"]["parallelism"] == "dp1"
+    assert j["config"]["launch"].startswith("hipGraph replay") and j["config"]["parallelism"] == "dp1"
 
 
 def test_bench_refuses_rank_count_mismatch(hip):

@@ -1309,3 +1309,55 @@ def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
     assert float((diff / (generic.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
 
 
+
+
+@pytest.mark.parametrize("M,N,bk,use_bias,act,use_mask,alpha,p", [
+    (8400, 2048, 1, True, 1, False, 1.0, 0.1),        # encoder FFN linear1 forward: bias + ReLU + keyed dropout
+    (8400, 2048, 0, False, 0, True, 1.0 / 0.9, 0.0),  # input gradient of linear2: alpha = 1/(1-p), ReLU / dropout mask
+    (4100, 1024, 1, True, 0, False, 0.5, 0.25),       # ragged last strip, alpha and dropout together
+])
+def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bias, act, use_mask, alpha, p):
+    """The K = 256 streaming kernel with the extended epilogue ((acc + bias) * alpha, keyed dropout after the activation) that
+    takes the transformer's FFN GEMMs at M = B*L: same call on the generic tile engine (DETR_HIP_GEMM_STREAM=2).  The dropout
+    masks are the SAME counter hash, so the zero patterns must coincide exactly; kept values may differ by one bf16 ulp
+    (order of the fp32 products inside an MFMA)."""
+    K = 256
+    torch.manual_seed(M + N + bk)
+    A = _bf(torch.randn(M, K))
+    Bm = _bf(torch.randn(N, K) / K ** 0.5 if bk else torch.randn(K, N) / K ** 0.5)
+    msk, bias = _bf(torch.randn(M, N)), torch.randn(N)
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    Ad, Bd, md, bd = b16(A), b16(Bm), b16(msk), g(bias.float())
+    step = torch.tensor([0x1234567, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+    outs = []
+    for mode in ("0", "2"):
+        hip.set_tuning("DETR_HIP_GEMM_STREAM", mode)
+        try:
+            C = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm(M, N, K, Ad, K, 1, Bd, K if bk else N, bk, C, N, bias=bd if use_bias else None, alpha=alpha,
+                     mask=md if use_mask else None, ldmask=N if use_mask else 0, act=act, compute=1, dropout_p=p, dropout_seed=77,
+                     dropout_step=step)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning("DETR_HIP_GEMM_STREAM", None)
+        outs.append(C.float().cpu().double())
+    stream, generic = outs
+    ref = A @ (Bm.t() if bk else Bm) + (bias.double() if use_bias else 0.0)
+    ref = ref * alpha
+    if act:
+        ref = torch.relu(ref)
+    if p > 0.0:
+        kept = stream != 0
+        frac = float((stream == 0).double().mean())
+        base = float((ref == 0).double().mean()) if act else 0.0
+        assert abs(frac - (base + (1 - base) * p)) < 0.01, (frac, base)            # the drop rate is p
+        assert torch.equal(stream == 0, generic == 0), "stream / tile engine dropout masks differ"
+        ref = torch.where(kept, ref / (1.0 - p), torch.zeros_like(ref))
+    if use_mask:
+        ref = torch.where(msk > 0, ref, torch.zeros_like(ref))
+    scale = float(ref.abs().max())
+    err = (stream - ref).abs()
+    assert float((err / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.05, "stream GEMM (extended epilogue): more than one bf16 rounding from fp64"
+    diff = (stream - generic).abs()
+    assert float((diff > 0).double().mean()) < 2e-3, float((diff > 0).double().mean())
+    assert float((diff / (generic.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
