@@ -1,0 +1,113 @@
+"""Micro-benchmark of the bf16 tile GEMM engine on the step's dominant shapes: the register-staged operand
+path (DETR_HIP_GEMM_DMA=2) against the LDS-DMA path (default; =3: its BK = 64 variants), and the streaming kernel's extended
+epilogue.  HIP events around `reps` back-to-back launches; also checks that the variants agree.
+usage: python scripts/micro_gemm.py out.json"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "detr-tensorflow_amd")):
+    sys.path.insert(0, p)
+import torch
+
+from detr_tf import _hip as hip
+
+hip.load()
+dev = "cuda"
+hip.ensure_workspace(dev)
+torch.manual_seed(0)
+bf = torch.bfloat16
+
+
+def operands(M, N, K, ak, bk):
+    A = (torch.randn(M, K, device=dev) if ak else torch.randn(K, M, device=dev)).to(bf)
+    B = ((torch.randn(N, K, device=dev) if bk else torch.randn(K, N, device=dev)) / K ** 0.5).to(bf)
+    return A, B
+
+
+def run(case, mode, reps=30):
+    name, M, N, K, ak, bk, kw = case
+    A, B = case_ops[name]
+    cdt = torch.float32 if kw.get("c32") else bf
+    C = torch.zeros(M, N, device=dev, dtype=cdt)
+    res = torch.randn(M, N, device=dev).to(torch.float32 if kw.get("r32") else bf) if kw.get("res") else None
+    msk = torch.randn(M, N, device=dev).to(bf) if kw.get("mask") else None
+    bias = torch.randn(N, device=dev) if kw.get("bias") else None
+    sk = hip.pick_split_k(M, N, K) if kw.get("wgrad") else 1
+    args = (M, N, K, A, A.stride(0), ak, B, B.stride(0), bk, C, N)
+    kws = dict(bias=bias, residual=res, ldr=N if res is not None else 0, mask=msk, ldmask=N if msk is not None else 0,
+               act=kw.get("act", 0), alpha=kw.get("alpha", 1.0), compute=1, split_k=sk)
+    if kw.get("wgrad") and sk == 1:
+        kws.update(residual=C, ldr=N)
+    for k, v in mode.items():
+        hip.set_tuning(k, v)
+    try:
+        for _ in range(3):
+            if kw.get("wgrad"):
+                C.zero_()
+            hip.gemm(*args, **kws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(3):
+            e0.record()
+            for _ in range(reps):
+                hip.gemm(*args, **kws)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / reps * 1e3)
+        if kw.get("wgrad"):
+            C.zero_()
+            hip.gemm(*args, **kws)
+            torch.cuda.synchronize()
+        return min(ts), C.float().clone(), sk
+    finally:
+        for k in mode:
+            hip.set_tuning(k, None)
+
+
+hip.COMPUTE_BF16 = 1
+cases = [
+    ("l3 conv3 dgrad", 33600, 256, 1024, 1, 1, dict(mask=1)),
+    ("l3 conv1 fwd", 33600, 256, 1024, 1, 0, dict(bias=1, act=1)),
+    ("l2 conv3 dgrad", 133600, 128, 512, 1, 1, dict(mask=1)),
+    ("l2 conv1 fwd", 133600, 128, 512, 1, 0, dict(bias=1, act=1)),
+    ("l4 conv3 fwd", 8400, 2048, 512, 1, 0, dict(bias=1, res=1, act=1)),
+    ("l4 conv3 dgrad", 8400, 512, 2048, 1, 1, dict(mask=1)),
+    ("l3 down fwd", 33600, 1024, 512, 1, 0, dict(bias=1)),
+    ("l3 conv1 dgrad b0", 33600, 1024, 512, 1, 1, dict(res=1, mask=1)),
+    ("ffn lin2 fwd", 8400, 256, 2048, 1, 1, dict(bias=1, res=1, r32=1, c32=1)),
+    ("ffn lin1 dgrad", 8400, 256, 2048, 1, 0, dict(res=1, r32=1, c32=1)),
+    ("l3 conv3 wgrad", 256, 1024, 33600, 0, 0, dict(wgrad=1, c32=1)),
+    ("l3 conv1 wgrad", 1024, 256, 33600, 0, 0, dict(wgrad=1, c32=1)),
+    ("l2 conv3 wgrad", 128, 512, 133600, 0, 0, dict(wgrad=1, c32=1)),
+    ("l2 conv1 wgrad", 512, 128, 133600, 0, 0, dict(wgrad=1, c32=1)),
+    ("l1 conv3 wgrad", 64, 256, 534400, 0, 0, dict(wgrad=1, c32=1)),
+    ("l1 conv1 wgrad", 256, 64, 534400, 0, 0, dict(wgrad=1, c32=1)),
+    ("l3 down wgrad", 1024, 512, 33600, 0, 0, dict(wgrad=1, c32=1)),
+    ("l4 conv3 wgrad", 512, 2048, 8400, 0, 0, dict(wgrad=1, c32=1)),
+    ("ffn lin2 wgrad", 256, 2048, 8400, 0, 0, dict(wgrad=1, c32=1)),
+    ("ffn lin1 fwd K256", 8400, 2048, 256, 1, 1, dict(bias=1, act=1)),
+    ("ffn lin2 dgrad K256", 8400, 2048, 256, 1, 0, dict(mask=1, alpha=1.0 / 0.9)),
+]
+case_ops = {c[0]: operands(c[1], c[2], c[3], c[4], c[5]) for c in cases}
+rows = []
+print(f"{'case':22s} {'shape':28s} {'sk':>4s} {'reg us':>8s} {'dma us':>8s} {'dma64 us':>9s}   dma/reg  maxdiff(dma) maxdiff(dma64)  TF/s(best)")
+for case in cases:
+    name, M, N, K, ak, bk, kw = case
+    stream_case = K == 256
+    t_reg, c_reg, sk = run(case, {"DETR_HIP_GEMM_DMA": 2, **({"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})})
+    t_dma, c_dma, _ = run(case, {"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})
+    t_d64, c_d64, _ = run(case, {"DETR_HIP_GEMM_DMA": 3, **({"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})})
+    extra = ""
+    if stream_case:
+        t_str, c_str, _ = run(case, {})
+        extra = f"  stream {t_str:7.1f} us diff {float((c_str - c_reg).abs().max()):.2e}"
+    scale = float(c_reg.abs().max()) + 1e-30
+    d1, d2 = float((c_dma - c_reg).abs().max()) / scale, float((c_d64 - c_reg).abs().max()) / scale
+    best = min(t_reg, t_dma, t_d64)
+    print(f"{name:22s} M{M} N{N} K{K} a{ak} b{bk:<3d} {sk:4d} {t_reg:8.1f} {t_dma:8.1f} {t_d64:9.1f}   {t_dma / t_reg:6.3f}  {d1:11.2e} {d2:13.2e}  {2.0 * M * N * K / best / 1e6:8.1f}{extra}")
+    rows.append(dict(case=name, M=M, N=N, K=K, ak=ak, bk=bk, split_k=sk, reg_us=t_reg, dma_us=t_dma, dma64_us=t_d64, rel_diff_dma=d1, rel_diff_dma64=d2))
+if len(sys.argv) > 1:
+    json.dump(rows, open(sys.argv[1], "w"), indent=1)
