@@ -86,7 +86,6 @@ enum TuneKey {
     T_WGRAD_TILE,
     T_STEM_ROWS,
     T_ATTN_WAVES,
-    T_GEMM_DMA,
     T_COUNT
 };
 int tune(TuneKey k);

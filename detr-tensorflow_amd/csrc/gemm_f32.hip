@@ -4,7 +4,6 @@
 #include "gemm_core.h"
 #include "gemm_bf16_core.h"
 #include "gemm_stream.h"
-#include "gemm_dma.h"
 
 namespace detr {
 
@@ -27,7 +26,6 @@ struct GemmArgs {
     int b16;                     // B operand is bf16 in memory (bf16 compute only)
     int a16;                     // A operand is bf16 in memory (bf16 activation storage)
     int split_xcd;               // split-K: remap the whole (split, tile) space over the XCDs (0 = per-split tile remap only, A/B hook)
-    int dma;                     // both operands bf16 in memory, no fused row sums: the LDS-DMA operand path (gemm_dma.h); 3 = its BK = 64 variants
 };
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
@@ -327,47 +325,6 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MI
     gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, A16, B16>(G.g[m], tile, z);
 }
 
-// The same GEMM on the LDS-DMA operand path (gemm_dma.h): both operands bf16 in memory.  Tile / split bookkeeping and the
-// epilogue are those of gemm_bf16c_body; the K loop has no register staging.
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, int BK, int NS>
-__device__ __forceinline__ void gemm_bf16dma_body(const GemmArgs &g, const int id, const int zidx) {
-    using T = TileCfg<BM, BN, WGM, WGN>;
-    __shared__ __attribute__((aligned(1024))) char smem_raw[DmaSmemBytes<BM, BN, BK, NS, WGN>::VALUE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int tn = id % g.tiles_n, tm = id / g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int split = zidx % g.split_k;
-    float *C = g.C + (long long)split * g.part_stride;
-    // the split boundaries are those of gemm_bf16c_body (32-deep tiles), whatever BK this variant stages
-    const int nkt = (g.K + BF_BK - 1) / BF_BK;
-    const int per = (nkt + g.split_k - 1) / g.split_k;
-    const int kt0 = split * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-    f32x16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    gemm_dma_kloop<BM, BN, WGM, WGN, BK, NS, AK, BKC>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0, kt0 * BF_BK, min(g.K, kt1 * BF_BK), smem_raw, acc);
-    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
-}
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, int BK, int NS>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void gemm_bf16dma_kernel(GemmArgs g) {
-    int tile, z;
-    gemm_work_item(g, tile, z);
-    gemm_bf16dma_body<BM, BN, WGM, WGN, AK, BKC, BK, NS>(g, tile, z);
-}
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, int BK, int NS>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16dma_group_kernel(GemmGroupArgs G) {
-    int m, tile, z;
-    if (!gemm_group_item(G, m, tile, z)) return;
-    gemm_bf16dma_body<BM, BN, WGM, WGN, AK, BKC, BK, NS>(G.g[m], tile, z);
-}
-
 // Reduction of the split-K partial slabs: 256 threads = (256 / G) float4 outputs x G split groups (the groups stride the
 // split index), combined through LDS in a fixed order.  G = 4 for large outputs; G = 16 for small ones (a 256 x 256
 // weight gradient has only 16 K float4 outputs: with G = 4 the launch is 256 blocks and purely latency bound).
@@ -523,21 +480,6 @@ static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak,
         else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, true, A16_, B16_>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, false, false, A16_, B16_>), grid, block, 0, s, a);               \
     } while (0)
-    if (g.dma && g.a16 && g.b16) {      // LDS-DMA operand path: ring depth / K tile per tile size (DETR_HIP_GEMM_DMA=3: the BK = 64 variants)
-        constexpr int NS32 = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 64 * 128) ? 3 : 4);
-        constexpr int NS64 = (BM * BN >= 128 * 128) ? 2 : 3;
-#define DETR_DMA_LAUNCH(BK_, NS_)                                                                                                  \
-    do {                                                                                                                           \
-        if (ak && bk) hipLaunchKernelGGL((gemm_bf16dma_kernel<BM, BN, WGM, WGN, true, true, BK_, NS_>), grid, block, 0, s, a);         \
-        else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16dma_kernel<BM, BN, WGM, WGN, true, false, BK_, NS_>), grid, block, 0, s, a);  \
-        else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16dma_kernel<BM, BN, WGM, WGN, false, true, BK_, NS_>), grid, block, 0, s, a);  \
-        else hipLaunchKernelGGL((gemm_bf16dma_kernel<BM, BN, WGM, WGN, false, false, BK_, NS_>), grid, block, 0, s, a);                \
-    } while (0)
-        if (g.dma == 3) DETR_DMA_LAUNCH(64, NS64);
-        else DETR_DMA_LAUNCH(32, NS32);
-#undef DETR_DMA_LAUNCH
-        return 0;
-    }
     if (g.a16 && g.b16) DETR_BF16_LAUNCH(true, true);
     else if (g.a16) DETR_BF16_LAUNCH(true, false);
     else if (g.b16) DETR_BF16_LAUNCH(false, true);
@@ -660,11 +602,6 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     g.b16 = d->b_dtype == 1;
     g.a16 = d->a_dtype == 1;
     g.split_xcd = tune(T_SPLIT_XCD) != 2;
-    {   // LDS-DMA operand path (gemm_dma.h): both operands bf16 in memory (16-byte chunks: the alignment rules above), no fused
-        // row sums (they are taken from the loader registers the DMA path does not have).  DETR_HIP_GEMM_DMA=2: off, 3: BK = 64
-        const int t = tune(T_GEMM_DMA);
-        g.dma = (bf16c && g.a16 && g.b16 && !d->rowsum_a && batch == 1 && t != 2) ? (t == 3 ? 3 : 1) : 0;
-    }
     EpiArgs final_e = g.e;
     if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;
@@ -813,7 +750,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         bool same = m > 1 && tune(T_GEMM_GROUP) != 2;
         for (int i = 0; i < m && same; ++i)
             same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
-                   p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && p[i].g.dma == p[0].g.dma && (p[i].split == 1 || p[i].partial) &&
+                   p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&
                    !gemm_stream_eligible(p[i]);
         if (!same) {
             for (int i = 0; i < m; ++i)
@@ -840,18 +777,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         else if (bk) launch_group_bf16<false, true, A16_, B16_>(G, grid, s);    \
         else launch_group_bf16<false, false, A16_, B16_>(G, grid, s);           \
     } while (0)
-        if (p[0].bf16c && p[0].g.dma) {
-#define DETR_GROUP_DMA(BK_, NS_)                                                                                                          \
-    do {                                                                                                                                  \
-        if (ak && bk) hipLaunchKernelGGL((gemm_bf16dma_group_kernel<64, 64, 2, 2, true, true, BK_, NS_>), grid, dim3(GEMM_THREADS), 0, s, G);     \
-        else if (ak) hipLaunchKernelGGL((gemm_bf16dma_group_kernel<64, 64, 2, 2, true, false, BK_, NS_>), grid, dim3(GEMM_THREADS), 0, s, G);     \
-        else if (bk) hipLaunchKernelGGL((gemm_bf16dma_group_kernel<64, 64, 2, 2, false, true, BK_, NS_>), grid, dim3(GEMM_THREADS), 0, s, G);     \
-        else hipLaunchKernelGGL((gemm_bf16dma_group_kernel<64, 64, 2, 2, false, false, BK_, NS_>), grid, dim3(GEMM_THREADS), 0, s, G);            \
-    } while (0)
-            if (p[0].g.dma == 3) DETR_GROUP_DMA(64, 3);
-            else DETR_GROUP_DMA(32, 4);
-#undef DETR_GROUP_DMA
-        } else if (p[0].bf16c) {
+        if (p[0].bf16c) {
             if (a16 && b16) DETR_GROUP_BF16(true, true);
             else if (a16) DETR_GROUP_BF16(true, false);
             else if (b16) DETR_GROUP_BF16(false, true);

@@ -1,3 +1,5 @@
+// NOT part of the product build (round 3 experiment, measured and not kept: profiles/r03_micro_gemm_dma_experiment.txt).
+// It was wired into csrc/gemm_f32.hip by commit 8b97606 (gemm_bf16dma_kernel) and taken out again.
 // gemm_dma.h -- operand path of the bf16 tile engine for operands that are ALREADY bf16 in memory: global -> LDS by
 // LDS-DMA (`buffer_load_dwordx4 ... lds`), no VGPR staging and no ds_write pass.
 //

@@ -1,7 +1,8 @@
-"""Micro-benchmark of the bf16 tile GEMM engine on the step's dominant shapes: the register-staged operand
-path (DETR_HIP_GEMM_DMA=2) against the LDS-DMA path (default; =3: its BK = 64 variants), and the streaming kernel's extended
-epilogue.  HIP events around `reps` back-to-back launches; also checks that the variants agree.
-usage: python scripts/micro_gemm.py out.json"""
+"""Micro-benchmark of the bf16 GEMM kernels on the step's dominant shapes: every case is timed under a list of library tuning
+settings (default: the product dispatch, and DETR_HIP_GEMM_STREAM=2 = tile engine only) with HIP events around `reps`
+back-to-back launches, and the variants' results are compared with the first one.
+usage: python scripts/micro_gemm.py out.json [NAME=VAL[,NAME=VAL] ...]      (extra settings to time, e.g. DETR_HIP_GEMM_TILE=1)
+(The round-3 LDS-DMA experiment -- profiles/r03_micro_gemm_dma_experiment.txt -- was produced with an earlier form of this script.)"""
 import json
 import os
 import sys
@@ -92,22 +93,17 @@ cases = [
     ("ffn lin2 dgrad K256", 8400, 2048, 256, 1, 0, dict(mask=1, alpha=1.0 / 0.9)),
 ]
 case_ops = {c[0]: operands(c[1], c[2], c[3], c[4], c[5]) for c in cases}
+modes = [("default", {}), ("tile-engine", {"DETR_HIP_GEMM_STREAM": 2})]
+for extra in sys.argv[2:]:
+    modes.append((extra, {kv.split("=")[0]: kv.split("=")[1] for kv in extra.split(",")}))
 rows = []
-print(f"{'case':22s} {'shape':28s} {'sk':>4s} {'reg us':>8s} {'dma us':>8s} {'dma64 us':>9s}   dma/reg  maxdiff(dma) maxdiff(dma64)  TF/s(best)")
+print(f"{'case':22s} {'shape':30s} {'sk':>4s} " + " ".join(f"{n[:18]:>18s}" for n, _ in modes) + "   (us; rel. max diff vs the first)")
 for case in cases:
     name, M, N, K, ak, bk, kw = case
-    stream_case = K == 256
-    t_reg, c_reg, sk = run(case, {"DETR_HIP_GEMM_DMA": 2, **({"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})})
-    t_dma, c_dma, _ = run(case, {"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})
-    t_d64, c_d64, _ = run(case, {"DETR_HIP_GEMM_DMA": 3, **({"DETR_HIP_GEMM_STREAM": 2} if stream_case else {})})
-    extra = ""
-    if stream_case:
-        t_str, c_str, _ = run(case, {})
-        extra = f"  stream {t_str:7.1f} us diff {float((c_str - c_reg).abs().max()):.2e}"
-    scale = float(c_reg.abs().max()) + 1e-30
-    d1, d2 = float((c_dma - c_reg).abs().max()) / scale, float((c_d64 - c_reg).abs().max()) / scale
-    best = min(t_reg, t_dma, t_d64)
-    print(f"{name:22s} M{M} N{N} K{K} a{ak} b{bk:<3d} {sk:4d} {t_reg:8.1f} {t_dma:8.1f} {t_d64:9.1f}   {t_dma / t_reg:6.3f}  {d1:11.2e} {d2:13.2e}  {2.0 * M * N * K / best / 1e6:8.1f}{extra}")
-    rows.append(dict(case=name, M=M, N=N, K=K, ak=ak, bk=bk, split_k=sk, reg_us=t_reg, dma_us=t_dma, dma64_us=t_d64, rel_diff_dma=d1, rel_diff_dma64=d2))
+    res = [run(case, m) for _, m in modes]
+    scale = float(res[0][1].abs().max()) + 1e-30
+    cells = [f"{t:9.1f} {float((c - res[0][1]).abs().max()) / scale:8.1e}" for t, c, _ in res]
+    print(f"{name:22s} M{M} N{N} K{K} a{ak} b{bk:<3d} {res[0][2]:4d} " + " ".join(cells))
+    rows.append(dict(case=name, M=M, N=N, K=K, ak=ak, bk=bk, split_k=res[0][2], us={n: r[0] for (n, _), r in zip(modes, res)}))
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)

@@ -25,7 +25,7 @@ def _reset_library_tuning():
     import os
     yield
     from detr_tf import _hip
-    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_GEMM_DMA")
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
