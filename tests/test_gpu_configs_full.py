@@ -2,6 +2,8 @@
 
   C3  DETR-R50 bf16 training step, B=8, 800x1333: the bf16 step against the fp32 step of the SAME HIP path (same weights, batch
       and dropout masks -- precision is the only difference): loss, matched index sets (flips counted), every gradient tensor.
+      Measured (round 3): loss 5e-4, 5-6 % of the matched pairs flip (random-init predictions are near-degenerate), gradient
+      relative L2 median 2.7-3.1 %, 90th percentile 3-4.5 %; bounds: 1e-3 / 12 % / 5 % / 10 %, named exceptions <= 40 %.
   C4  DETR-R101, 1000x1333: bf16 forward + set loss against the fp32 oracle (B=2), and the bf16 training step at B=8
       against the fp32 HIP step.
   C5  DETR-R50, 300 queries + 5 aux losses, B=16, 800x1333: properties of the training step (every assignment problem solved,
@@ -76,6 +78,12 @@ def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_m
     assert np.isfinite(b16["total"]) and dloss <= loss_tol, rep
     assert flips <= flip_frac_max * matched, rep
     assert rep["grad_median"] <= median_max and rep["grad_p90"] <= p90_max, rep
+    # named exceptions (measured 0.10 .. 0.26): cancellation-dominated tensors -- the q / k projection of decoder layer 0's self
+    # attention (its true gradient is ~0: tgt is the zero target, every query sees the same keys), query_embed (a sum of
+    # nearly cancelling terms over layers), and the stem kernel (the end of the longest bf16 chain).  Everything else <= 12 %.
+    loose = ("transformer/decoder/layer_0/self_attn/in_proj", "query_embed/kernel", "backbone/conv1/kernel")
+    for v, name in l2:
+        assert v <= (0.40 if any(name.startswith(t) for t in loose) else 0.12), (name, v, rep)
     return rep
 
 
@@ -89,7 +97,7 @@ def test_c3_bf16_train_step_vs_fp32_step_at_b8_800x1333(hip):
     b16 = _step("bf16", params, images, t_bbox, t_class)
     # exceptions named by test_bf16_compute_mode_deviation_from_fp32_oracle: cancellation-dominated tensors (query_embed, the
     # zero-gradient q / k projections of decoder layer 0) sit far above the median; they are in the report, not in the bounds
-    _compare(a32, b16, t_bbox, 6, "C3 R50 B8 800x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.10, p90_max=0.60)
+    _compare(a32, b16, t_bbox, 6, "C3 R50 B8 800x1333", loss_tol=1e-3, flip_frac_max=0.12, median_max=0.05, p90_max=0.10)
 
 
 def test_c4_r101_bf16_forward_loss_vs_fp32_oracle_at_1000x1333(hip):
@@ -129,7 +137,7 @@ def test_c4_r101_bf16_train_step_at_b8_1000x1333(hip):
     t_bbox, t_class = L.make_targets(8, seed=19)
     a32 = _step("fp32", params, images, t_bbox, t_class, backbone="resnet101")
     b16 = _step("bf16", params, images, t_bbox, t_class, backbone="resnet101")
-    _compare(a32, b16, t_bbox, 6, "C4 R101 B8 1000x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.12, p90_max=0.70)
+    _compare(a32, b16, t_bbox, 6, "C4 R101 B8 1000x1333", loss_tol=1e-3, flip_frac_max=0.12, median_max=0.05, p90_max=0.10)
 
 
 def test_c5_300_queries_b16_800x1333_train_step(hip):
@@ -144,4 +152,4 @@ def test_c5_300_queries_b16_800x1333_train_step(hip):
     assert torch.isfinite(a32["grad"]).all() and float(a32["grad"].abs().max()) > 0
     assert float(a32["boxes"].min()) >= 0.0 and float(a32["boxes"].max()) <= 1.0
     b16 = _step("bf16", params, images, t_bbox, t_class, num_queries=300)
-    _compare(a32, b16, t_bbox, 6, "C5 R50 Q300 B16 800x1333", loss_tol=1e-3, flip_frac_max=0.35, median_max=0.12, p90_max=0.70)
+    _compare(a32, b16, t_bbox, 6, "C5 R50 Q300 B16 800x1333", loss_tol=1e-3, flip_frac_max=0.12, median_max=0.05, p90_max=0.10)
