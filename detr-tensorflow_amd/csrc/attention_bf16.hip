@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
     float m = -INFINITY, lsum = 0.0f;
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
+    const float lg2scale = a.drop_scale != 0.0f ? __log2f(a.drop_scale) : 0.0f;
 
     const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
     // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
@@ -180,27 +181,20 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r)
                 if (kbase + krow(r, hi) >= a.S) s[r] = -INFINITY;
         }
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mx = halves_max(tree_max16(s));
         const float mn = fmaxf(m, mx);
         const float corr = fast_exp2(m - mn);
-        float rs = 0.0f;
+        // the dropout scale 1/(1-p) rides in the exponent (p_r / (1-p) = exp2(s_r - mn + log2 1/(1-p))): no multiply per kept
+        // element; the row sums carry the same factor, which the epilogue takes out again
+        const float mne = mn - lg2scale;
         float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = fast_exp2(s[r] - mn);
-            rs += p[r];
-        }
-        rs += __shfl_xor(rs, 32, 64);
+        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[r] - mne);
+        const float rs = halves_sum(tree_sum16(p));
         lsum = lsum * corr + rs;
         m = mn;
-        if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
-        }
+        if (a.drop_scale != 0.0f)
+            drop_keep16(dkey, rowbase, kbase, hi, a.drop_thresh, [&](int r, bool keep) { p[r] = keep ? p[r] : 0.0f; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
         o = MFMA_BF16(frag_col(Vt, 0, lane), pack8(p), o);
@@ -217,11 +211,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
         if (it < ntiles) tile(it, 0, rk0, rv0);
     }
     if (qok) {
-        const float inv = 1.0f / lsum;
+        // lsum carries the dropout scale (see mne above): the true row sum is lsum / scale
+        const float dsc = a.drop_scale != 0.0f ? a.drop_scale : 1.0f;
+        const float inv = dsc / lsum;
         float *Ob = a.O + ((long long)b * a.T + tq) * a.ldo + h * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ob[krow(r, hi)] = o[r] * inv;
-        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum);
+        if (hi == 0) a.LSE[(long long)bh * a.T + tq] = m * AT_LN2 + logf(lsum / dsc);
     }
 }
 
@@ -312,13 +308,17 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
             dp = MFMA_BF16(frag_row(Vt, st, lane), dob[st], dp);
         }
         float ds[16];
+        // ds = p * (drop(dp) - delta), drop(dp) = keep ? dp / (1-p) : 0: one fused multiply-subtract per element either way
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] - lse);
         if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
+            const float ndl = -dl;
+            drop_keep16(dkey, rowbase, kbase, hi, a.drop_thresh,
+                        [&](int r, bool keep) { ds[r] *= keep ? __builtin_fmaf(dp[r], a.drop_scale, ndl) : ndl; });
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] = ((keep >> r) & 1u) ? dp[r] * a.drop_scale : 0.0f;
+            for (int r = 0; r < 16; ++r) ds[r] *= dp[r] - dl;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] - lse) * (dp[r] - dl);
         if (kbase + AT_KEYS > a.S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -396,12 +396,17 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
     BufSrc lsrc, dlsrc;
     lsrc.init(lse, a.T);
     dlsrc.init(dlt, a.T);
+    // With dropout the scale 1/(1-p) rides in the exponent, as in the forward: the staged row constants are
+    //   L' = lse * log2 e - log2 scale   (exp2(s - L') = P * scale)      and      delta' = delta / scale,
+    // so that  dS = P (drop(dP) - delta) = (P scale) ((keep ? dP : 0) - delta')  and  drop(P) = keep ? P scale : 0.
+    const float lg2scale = a.drop_scale != 0.0f ? __log2f(a.drop_scale) : 0.0f;
+    const float inv_scale = a.drop_scale != 0.0f ? 1.0f / a.drop_scale : 1.0f;
     float rl[LPP], rdl[LPP];
 #pragma unroll
     for (int j = 0; j < LPP; ++j) {
         const int t = tid + NTH * j;
-        rl[j] = (t < AB_ROWS && t < a.T) ? lse[t] * AT_LOG2E : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
-        rdl[j] = (t < AB_ROWS && t < a.T) ? dlt[t] : 0.0f;
+        rl[j] = (t < AB_ROWS && t < a.T) ? lse[t] * AT_LOG2E - lg2scale : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
+        rdl[j] = (t < AB_ROWS && t < a.T) ? dlt[t] * inv_scale : 0.0f;
     }
     rq.store(Qs[0], tid, qmul);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
     rd.store(Ds[0], tid);                // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
@@ -441,44 +446,50 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             s = MFMA_BF16(frag_row(Qt, st, lane), kb[st], s);
             dp = MFMA_BF16(frag_row(Dt, st, lane), vb[st], dp);
         }
-        // dropout keep bits of the 16 (query, key sk) elements of this lane.  One 32-bit hash serves the key PAIR
-        // (sk & ~1, sk | 1) of a query row (common.h), and the partner key lives in lane ^ 1: each lane hashes 8 of its 16
-        // query rows (registers r8 + 8 * parity) and takes the other 8 hashes from its neighbour with one DPP quad_perm
-        // each -- half of the integer multiplies (quarter rate) that dominated this loop.
-        uint32_t keepbits = 0xFFFFu;
+        float p[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[r] - Lt[krow(r, hi)]);          // P (* scale with dropout)
         if (a.drop_scale != 0.0f) {
+            // Keep flags of the 16 (query row, key sk) elements of this lane.  One 32-bit hash serves the key PAIR (sk & ~1,
+            // sk | 1) of a query row (common.h), and the partner key lives in lane ^ 1: each lane hashes 8 of its 16 query rows
+            // (registers r8 + 8 * parity) and takes the other 8 words from its neighbour with one DPP quad_perm each.  The
+            // 64-bit pair index is formed once per tile (drop_keep16 in attention_common.h has the derivation): the eight rows
+            // of a lane are multiples of Sp / 2 above it; a low word that could carry takes the plain drop_hash path.
             const unsigned halfSp = (unsigned)(Sp >> 1);         // Sp is even: ((row * Sp + sk) >> 1) = row * Sp/2 + (sk >> 1)
-            const unsigned long long pbase = ((unsigned long long)bh * a.T + qbase) * halfSp + (unsigned)(sk >> 1);
             const int odd = lane & 1;                            // == sk & 1 (the workgroup's first key is even)
+            const unsigned long long pb = ((unsigned long long)bh * a.T + qbase) * halfSp + (unsigned)(sk >> 1) +
+                                          (unsigned long long)(unsigned)(4 * hi + 16 * odd) * halfSp;
+            const uint32_t tlo = (uint32_t)pb, thi = (uint32_t)(pb >> 32);
+            const uint32_t key2 = dkey * 0x85EBCA6Bu + 0xC2B2AE35u;
+            const uint32_t kx = dkey ^ (thi * 0x9E3779B9u);
+            const bool slow = tlo > 0xFFFFFFFFu - 12u * halfSp;
             uint32_t hown[8], hoth[8];
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8)
-                hown[r8] = drop_hash(dkey, pbase + (unsigned)(krow(r8, hi) + 16 * odd) * halfSp);
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const unsigned c = (unsigned)((r8 & 3) + 8 * (r8 >> 2));         // krow(r8, hi) - 4 hi
+                uint32_t x = (tlo + c * halfSp) ^ kx;
+                x ^= x >> 16; x *= 0x7feb352du;
+                x ^= key2;
+                x ^= x >> 15; x *= 0x846ca68bu;
+                x ^= x >> 16;
+                hown[r8] = slow ? drop_hash(dkey, pb + (unsigned long long)c * halfSp) : x;
+            }
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
                 hoth[r8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[r8], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-            keepbits = 0;
+            // this lane's key uses the high half of a word when sk is odd, the low half otherwise: shift the half to the top
+            // and compare the whole word with thresh << 16
+            const uint32_t sh = odd ? 0u : 16u, th_hi = a.drop_thresh << 16;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t h = ((r >> 3) == odd) ? hown[r & 7] : hoth[r & 7];
-                const uint32_t half = odd ? (h >> 16) : (h & 0xFFFFu);
-                keepbits |= (half >= a.drop_thresh ? 1u : 0u) << r;
+                const uint32_t hw = ((r >> 3) == odd) ? hown[r & 7] : hoth[r & 7];
+                const bool keep = (hw << sh) >= th_hi;
+                ds[r] = p[r] * ((keep ? dp[r] : 0.0f) - Dlt[krow(r, hi)]);
+                p[r] = keep ? p[r] : 0.0f;                                      // dV uses the dropped probabilities
             }
-        }
-        float p[16], ds[16];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = krow(r, hi);
-            p[r] = fast_exp2(s[r] - Lt[qr]);
-            float dpr = dp[r];
-            if (a.drop_scale != 0.0f) {
-                const bool keep = (keepbits >> r) & 1u;
-                dpr = keep ? dpr * a.drop_scale : 0.0f;
-                ds[r] = p[r] * (dpr - Dlt[qr]);
-                p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
-            } else {
-                ds[r] = p[r] * (dpr - Dlt[qr]);
-            }
+            for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - Dlt[krow(r, hi)]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -494,8 +505,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
                 const int t = tid + NTH * j;
                 if (t < AB_ROWS) {
                     const bool ok = (it + 1) * AB_ROWS + t < a.T;
-                    Ls[cur ^ 1][t] = ok ? rl[j] * AT_LOG2E : INFINITY;     // +inf => p = exp2(-inf) = 0 for padded queries
-                    Dl[cur ^ 1][t] = ok ? rdl[j] : 0.0f;
+                    Ls[cur ^ 1][t] = ok ? rl[j] * AT_LOG2E - lg2scale : INFINITY;     // +inf => p = exp2(-inf) = 0 for padded queries
+                    Dl[cur ^ 1][t] = ok ? rdl[j] * inv_scale : 0.0f;
                 }
             }
         }

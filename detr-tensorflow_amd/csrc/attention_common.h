@@ -33,18 +33,61 @@ constexpr float AT_LOG2E = 1.4426950408889634f;
 constexpr float AT_LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
 
-// keep flags of the 16 scores a lane holds (keys kbase + krow(r, hi), r = 0..15): adjacent keys (r, r+1), r even,
-// share one hash.  rowbase = row * Sp (even), bit r of the result = keep.
-__device__ __forceinline__ uint32_t keep_bits16(uint32_t seed, unsigned long long rowbase, int kbase, int hi, uint32_t thresh16) {
-    uint32_t bits = 0;
+// Keep flags of the 16 scores a lane holds (keys kbase + krow(r, hi), r = 0..15): adjacent keys (r, r + 1), r even,
+// share one hash (common.h drop_hash).  rowbase = row * Sp and kbase are even.  f(r, keep) is called for r = 0..15.
+// Same function as drop_keep(), restated so that a tile costs 8 x (1 add + 5 xor/shift + 2 multiplies) + 16 compares:
+//   * the 64-bit pair index is formed ONCE per tile (rowbase + kbase + 4 hi) / 2; the eight pairs of a lane are small
+//     constants above it.  Its high word only enters the hash as hi * 0x9E3779B9, folded into the key once per tile;
+//     a low word within 32 of wrapping (never for < 2^33 elements) takes the plain drop_hash path;
+//   * the last round x ^= x >> 16 only changes the LOW half: the high element compares the whole word with thresh << 16;
+//   * the flags go straight to the caller (v_cmp -> v_cndmask), not through a bit mask.
+template <typename F>
+__device__ __forceinline__ void drop_keep16(uint32_t key, unsigned long long rowbase, int kbase, int hi, uint32_t thresh16, F &&f) {
+    const unsigned long long tb = (rowbase + (unsigned)(kbase + 4 * hi)) >> 1;
+    const uint32_t tlo = (uint32_t)tb, thi = (uint32_t)(tb >> 32);
+    if (tlo > 0xFFFFFFDFu) {                     // (tlo + 13 could carry into the high word: generic form)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t h = drop_hash(key, tb + (unsigned)(((r & 3) + 8 * (r >> 2)) >> 1));
+            f(r, (h & 0xFFFFu) >= thresh16);
+            f(r + 1, (h >> 16) >= thresh16);
+        }
+        return;
+    }
+    const uint32_t key2 = key * 0x85EBCA6Bu + 0xC2B2AE35u;
+    const uint32_t kx = key ^ (thi * 0x9E3779B9u);
+    const uint32_t th_hi = thresh16 << 16;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const uint32_t h = drop_hash(seed, (rowbase + (unsigned)(kbase + krow(r, hi))) >> 1);
-        bits |= ((h & 0xFFFFu) >= thresh16 ? 1u : 0u) << r;
-        bits |= ((h >> 16) >= thresh16 ? 1u : 0u) << (r + 1);
+        uint32_t x = (tlo + (uint32_t)(((r & 3) + 8 * (r >> 2)) >> 1)) ^ kx;
+        x ^= x >> 16; x *= 0x7feb352du;
+        x ^= key2;
+        x ^= x >> 15; x *= 0x846ca68bu;
+        f(r, ((x ^ (x >> 16)) & 0xFFFFu) >= thresh16);
+        f(r + 1, x >= th_hi);
     }
-    return bits;
 }
+
+// maximum / sum of the 16 registers of a score column as trees (depth 4 instead of a 15-deep dependent chain: with ~2
+// waves per SIMD the chain latency, not the issue rate, is what a tile waits for)
+__device__ __forceinline__ float tree_max16(const f32x16 &s) {
+    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]), a2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
+    const float a3 = fmaxf(fmaxf(s[9], s[10]), s[11]), a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+    return fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+}
+__device__ __forceinline__ float tree_sum16(const float (&p)[16]) {
+    const float a0 = (p[0] + p[1]) + (p[2] + p[3]), a1 = (p[4] + p[5]) + (p[6] + p[7]);
+    const float a2 = (p[8] + p[9]) + (p[10] + p[11]), a3 = (p[12] + p[13]) + (p[14] + p[15]);
+    return (a0 + a1) + (a2 + a3);
+}
+// the two halves of a wave hold the two halves of every score column (hi = lane >> 5): combine across them with
+// v_permlane32_swap (one VALU instruction; __shfl_xor(x, 32) is a ds_bpermute round trip through the LDS pipe).
+// After the swap a = [x.lo | x.lo], b = [x.hi | x.hi]: every lane sees both halves of its column.
+__device__ __forceinline__ void half_swap(float &a, float &b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float halves_max(float x) { float a = x, b = x; half_swap(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float halves_sum(float x) { float a = x, b = x; half_swap(a, b); return a + b; }
 
 
 static int attn_check_ld(long long ld, int H, const char *what) {

@@ -123,10 +123,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r)
                 if (kbase + krow(r, hi) >= a.S) s[r] = -INFINITY;
         }
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mx = halves_max(tree_max16(s));
         const float mn = fmaxf(m, mx);              // finite: every tile holds at least one valid key
         const float corr = fast_exp2(m - mn);       // exp2(-inf) = 0 on the first tile
         float rs = 0.0f;
@@ -140,9 +137,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         lsum = lsum * corr + rs;
         m = mn;
         if (a.drop_scale != 0.0f) {          // dropout on the attention probabilities (after normalisation == on p)
-            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * a.drop_scale : 0.0f;
+            drop_keep16(dkey, rowbase, kbase, hi, a.drop_thresh, [&](int r, bool keep) { p[r] = keep ? p[r] * a.drop_scale : 0.0f; });
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= corr;
@@ -230,9 +225,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         const int kbase = it * AT_KEYS;
         float ds[16];
         if (a.drop_scale != 0.0f) {
-            const uint32_t keep = keep_bits16(dkey, rowbase, kbase, hi, a.drop_thresh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] = ((keep >> r) & 1u) ? dp[r] * a.drop_scale : 0.0f;
+            drop_keep16(dkey, rowbase, kbase, hi, a.drop_thresh, [&](int r, bool keep) { dp[r] = keep ? dp[r] * a.drop_scale : 0.0f; });
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] - lse) * (dp[r] - dl);
