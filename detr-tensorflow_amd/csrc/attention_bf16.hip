@@ -22,12 +22,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int AB_LD = 40;        // bf16 per LDS tile row (80 B): 16-byte aligned rows, conflict-free ds_read_b128 fragments
-// One loop iteration stages AB_SUB sub-tiles of 32 keys (queries in the dK/dV kernel).  Measured (B=8, L=1050): 1 -> 35 / 45 /
-// 81 us (fwd / dQ / dKdV averages), 2 -> 37 / 45 / 76, 4 -> 39 / 47 / 98: the kernels are VALU-issue bound (SQ counters:
-// 48 % of the wave cycles issue instructions at ~2 waves per SIMD, MFMA busy 16 %), not load-latency bound, so fatter
-// iterations only cost registers / occupancy.
-constexpr int AB_SUB = 1;
-constexpr int AB_ROWS = AT_KEYS * AB_SUB;
+// (One 32-key tile per loop iteration: staging 2 / 4 sub-tiles per iteration and walking them in sequence measured 35 / 45 / 81 ->
+//  37 / 45 / 76 -> 39 / 47 / 98 us (fwd / dQ / dKdV averages, round 1): sequential sub-tiles add no parallelism.  What does is
+//  more WAVES per problem -- the in-workgroup split of the streamed dimension below.)
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2 r;
@@ -42,37 +39,30 @@ __device__ __forceinline__ bf16x8 pack8(const float *v) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// 32 x 32 fp32 tile -> bf16 LDS image [row][AB_LD], by a workgroup of NW waves (256 float4 per tile)
-template <int NW>
-struct TileB {
-    static constexpr int LPT = 4 * AB_SUB / NW;
+// KS x (32 x 32) fp32 tiles -> bf16 LDS images [part][row][AB_LD], loaded by the whole workgroup (NT threads).
+// Part p of the workgroup streams its own contiguous run of `nth` tiles (tile index p * nth + it): the in-workgroup split
+// of the streamed dimension (see the forward kernel).  LPT = float4 per thread, operand and iteration.
+template <int NT, int KS>
+struct TileP {
+    static constexpr int LPT = (KS * 256 + NT - 1) / NT;
+    static_assert((KS * 256) % NT == 0, "the tiles of an iteration divide evenly over the threads");
     float4 v[LPT];
-    __device__ __forceinline__ void load(const float *base, long long ld, int row0, int nrows, int tid) {
+    // rows past nrows, and tiles past this part's run, take the out-of-range offset (zeros): one unconditional request each
+    __device__ __forceinline__ void loadb(const BufSrc &src, unsigned ld_bytes, int it, int nth, int nrows, int tid) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int u = tid + 64 * NW * i;
+            const int u = tid + NT * i;
             const int r = u >> 3, c = (u & 7) * 4;
-            const int row = row0 + r;
-            v[i] = (row < nrows) ? *reinterpret_cast<const float4 *>(base + (long long)row * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row = ((r >> 5) * nth + it) * AT_KEYS + (r & 31);
+            v[i] = src.ld4((it < nth && row < nrows) ? (unsigned)row * ld_bytes + 4u * (unsigned)c : BUF_OOB);
         }
     }
-    // the same through a buffer descriptor: rows past nrows take the out-of-range offset (zeros), so the request is one
-    // unconditional instruction per float4 -- what the two-tile-deep pipelines below need for exact vmcnt waits
-    __device__ __forceinline__ void loadb(const BufSrc &src, unsigned ld_bytes, int row0, int nrows, int tid) {
+    __device__ __forceinline__ void store(unsigned short (*S)[2][AT_KEYS][AB_LD], int buf, int tid, float scale = 1.0f) const {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int u = tid + 64 * NW * i;
+            const int u = tid + NT * i;
             const int r = u >> 3, c = (u & 7) * 4;
-            const int row = row0 + r;
-            v[i] = src.ld4(row < nrows ? (unsigned)row * ld_bytes + 4u * (unsigned)c : BUF_OOB);
-        }
-    }
-    __device__ __forceinline__ void store(unsigned short (*S)[AB_LD], int tid, float scale = 1.0f) const {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int u = tid + 64 * NW * i;
-            const int r = u >> 3, c = (u & 7) * 4;
-            *reinterpret_cast<uint2 *>(&S[r][c]) =
+            *reinterpret_cast<uint2 *>(&S[r >> 5][buf][r & 31][c]) =
                 make_uint2(pk_bf16(v[i].x * scale, v[i].y * scale), pk_bf16(v[i].z * scale, v[i].w * scale));
         }
     }
@@ -107,15 +97,25 @@ __device__ __forceinline__ void ld_row8(const BufSrc &src, bool ok, unsigned byt
 
 // ------------------------------------------------------------------------------------------------
 // forward
+//
+// Workgroup = NW query waves x KS parts.  The encoder's 1050 x 1050 problems offer only ~2 waves per SIMD when a wave
+// owns 32 queries and streams all keys (64 (b, h) problems x 33 query tiles / 1024 SIMDs), and the decoder's cross
+// attention (100 queries x 1050 keys) a quarter of a wave: the kernels are bound by the latency of ONE wave's dependent
+// chain per tile (MFMA -> row maximum -> exponentials -> row sum -> pack -> MFMA), which nothing else on the SIMD covers.
+// With KS > 1 the key range is cut into KS contiguous runs; wave (qw, kp) streams run kp for the queries of qw with its own
+// running (m, l, O), and the KS partial results are merged through LDS at the end (the log-sum-exp merge of two softmax
+// partials).  Same arithmetic per key tile, twice / four times the waves in flight.
 // ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AB_ROWS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AB_ROWS][AB_LD];
+template <int NW, int KS>
+__global__ __launch_bounds__(64 * NW * KS, (KS == 2) ? 4 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
+    constexpr int NT = 64 * NW * KS;
+    __shared__ __attribute__((aligned(16))) unsigned short KVs[2 * KS][2][AT_KEYS][AB_LD];     // [K parts | V parts][buffer]
+    unsigned short (*Ks)[2][AT_KEYS][AB_LD] = KVs, (*Vs)[2][AT_KEYS][AB_LD] = KVs + KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qw = wave % NW, kp = wave / NW;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const int tq = blockIdx.x * (32 * NW) + qw * 32 + l31;
     const bool qok = tq < a.T;
     const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
     const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
@@ -143,34 +143,33 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
     const float lg2scale = a.drop_scale != 0.0f ? __log2f(a.drop_scale) : 0.0f;
 
-    const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
+    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    const int nth = (ntiles + KS - 1) / KS;            // tiles per part (the last part may own fewer)
     // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
     // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
     BufSrc ksrc, vsrc;
     ksrc.init(Kb, (long long)(a.S - 1) * a.ldk + 32);
     vsrc.init(Vb, (long long)(a.S - 1) * a.ldv + 32);
     const unsigned ldbk = (unsigned)(a.ldk * 4), ldbv = (unsigned)(a.ldv * 4);
-    TileB<NW> rk0, rv0, rk1, rv1;
-    rk0.loadb(ksrc, ldbk, 0, a.S, tid);
-    rv0.loadb(vsrc, ldbv, 0, a.S, tid);
-    rk0.store(Ks[0], tid);
-    rv0.store(Vs[0], tid);
-    rk0.loadb(ksrc, ldbk, AB_ROWS, a.S, tid);
-    rv0.loadb(vsrc, ldbv, AB_ROWS, a.S, tid);
-    rk1.loadb(ksrc, ldbk, 2 * AB_ROWS, a.S, tid);
-    rv1.loadb(vsrc, ldbv, 2 * AB_ROWS, a.S, tid);
+    TileP<NT, KS> rk0, rv0, rk1, rv1;
+    rk0.loadb(ksrc, ldbk, 0, nth, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 0, nth, a.S, tid);
+    rk0.store(Ks, 0, tid);
+    rv0.store(Vs, 0, tid);
+    rk0.loadb(ksrc, ldbk, 1, nth, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 1, nth, a.S, tid);
+    rk1.loadb(ksrc, ldbk, 2, nth, a.S, tid);
+    rv1.loadb(vsrc, ldbv, 2, nth, a.S, tid);
     lds_barrier();
-    auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
-        rpk.store(Ks[cur ^ 1], tid);
-        rpv.store(Vs[cur ^ 1], tid);
-        rpk.loadb(ksrc, ldbk, (it + 3) * AB_ROWS, a.S, tid);
-        rpv.loadb(vsrc, ldbv, (it + 3) * AB_ROWS, a.S, tid);
-#pragma unroll 1
-        for (int sub = 0; sub < AB_SUB; ++sub) {
-        const int kbase = it * AB_ROWS + sub * AT_KEYS;
-        if (kbase >= a.S) break;                    // sub-tiles past the last key (wave-uniform)
-        const unsigned short (*Kt)[AB_LD] = Ks[cur] + sub * AT_KEYS;
-        const unsigned short (*Vt)[AB_LD] = Vs[cur] + sub * AT_KEYS;
+    auto tile = [&](const int it, const int cur, TileP<NT, KS> &rpk, TileP<NT, KS> &rpv) {
+        rpk.store(Ks, cur ^ 1, tid);
+        rpv.store(Vs, cur ^ 1, tid);
+        rpk.loadb(ksrc, ldbk, it + 3, nth, a.S, tid);
+        rpv.loadb(vsrc, ldbv, it + 3, nth, a.S, tid);
+        const int kbase = (kp * nth + it) * AT_KEYS;
+        if (kbase < a.S) {                          // (wave-uniform: the last part may run out of keys early)
+        const unsigned short (*Kt)[AB_LD] = Ks[kp][cur];
+        const unsigned short (*Vt)[AB_LD] = Vs[kp][cur];
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
@@ -199,16 +198,42 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[r] *= corr;
         o = MFMA_BF16(frag_col(Vt, 0, lane), pack8(p), o);
         o = MFMA_BF16(frag_col(Vt, 1, lane), pack8(p + 8), o);
-        }   // sub
+        }
         lds_barrier();
     };
     {
         int it = 0;
-        for (; it + 2 <= ntiles; it += 2) {
+        for (; it + 2 <= nth; it += 2) {
             tile(it, 0, rk0, rv0);
             tile(it + 1, 1, rk1, rv1);
         }
-        if (it < ntiles) tile(it, 0, rk0, rv0);
+        if (it < nth) tile(it, 0, rk0, rv0);
+    }
+    if constexpr (KS > 1) {
+        // merge the KS partial softmaxes of a query: (m, l, O) of parts 1 .. KS-1 travel through LDS (component-major:
+        // conflict-free), part 0 rescales everything to the common maximum.  A part without keys left (m = -inf, l = 0).
+        __syncthreads();                                  // (every tile consumed, the trailing prefetches have landed in registers only)
+        float *comb = reinterpret_cast<float *>(&KVs[0][0][0][0]);
+        static_assert((KS - 1) * NW * 18 * 64 * 4 <= (int)sizeof(KVs), "merge buffer fits the tile buffers");
+        if (kp > 0) {
+            float *c = comb + ((kp - 1) * NW + qw) * 18 * 64 + lane;
+            c[0] = m; c[64] = lsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[(2 + r) * 64] = o[r];
+        }
+        __syncthreads();
+        if (kp > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float *c = comb + ((k - 1) * NW + qw) * 18 * 64 + lane;
+            const float mb = c[0], lb = c[64];
+            const float mn = fmaxf(m, mb);
+            const float ca = fast_exp2(m - mn), cb = fast_exp2(mb - mn);
+            lsum = lsum * ca + lb * cb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = o[r] * ca + c[(2 + r) * 64] * cb;
+            m = mn;
+        }
     }
     if (qok) {
         // lsum carries the dropout scale (see mne above): the true row sum is lsum / scale
@@ -222,16 +247,19 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 1/2: dQ (per query tile, streams the keys) and delta = rowsum(dO * O)
+// backward 1/2: dQ (per query tile, streams the keys; KS parts as in the forward, partial dQ summed through LDS)
+// and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AB_ROWS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AB_ROWS][AB_LD];
+template <int NW, int KS, int MINW = ((NW * KS > 4) ? 2 : 3)>
+__global__ __launch_bounds__(64 * NW * KS, MINW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+    constexpr int NT = 64 * NW * KS;
+    __shared__ __attribute__((aligned(16))) unsigned short KVs[2 * KS][2][AT_KEYS][AB_LD];
+    unsigned short (*Ks)[2][AT_KEYS][AB_LD] = KVs, (*Vs)[2][AT_KEYS][AB_LD] = KVs + KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qw = wave % NW, kp = wave / NW;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int tq = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const int tq = blockIdx.x * (32 * NW) + qw * 32 + l31;
     const bool qok = tq < a.T;
     const long long qoff = ((long long)b * a.T + tq) * a.lddq + h * 32;
     const float *Kb = a.K + (long long)b * a.S * a.ldk + h * 32;
@@ -262,43 +290,40 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
             dob[s] = pack8(tdo);
         }
     }
-    dl += __shfl_xor(dl, 32, 64);
+    dl = halves_sum(dl);
     const float lse = qok ? a.LSE[(long long)bh * a.T + tq] * AT_LOG2E : INFINITY;
-    if (qok && hi == 0) a.delta[(long long)bh * a.T + tq] = dl;
+    if (qok && hi == 0 && kp == 0) a.delta[(long long)bh * a.T + tq] = dl;
     const unsigned long long rowbase = ((unsigned long long)bh * a.T + tq) * (unsigned long long)((a.S + 1) & ~1);
 
     f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.0f;
 
-    const int ntiles = (a.S + AB_ROWS - 1) / AB_ROWS;
-    // K / V tiles: operand pipeline two tiles deep with LDS-only barriers (see gemm_bf16c_body in gemm_f32.hip): tile it
-    // is consumed from LDS while tile it+1 waits in one register set and tile it+2 is in flight into the other.
+    const int ntiles = (a.S + AT_KEYS - 1) / AT_KEYS;
+    const int nth = (ntiles + KS - 1) / KS;
     BufSrc ksrc, vsrc;
     ksrc.init(Kb, (long long)(a.S - 1) * a.ldk + 32);
     vsrc.init(Vb, (long long)(a.S - 1) * a.ldv + 32);
     const unsigned ldbk = (unsigned)(a.ldk * 4), ldbv = (unsigned)(a.ldv * 4);
-    TileB<NW> rk0, rv0, rk1, rv1;
-    rk0.loadb(ksrc, ldbk, 0, a.S, tid);
-    rv0.loadb(vsrc, ldbv, 0, a.S, tid);
-    rk0.store(Ks[0], tid);
-    rv0.store(Vs[0], tid);
-    rk0.loadb(ksrc, ldbk, AB_ROWS, a.S, tid);
-    rv0.loadb(vsrc, ldbv, AB_ROWS, a.S, tid);
-    rk1.loadb(ksrc, ldbk, 2 * AB_ROWS, a.S, tid);
-    rv1.loadb(vsrc, ldbv, 2 * AB_ROWS, a.S, tid);
+    TileP<NT, KS> rk0, rv0, rk1, rv1;
+    rk0.loadb(ksrc, ldbk, 0, nth, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 0, nth, a.S, tid);
+    rk0.store(Ks, 0, tid);
+    rv0.store(Vs, 0, tid);
+    rk0.loadb(ksrc, ldbk, 1, nth, a.S, tid);
+    rv0.loadb(vsrc, ldbv, 1, nth, a.S, tid);
+    rk1.loadb(ksrc, ldbk, 2, nth, a.S, tid);
+    rv1.loadb(vsrc, ldbv, 2, nth, a.S, tid);
     lds_barrier();
-    auto tile = [&](const int it, const int cur, TileB<NW> &rpk, TileB<NW> &rpv) {
-        rpk.store(Ks[cur ^ 1], tid);
-        rpv.store(Vs[cur ^ 1], tid);
-        rpk.loadb(ksrc, ldbk, (it + 3) * AB_ROWS, a.S, tid);
-        rpv.loadb(vsrc, ldbv, (it + 3) * AB_ROWS, a.S, tid);
-#pragma unroll 1
-        for (int sub = 0; sub < AB_SUB; ++sub) {
-        const int kbase = it * AB_ROWS + sub * AT_KEYS;
-        if (kbase >= a.S) break;
-        const unsigned short (*Kt)[AB_LD] = Ks[cur] + sub * AT_KEYS;
-        const unsigned short (*Vt)[AB_LD] = Vs[cur] + sub * AT_KEYS;
+    auto tile = [&](const int it, const int cur, TileP<NT, KS> &rpk, TileP<NT, KS> &rpv) {
+        rpk.store(Ks, cur ^ 1, tid);
+        rpv.store(Vs, cur ^ 1, tid);
+        rpk.loadb(ksrc, ldbk, it + 3, nth, a.S, tid);
+        rpv.loadb(vsrc, ldbv, it + 3, nth, a.S, tid);
+        const int kbase = (kp * nth + it) * AT_KEYS;
+        if (kbase < a.S) {
+        const unsigned short (*Kt)[AB_LD] = Ks[kp][cur];
+        const unsigned short (*Vt)[AB_LD] = Vs[kp][cur];
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
@@ -326,16 +351,34 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
         }
         dq = MFMA_BF16(frag_col(Kt, 0, lane), pack8(ds), dq);
         dq = MFMA_BF16(frag_col(Kt, 1, lane), pack8(ds + 8), dq);
-        }   // sub
+        }
         lds_barrier();
     };
     {
         int it = 0;
-        for (; it + 2 <= ntiles; it += 2) {
+        for (; it + 2 <= nth; it += 2) {
             tile(it, 0, rk0, rv0);
             tile(it + 1, 1, rk1, rv1);
         }
-        if (it < ntiles) tile(it, 0, rk0, rv0);
+        if (it < nth) tile(it, 0, rk0, rv0);
+    }
+    if constexpr (KS > 1) {
+        __syncthreads();
+        float *comb = reinterpret_cast<float *>(&KVs[0][0][0][0]);
+        static_assert((KS - 1) * NW * 16 * 64 * 4 <= (int)sizeof(KVs), "merge buffer fits the tile buffers");
+        if (kp > 0) {
+            float *c = comb + ((kp - 1) * NW + qw) * 16 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r * 64] = dq[r];
+        }
+        __syncthreads();
+        if (kp > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float *c = comb + ((k - 1) * NW + qw) * 16 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[r] += c[r * 64];
+        }
     }
     if (qok) {
 #pragma unroll
@@ -346,16 +389,20 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_bf16_kernel(AttnArgs a
 // ------------------------------------------------------------------------------------------------
 // backward 2/2: dK, dV (per key tile, streams the queries): lane l holds key (l&31) and 16 queries krow(r, hi).
 // The Q tile is staged as bf16(Q * log2 e) -- the forward's rounded operand -- and K unscaled.
+// KS parts as in the forward, here over the QUERY tiles: wave (kw, qp) accumulates dK / dV of the keys of kw over the
+// query run qp; the partial sums are added through LDS at the end (fixed order: deterministic).
 // ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AB_ROWS][AB_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Ds[2][AB_ROWS][AB_LD];
-    __shared__ __attribute__((aligned(16))) float Ls[2][AB_ROWS], Dl[2][AB_ROWS];
+template <int NW, int KS, int MINW = ((NW * KS > 4) ? 2 : 3)>
+__global__ __launch_bounds__(64 * NW * KS, MINW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+    constexpr int NT = 64 * NW * KS;
+    __shared__ __attribute__((aligned(16))) unsigned short QDs[2 * KS][2][AT_KEYS][AB_LD];     // [Q parts | dO parts][buffer]
+    __shared__ __attribute__((aligned(16))) float Ls[KS][2][AT_KEYS], Dl[KS][2][AT_KEYS];
+    unsigned short (*Qs)[2][AT_KEYS][AB_LD] = QDs, (*Ds)[2][AT_KEYS][AB_LD] = QDs + KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kw = wave % NW, qp = wave / NW;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int sk = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const int sk = blockIdx.x * (32 * NW) + kw * 32 + l31;
     const bool kok = sk < a.S;
     const long long dkoff = ((long long)b * a.S + sk) * a.lddk + h * 32, dvoff = ((long long)b * a.S + sk) * a.lddv + h * 32;
     const float *Qb = a.Q + (long long)b * a.T * a.ldq + h * 32;
@@ -385,59 +432,69 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.0f; dv[r] = 0.0f; }
 
-    const int ntiles = (a.T + AB_ROWS - 1) / AB_ROWS;
-    constexpr int NTH = 64 * NW;                      // threads; each stages AB_ROWS / NTH (l, delta) pairs per iteration
-    constexpr int LPP = (AB_ROWS + NTH - 1) / NTH;
+    const int ntiles = (a.T + AT_KEYS - 1) / AT_KEYS;
+    const int nth = (ntiles + KS - 1) / KS;           // query tiles per part
+    constexpr int LPP = (KS * AT_KEYS + NT - 1) / NT; // (lse, delta) pairs a thread stages per iteration (0 or 1 here)
     // (one-tile-deep staging here: the two-deep form of the forward / dQ kernels needs a second register set, which takes
     //  this kernel from 2 waves per SIMD to 1 -- measured +0.7 ms per step)
-    TileB<NW> rq, rd;
-    rq.load(Qb, a.ldq, 0, a.T, tid);
-    rd.load(Db, a.lddo, 0, a.T, tid);
-    BufSrc lsrc, dlsrc;
+    BufSrc qsrc, dosrc, lsrc, dlsrc;
+    qsrc.init(Qb, (long long)(a.T - 1) * a.ldq + 32);
+    dosrc.init(Db, (long long)(a.T - 1) * a.lddo + 32);
     lsrc.init(lse, a.T);
     dlsrc.init(dlt, a.T);
+    const unsigned ldbq = (unsigned)(a.ldq * 4), ldbd = (unsigned)(a.lddo * 4);
     // With dropout the scale 1/(1-p) rides in the exponent, as in the forward: the staged row constants are
     //   L' = lse * log2 e - log2 scale   (exp2(s - L') = P * scale)      and      delta' = delta / scale,
     // so that  dS = P (drop(dP) - delta) = (P scale) ((keep ? dP : 0) - delta')  and  drop(P) = keep ? P scale : 0.
     const float lg2scale = a.drop_scale != 0.0f ? __log2f(a.drop_scale) : 0.0f;
     const float inv_scale = a.drop_scale != 0.0f ? 1.0f / a.drop_scale : 1.0f;
+    TileP<NT, KS> rq, rd;
     float rl[LPP], rdl[LPP];
+    // raw (lse, delta) of iteration `it` for the rows this thread stages: row t of the iteration = part t >> 5, query
+    // (part * nth + it) * 32 + (t & 31); scaling / padding happens when the set is stored (arithmetic on a just-requested
+    // value would put a vmcnt wait in front of the iteration's MFMAs)
+    auto load_rows = [&](int it) {
 #pragma unroll
-    for (int j = 0; j < LPP; ++j) {
-        const int t = tid + NTH * j;
-        rl[j] = (t < AB_ROWS && t < a.T) ? lse[t] * AT_LOG2E - lg2scale : INFINITY;      // +inf => p = exp2(-inf) = 0 for padded queries
-        rdl[j] = (t < AB_ROWS && t < a.T) ? dlt[t] * inv_scale : 0.0f;
-    }
-    rq.store(Qs[0], tid, qmul);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
-    rd.store(Ds[0], tid);                // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
+        for (int j = 0; j < LPP; ++j) {
+            const int t = tid + NT * j;
+            const int q = ((t >> 5) * nth + it) * AT_KEYS + (t & 31);
+            const bool ok = t < KS * AT_KEYS && it < nth && q < a.T;
+            rl[j] = lsrc.ld1(ok ? 4u * (unsigned)q : BUF_OOB);
+            rdl[j] = dlsrc.ld1(ok ? 4u * (unsigned)q : BUF_OOB);
+        }
+    };
+    auto store_rows = [&](int it, int buf) {
 #pragma unroll
-    for (int j = 0; j < LPP; ++j)
-        if (tid + NTH * j < AB_ROWS) { Ls[0][tid + NTH * j] = rl[j]; Dl[0][tid + NTH * j] = rdl[j]; }
-    __syncthreads();
-    int cur = 0;
-    for (int it = 0; it < ntiles; ++it) {
-        const bool more = (it + 1) < ntiles;
-        if (more) {
-            const int t0 = (it + 1) * AB_ROWS;
-            rq.load(Qb, a.ldq, t0, a.T, tid);
-            rd.load(Db, a.lddo, t0, a.T, tid);
-            // raw values only: scaling / padding happens when the set is stored -- arithmetic on a just-requested value
-            // would put a vmcnt wait (for this AND the older Q / dO requests) in front of this iteration's MFMAs
-#pragma unroll
-            for (int j = 0; j < LPP; ++j) {
-                const int t = tid + NTH * j;
-                const bool ok = t < AB_ROWS && t0 + t < a.T;
-                rl[j] = lsrc.ld1(ok ? 4u * (unsigned)(t0 + t) : BUF_OOB);
-                rdl[j] = dlsrc.ld1(ok ? 4u * (unsigned)(t0 + t) : BUF_OOB);
+        for (int j = 0; j < LPP; ++j) {
+            const int t = tid + NT * j;
+            if (t < KS * AT_KEYS) {
+                const int q = ((t >> 5) * nth + it) * AT_KEYS + (t & 31);
+                const bool ok = it < nth && q < a.T;
+                Ls[t >> 5][buf][t & 31] = ok ? rl[j] * AT_LOG2E - lg2scale : INFINITY;     // +inf => p = exp2(-inf) = 0 for padded queries
+                Dl[t >> 5][buf][t & 31] = ok ? rdl[j] * inv_scale : 0.0f;
             }
         }
-#pragma unroll 1
-        for (int sub = 0; sub < AB_SUB; ++sub) {
-        const int qbase = it * AB_ROWS + sub * AT_KEYS;
-        if (qbase >= a.T) break;                    // sub-tiles past the last query (wave-uniform)
-        const unsigned short (*Qt)[AB_LD] = Qs[cur] + sub * AT_KEYS;
-        const unsigned short (*Dt)[AB_LD] = Ds[cur] + sub * AT_KEYS;
-        const float *Lt = Ls[cur] + sub * AT_KEYS, *Dlt = Dl[cur] + sub * AT_KEYS;
+    };
+    rq.loadb(qsrc, ldbq, 0, nth, a.T, tid);
+    rd.loadb(dosrc, ldbd, 0, nth, a.T, tid);
+    load_rows(0);
+    rq.store(Qs, 0, tid, qmul);      // bf16(Q * log2 e): the SAME rounded operands as the forward / dQ kernels, so that
+    rd.store(Ds, 0, tid);            // exp2(s - lse) is consistent with the stored LSE; dK is rescaled by ln 2 at the end
+    store_rows(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < nth; ++it) {
+        const bool more = (it + 1) < nth;
+        if (more) {
+            rq.loadb(qsrc, ldbq, it + 1, nth, a.T, tid);
+            rd.loadb(dosrc, ldbd, it + 1, nth, a.T, tid);
+            load_rows(it + 1);
+        }
+        const int qbase = (qp * nth + it) * AT_KEYS;
+        if (qbase < a.T) {                          // (wave-uniform: the last part may run out of queries early)
+        const unsigned short (*Qt)[AB_LD] = Qs[qp][cur];
+        const unsigned short (*Dt)[AB_LD] = Ds[qp][cur];
+        const float *Lt = Ls[qp][cur], *Dlt = Dl[qp][cur];
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
@@ -496,22 +553,31 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
             dv = MFMA_BF16(frag_col(Dt, s2, lane), pack8(p + 8 * s2), dv);
             dk = MFMA_BF16(frag_col(Qt, s2, lane), pack8(ds + 8 * s2), dk);
         }
-        }   // sub
+        }
         if (more) {
-            rq.store(Qs[cur ^ 1], tid, qmul);
-            rd.store(Ds[cur ^ 1], tid);
-#pragma unroll
-            for (int j = 0; j < LPP; ++j) {
-                const int t = tid + NTH * j;
-                if (t < AB_ROWS) {
-                    const bool ok = (it + 1) * AB_ROWS + t < a.T;
-                    Ls[cur ^ 1][t] = ok ? rl[j] * AT_LOG2E - lg2scale : INFINITY;     // +inf => p = exp2(-inf) = 0 for padded queries
-                    Dl[cur ^ 1][t] = ok ? rdl[j] * inv_scale : 0.0f;
-                }
-            }
+            rq.store(Qs, cur ^ 1, tid, qmul);
+            rd.store(Ds, cur ^ 1, tid);
+            store_rows(it + 1, cur ^ 1);
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (KS > 1) {
+        float *comb = reinterpret_cast<float *>(&QDs[0][0][0][0]);
+        static_assert((KS - 1) * NW * 32 * 64 * 4 <= (int)sizeof(QDs), "merge buffer fits the tile buffers");
+        if (qp > 0) {
+            float *c = comb + ((qp - 1) * NW + kw) * 32 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c[r * 64] = dk[r]; c[(16 + r) * 64] = dv[r]; }
+        }
+        __syncthreads();
+        if (qp > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float *c = comb + ((k - 1) * NW + kw) * 32 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[r] += c[r * 64]; dv[r] += c[(16 + r) * 64]; }
+        }
     }
     if (kok) {
 #pragma unroll
@@ -526,19 +592,48 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dkv_bf16_kernel(AttnArgs 
 
 namespace detr {
 
+// Parts of the streamed dimension per workgroup (KS): enough waves to cover each other's dependent chains -- the aim is
+// >= 4 waves per SIMD (4096 on the chip) -- but at least 8 streamed tiles per part.  DETR_HIP_ATTN_SPLIT=1 / 2 / 4 forces.
+static int attn_parts(int rows, int streamed, int bh, int max_parts) {
+    const int force = tune(T_ATTN_SPLIT);         // (22: heuristic, with the 4-waves-per-SIMD builds of the two-part backward kernels)
+    if (force == 1 || force == 2 || (force == 4 && max_parts >= 4)) return force;
+    const long long waves = (long long)cdiv(rows, 64) * 2 * bh;       // 2-wave row groups
+    const int tiles = cdiv(streamed, AT_KEYS);
+    if (waves >= 4096 || tiles < 16) return 1;
+    if (waves * 2 >= 2048 || tiles < 32 || max_parts < 4) return 2;
+    return 4;
+}
+
 int attn_fwd_bf16_launch(const AttnArgs &a, hipStream_t s) {
-    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
+    const int bh = a.B * a.H;
+    if (attn_waves(a.T, bh) == 2) {
+        const dim3 grid((unsigned)cdiv(a.T, 64), (unsigned)bh);
+        const int ks = attn_parts(a.T, a.S, bh, 4);
+        if (ks == 4) hipLaunchKernelGGL((attn_fwd_bf16_kernel<2, 4>), grid, dim3(512), 0, s, a);
+        else if (ks == 2) hipLaunchKernelGGL((attn_fwd_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<2, 1>), grid, dim3(128), 0, s, a);
+    } else hipLaunchKernelGGL((attn_fwd_bf16_kernel<4, 1>), dim3((unsigned)cdiv(a.T, 128), (unsigned)bh), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention fwd (bf16 MFMA)");
     return 0;
 }
 
 int attn_bwd_bf16_launch(const AttnArgs &a, hipStream_t s) {
-    if (attn_waves(a.T, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, dim3((unsigned)cdiv(a.T, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<4>, dim3((unsigned)cdiv(a.T, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
+    const int bh = a.B * a.H;
+    if (attn_waves(a.T, bh) == 2) {
+        const dim3 grid((unsigned)cdiv(a.T, 64), (unsigned)bh);
+        const int ks = attn_parts(a.T, a.S, bh, 4);
+        if (ks == 4) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 4>), grid, dim3(512), 0, s, a);
+        else if (ks == 2 && tune(T_ATTN_SPLIT) == 22) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 2, 4>), grid, dim3(256), 0, s, a);   // A/B: 4 waves per SIMD (spills 33 dwords)
+        else if (ks == 2) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 1>), grid, dim3(128), 0, s, a);
+    } else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<4, 1>), dim3((unsigned)cdiv(a.T, 128), (unsigned)bh), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq (bf16 MFMA)");
-    if (attn_waves(a.S, a.B * a.H) == 2) hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, dim3((unsigned)cdiv(a.S, 64), (unsigned)(a.B * a.H)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<4>, dim3((unsigned)cdiv(a.S, 128), (unsigned)(a.B * a.H)), dim3(256), 0, s, a);
+    if (attn_waves(a.S, bh) == 2) {
+        const dim3 grid((unsigned)cdiv(a.S, 64), (unsigned)bh);
+        if (attn_parts(a.S, a.T, bh, 2) >= 2 && tune(T_ATTN_SPLIT) == 22) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 2, 4>), grid, dim3(256), 0, s, a);
+        else if (attn_parts(a.S, a.T, bh, 2) >= 2) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 1>), grid, dim3(128), 0, s, a);
+    } else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 1>), dim3((unsigned)cdiv(a.S, 128), (unsigned)bh), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dkv (bf16 MFMA)");
     return 0;
 }

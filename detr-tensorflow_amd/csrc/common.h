@@ -86,6 +86,7 @@ enum TuneKey {
     T_WGRAD_TILE,
     T_STEM_ROWS,
     T_ATTN_WAVES,
+    T_ATTN_SPLIT,
     T_COUNT
 };
 int tune(TuneKey k);

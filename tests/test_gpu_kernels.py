@@ -25,7 +25,7 @@ def _reset_library_tuning():
     import os
     yield
     from detr_tf import _hip
-    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE")
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1361,3 +1361,45 @@ def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bia
     diff = (stream - generic).abs()
     assert float((diff > 0).double().mean()) < 2e-3, float((diff > 0).double().mean())
     assert float((diff / (generic.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
+
+
+@pytest.mark.parametrize("split", [1, 2, 4, 22])
+@pytest.mark.parametrize("B,T,S,p", [(2, 200, 333, 0.1), (1, 70, 40, 0.0), (1, 129, 1050, 0.1)])
+def test_fused_attention_bf16_in_workgroup_split(hip, split, B, T, S, p):
+    """The bf16 attention kernels with the streamed dimension cut into 1 / 2 / 4 runs per workgroup (DETR_HIP_ATTN_SPLIT; 22 = the
+    two-run backward kernels built for 4 waves per SIMD): forward merge of the partial softmaxes (incl. runs that own no keys:
+    S = 40 is two tiles for four runs), partial dQ / dK / dV sums, ragged last tiles -- all against the fp64 reference with the
+    oracle's dropout masks.  The split must not change what is computed."""
+    from oracle import dropout_ref as DR
+    torch.manual_seed(B * 13 + T + S)
+    H, hd, seed = 8, 32, 4242
+    D = H * hd
+    q = (torch.randn(B, T, D, dtype=torch.float64) * 0.6).requires_grad_(True)
+    k = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    v = torch.randn(B, S, D, dtype=torch.float64).requires_grad_(True)
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2)
+    w = torch.softmax(sc, dim=-1)
+    if p > 0.0:
+        keep = torch.from_numpy(DR.keep_mask(DR.drop_key(seed, 0), DR.attn_index(B * H, T, S).reshape(B, H, T, S), p))
+        w = torch.where(keep, w / (1.0 - p), torch.zeros_like(w))
+    o = (w @ vh).transpose(1, 2).reshape(B, T, D)
+    do = torch.randn(B, T, D, dtype=torch.float64)
+    o.backward(do)
+    qd, kd, vd, dod = (t.view(-1, D) for t in (g(q.detach().float()), g(k.detach().float()), g(v.detach().float()), g(do.float())))
+    hip.set_tuning("DETR_HIP_ATTN_SPLIT", split)
+    try:
+        od, lse = torch.full((B * T, D), 7.0, device=DEV), torch.zeros(B * H, T, device=DEV)
+        hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=1, dropout_p=p, dropout_site=seed)
+        dq, dk, dv = (torch.full_like(t, 3.0).view(B, -1, D) for t in (qd, kd, vd))
+        delta = torch.zeros(B * H, T, device=DEV)
+        hip.attention(qd, kd, vd, od, lse, B, H, T, S, compute=1, dropout_p=p, dropout_site=seed, d_o=dod, dq=dq.view(-1, D),
+                      dk=dk.view(-1, D), dv=dv.view(-1, D), delta=delta)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_tuning("DETR_HIP_ATTN_SPLIT", None)
+    close(od.view(B, T, D), o, rtol=1.5e-2, what=f"bf16 attention fwd (split {split})")
+    close(lse.view(B, H, T), torch.logsumexp(sc, dim=-1), rtol=3e-3, what=f"bf16 attention lse (split {split})")
+    close(dq, q.grad, rtol=2.5e-2, what=f"bf16 attention dq (split {split})")
+    close(dk, k.grad, rtol=2.5e-2, what=f"bf16 attention dk (split {split})")
+    close(dv, v.grad, rtol=2.5e-2, what=f"bf16 attention dv (split {split})")
