@@ -83,8 +83,23 @@ class DetrModel:
     def _npz(path):
         return path if path.endswith(".npz") else path + ".npz"      # np.savez appends the suffix: keep save / load symmetric
 
+    def wanted_shapes(self):
+        """{parameter name: shape} of everything a weight file may provide (trainable tensors + frozen-BN vectors)."""
+        P = self.engine.P
+        out = dict(P.shapes)
+        for p, c in P.bn.items():
+            for leaf in P.bn_leaves:
+                out[f"{p}/{leaf}"] = (c,)
+        return out
+
     def load_weights(self, path_or_dict):
+        """A parameter dict, this package's `.npz` file, or a TensorFlow checkpoint prefix (`x.ckpt` with `x.ckpt.index` next to
+        it: the reference's own weight files, weights.py:33 -- read without TensorFlow).  Returns the names left unset."""
         # (ParamStore.load / load_dict notify the engine: frozen-BN refold + weights-version bump)
+        if isinstance(path_or_dict, str) and os.path.exists(path_or_dict + ".index"):
+            from .weights import load_tf_checkpoint_params
+            params, _unused = load_tf_checkpoint_params(path_or_dict, self.wanted_shapes())
+            return self.engine.load_params(params)
         return self.engine.P.load(self._npz(path_or_dict)) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
 
     def save_weights(self, path):
@@ -164,9 +179,18 @@ def get_detr_model(config, include_top=False, nb_class=None, weights=None, tf_ba
                       seed=seed, dropout=dropout, precision=precision, tf_backbone=tf_backbone)
     if weights is not None:
         if isinstance(weights, str) and weights == "detr":
-            raise NotImplementedError('weights="detr": the reference downloads a TF checkpoint from GCS (weights.py:5-11); convert the '
-                                      "original PyTorch detr-r50 state-dict with detr_tf.networks.weights.convert_state_dict() (or "
-                                      "`python -m detr_tf.networks.weights in.pth out.npz`) and pass the .npz path instead")
+            # the reference downloads three files from GCS into weights/detr/ (weights.py:5-11,24-32) and loads
+            # weights/detr/detr.ckpt; there is no network here, but files placed there are read (networks/tf_checkpoint.py)
+            weights = os.path.join("weights", "detr", "detr.ckpt")
+            if not os.path.exists(weights + ".index"):
+                raise FileNotFoundError(
+                    f'weights="detr": {weights}.index not found.  The reference fetches checkpoint / detr.ckpt.index / '
+                    "detr.ckpt.data-00000-of-00001 from https://storage.googleapis.com/visualbehavior-publicweights/detr/ "
+                    "(weights.py:5-11); put them under weights/detr/, or convert the original PyTorch detr-r50 state-dict with "
+                    "`python -m detr_tf.networks.weights in.pth out.npz` and pass the .npz path")
+            model.load_weights(weights)          # (`.expect_partial()`, weights.py:35: fine-tuning heads are not in the file)
+            weights = None
+    if weights is not None:
         model.load_weights(weights)
     if include_top is False and nb_class is not None:
         config.add_nlayers([_Layer("cls_layer", None), _Layer("pos_layer", None)])      # detr.py:103

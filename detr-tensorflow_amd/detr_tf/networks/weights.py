@@ -227,6 +227,34 @@ def export_state_dict(params):
     return out
 
 
+def map_tf_variables(variables, wanted):
+    """TensorFlow variable names -> this package's parameter names.  `variables`: {name: array} from
+    tf_checkpoint.load_tf_checkpoint (Keras names such as `detr/transformer/encoder/layer_0/linear1/kernel`, whatever model /
+    scope prefix the saving program put in front); `wanted`: {parameter name: shape} (ParamStore.shapes + the frozen-BN
+    vectors).  A variable is taken for parameter K when its name is K or ends with "/" + K -- the LONGEST such K wins, so
+    `.../layer1/0/conv1/kernel` is never mistaken for the stem's `backbone/conv1/kernel` -- and the shape agrees.
+    Returns (params, unused variable names)."""
+    by_len = sorted(wanted, key=len, reverse=True)
+    params, unused = {}, []
+    for name, arr in variables.items():
+        n = name[:-2] if name.endswith(":0") else name
+        hit = next((k for k in by_len if n == k or n.endswith("/" + k)), None)
+        if hit is None or tuple(np.shape(arr)) != tuple(wanted[hit]):
+            unused.append(name)
+            continue
+        if hit in params:
+            raise ValueError(f"two checkpoint variables map to {hit}: {name} and another one")
+        params[hit] = np.ascontiguousarray(arr, dtype=np.float32)
+    return params, unused
+
+
+def load_tf_checkpoint_params(prefix, wanted):
+    """Parameters of a TensorFlow checkpoint `<prefix>.index` / `.data-*` (the reference's `weights="detr"` files,
+    weights.py:5-11,33) under this package's names; no TensorFlow needed (networks/tf_checkpoint.py)."""
+    from .tf_checkpoint import load_tf_checkpoint
+    return map_tf_variables(load_tf_checkpoint(prefix), wanted)
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     if len(argv) != 2:
