@@ -250,8 +250,8 @@ __global__ __launch_bounds__(64 * NW * KS, (KS == 2) ? 4 : 1) void attn_fwd_bf16
 // backward 1/2: dQ (per query tile, streams the keys; KS parts as in the forward, partial dQ summed through LDS)
 // and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-template <int NW, int KS, int MINW = ((NW * KS > 4) ? 2 : 3)>
-__global__ __launch_bounds__(64 * NW * KS, MINW) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+template <int NW, int KS>
+__global__ __launch_bounds__(64 * NW * KS, (NW * KS > 4) ? 2 : 3) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
     constexpr int NT = 64 * NW * KS;
     __shared__ __attribute__((aligned(16))) unsigned short KVs[2 * KS][2][AT_KEYS][AB_LD];
     unsigned short (*Ks)[2][AT_KEYS][AB_LD] = KVs, (*Vs)[2][AT_KEYS][AB_LD] = KVs + KS;
@@ -392,8 +392,8 @@ __global__ __launch_bounds__(64 * NW * KS, MINW) void attn_bwd_dq_bf16_kernel(At
 // KS parts as in the forward, here over the QUERY tiles: wave (kw, qp) accumulates dK / dV of the keys of kw over the
 // query run qp; the partial sums are added through LDS at the end (fixed order: deterministic).
 // ------------------------------------------------------------------------------------------------
-template <int NW, int KS, int MINW = ((NW * KS > 4) ? 2 : 3)>
-__global__ __launch_bounds__(64 * NW * KS, MINW) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+template <int NW, int KS>
+__global__ __launch_bounds__(64 * NW * KS, (NW * KS > 4) ? 2 : 3) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
     constexpr int NT = 64 * NW * KS;
     __shared__ __attribute__((aligned(16))) unsigned short QDs[2 * KS][2][AT_KEYS][AB_LD];     // [Q parts | dO parts][buffer]
     __shared__ __attribute__((aligned(16))) float Ls[KS][2][AT_KEYS], Dl[KS][2][AT_KEYS];
@@ -595,11 +595,16 @@ namespace detr {
 // Parts of the streamed dimension per workgroup (KS): enough waves to cover each other's dependent chains -- the aim is
 // >= 4 waves per SIMD (4096 on the chip) -- but at least 8 streamed tiles per part.  DETR_HIP_ATTN_SPLIT=1 / 2 / 4 forces.
 static int attn_parts(int rows, int streamed, int bh, int max_parts) {
-    const int force = tune(T_ATTN_SPLIT);         // (22: heuristic, with the 4-waves-per-SIMD builds of the two-part backward kernels)
-    if (force == 1 || force == 2 || (force == 4 && max_parts >= 4)) return force;
+    // Measured (scripts/micro_attn.py, dropout 0.1, us fwd / bwd; 1 / 2 / 4 parts): B8 1050x1050 66 / 140, 47.5 / 124, 52 / 151;
+    // B16 1050x1050 98 / 222, 78 / 206, 90 / 272; B8 100x1050 (cross attention) 33 / 54, 17 / 43, 16 / 43; B8 1344x1344
+    // 79 / 173, 65 / 170, 72 / 206.  (The two-part backward kernels squeezed to 128 VGPRs for 4 waves per SIMD spill 33 dwords
+    // and run 1.9x slower: they stay at 3.)
+    const int force = tune(T_ATTN_SPLIT);
+    if (force == 1 || force == 2) return force;
+    if (force == 4) return max_parts >= 4 ? 4 : 2;
     const long long waves = (long long)cdiv(rows, 64) * 2 * bh;       // 2-wave row groups
     const int tiles = cdiv(streamed, AT_KEYS);
-    if (waves >= 4096 || tiles < 16) return 1;
+    if (waves >= 8192 || tiles < 16) return 1;
     if (waves * 2 >= 2048 || tiles < 32 || max_parts < 4) return 2;
     return 4;
 }
@@ -623,15 +628,13 @@ int attn_bwd_bf16_launch(const AttnArgs &a, hipStream_t s) {
         const dim3 grid((unsigned)cdiv(a.T, 64), (unsigned)bh);
         const int ks = attn_parts(a.T, a.S, bh, 4);
         if (ks == 4) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 4>), grid, dim3(512), 0, s, a);
-        else if (ks == 2 && tune(T_ATTN_SPLIT) == 22) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 2, 4>), grid, dim3(256), 0, s, a);   // A/B: 4 waves per SIMD (spills 33 dwords)
         else if (ks == 2) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<2, 1>), grid, dim3(128), 0, s, a);
     } else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<4, 1>), dim3((unsigned)cdiv(a.T, 128), (unsigned)bh), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dq (bf16 MFMA)");
     if (attn_waves(a.S, bh) == 2) {
         const dim3 grid((unsigned)cdiv(a.S, 64), (unsigned)bh);
-        if (attn_parts(a.S, a.T, bh, 2) >= 2 && tune(T_ATTN_SPLIT) == 22) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 2, 4>), grid, dim3(256), 0, s, a);
-        else if (attn_parts(a.S, a.T, bh, 2) >= 2) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        if (attn_parts(a.S, a.T, bh, 2) >= 2) hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<2, 1>), grid, dim3(128), 0, s, a);
     } else hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<4, 1>), dim3((unsigned)cdiv(a.S, 128), (unsigned)bh), dim3(256), 0, s, a);
     DETR_LAUNCH_CHECK("attention bwd dkv (bf16 MFMA)");

@@ -1,5 +1,5 @@
 """Micro-benchmark of the bf16 attention kernels on the step's shapes under a list of DETR_HIP_ATTN_SPLIT settings.
-usage: python scripts/micro_attn.py [split ...]       (default: 0 = heuristic, 1, 2, 4, 22)"""
+usage: python scripts/micro_attn.py [split ...]       (default: 0 = heuristic, 1, 2, 4)"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ from detr_tf import _hip as hip
 
 hip.load()
 dev = "cuda"
-splits = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 22]
+splits = [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4]
 H, D = 8, 256
 step = torch.tensor([0x1234567, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
 print(f"{'shape':24s} " + " ".join(f"split{s:<3d} fwd   bwd  |" for s in splits) + "  (us, dropout 0.1)")
