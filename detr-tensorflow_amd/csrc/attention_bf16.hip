@@ -507,43 +507,10 @@ __global__ __launch_bounds__(64 * NW * KS, (NW * KS > 4) ? 2 : 3) void attn_bwd_
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[r] - Lt[krow(r, hi)]);          // P (* scale with dropout)
         if (a.drop_scale != 0.0f) {
-            // Keep flags of the 16 (query row, key sk) elements of this lane.  One 32-bit hash serves the key PAIR (sk & ~1,
-            // sk | 1) of a query row (common.h), and the partner key lives in lane ^ 1: each lane hashes 8 of its 16 query rows
-            // (registers r8 + 8 * parity) and takes the other 8 words from its neighbour with one DPP quad_perm each.  The
-            // 64-bit pair index is formed once per tile (drop_keep16 in attention_common.h has the derivation): the eight rows
-            // of a lane are multiples of Sp / 2 above it; a low word that could carry takes the plain drop_hash path.
-            const unsigned halfSp = (unsigned)(Sp >> 1);         // Sp is even: ((row * Sp + sk) >> 1) = row * Sp/2 + (sk >> 1)
-            const int odd = lane & 1;                            // == sk & 1 (the workgroup's first key is even)
-            const unsigned long long pb = ((unsigned long long)bh * a.T + qbase) * halfSp + (unsigned)(sk >> 1) +
-                                          (unsigned long long)(unsigned)(4 * hi + 16 * odd) * halfSp;
-            const uint32_t tlo = (uint32_t)pb, thi = (uint32_t)(pb >> 32);
-            const uint32_t key2 = dkey * 0x85EBCA6Bu + 0xC2B2AE35u;
-            const uint32_t kx = dkey ^ (thi * 0x9E3779B9u);
-            const bool slow = tlo > 0xFFFFFFFFu - 12u * halfSp;
-            uint32_t hown[8], hoth[8];
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const unsigned c = (unsigned)((r8 & 3) + 8 * (r8 >> 2));         // krow(r8, hi) - 4 hi
-                uint32_t x = (tlo + c * halfSp) ^ kx;
-                x ^= x >> 16; x *= 0x7feb352du;
-                x ^= key2;
-                x ^= x >> 15; x *= 0x846ca68bu;
-                x ^= x >> 16;
-                hown[r8] = slow ? drop_hash(dkey, pb + (unsigned long long)c * halfSp) : x;
-            }
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8)
-                hoth[r8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[r8], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-            // this lane's key uses the high half of a word when sk is odd, the low half otherwise: shift the half to the top
-            // and compare the whole word with thresh << 16
-            const uint32_t sh = odd ? 0u : 16u, th_hi = a.drop_thresh << 16;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t hw = ((r >> 3) == odd) ? hown[r & 7] : hoth[r & 7];
-                const bool keep = (hw << sh) >= th_hi;
+            drop_keep16_keycol(dkey, (unsigned long long)bh * a.T + qbase, Sp, sk, lane, hi, a.drop_thresh, [&](int r, bool keep) {
                 ds[r] = p[r] * ((keep ? dp[r] : 0.0f) - Dlt[krow(r, hi)]);
                 p[r] = keep ? p[r] : 0.0f;                                      // dV uses the dropped probabilities
-            }
+            });
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - Dlt[krow(r, hi)]);

@@ -68,6 +68,45 @@ __device__ __forceinline__ void drop_keep16(uint32_t key, unsigned long long row
     }
 }
 
+// The same flags for the dK / dV kernels, where a lane holds ONE key (sk, parity = lane & 1) and 16 query rows
+// qbase + krow(r, hi): f(r, keep) for r = 0..15.  One 32-bit hash serves the key PAIR (sk & ~1, sk | 1) of a query row, and
+// the partner key lives in lane ^ 1: each lane hashes 8 of its 16 rows (registers r8 + 8 * parity) and takes the other 8
+// words from its neighbour with one DPP quad_perm each.  The 64-bit pair index (row * Sp + sk) / 2 = row * Sp/2 + sk/2 is formed
+// once per tile; the eight rows of a lane are multiples of Sp / 2 above it (a low word that could carry: plain drop_hash).
+// This lane's key uses the high half of a word when sk is odd, the low half otherwise: the half is shifted to the top and
+// the whole word compared with thresh << 16.
+template <typename F>
+__device__ __forceinline__ void drop_keep16_keycol(uint32_t key, unsigned long long row0, unsigned long long Sp, int sk, int lane, int hi,
+                                                   uint32_t thresh16, F &&f) {
+    const unsigned halfSp = (unsigned)(Sp >> 1);
+    const int odd = lane & 1;                            // == sk & 1 (a workgroup's first key is even)
+    const unsigned long long pb = row0 * halfSp + (unsigned)(sk >> 1) + (unsigned long long)(unsigned)(4 * hi + 16 * odd) * halfSp;
+    const uint32_t tlo = (uint32_t)pb, thi = (uint32_t)(pb >> 32);
+    const uint32_t key2 = key * 0x85EBCA6Bu + 0xC2B2AE35u;
+    const uint32_t kx = key ^ (thi * 0x9E3779B9u);
+    const bool slow = tlo > 0xFFFFFFFFu - 12u * halfSp;
+    uint32_t hown[8], hoth[8];
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+        const unsigned c = (unsigned)((r8 & 3) + 8 * (r8 >> 2));         // krow(r8, hi) - 4 hi
+        uint32_t x = (tlo + c * halfSp) ^ kx;
+        x ^= x >> 16; x *= 0x7feb352du;
+        x ^= key2;
+        x ^= x >> 15; x *= 0x846ca68bu;
+        x ^= x >> 16;
+        hown[r8] = slow ? drop_hash(key, pb + (unsigned long long)c * halfSp) : x;
+    }
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8)
+        hoth[r8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hown[r8], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    const uint32_t sh = odd ? 0u : 16u, th_hi = thresh16 << 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t hw = ((r >> 3) == odd) ? hown[r & 7] : hoth[r & 7];
+        f(r, (hw << sh) >= th_hi);
+    }
+}
+
 // maximum / sum of the 16 registers of a score column as trees (depth 4 instead of a 15-deep dependent chain: with ~2
 // waves per SIMD the chain latency, not the issue rate, is what a tile waits for)
 __device__ __forceinline__ float tree_max16(const f32x16 &s) {

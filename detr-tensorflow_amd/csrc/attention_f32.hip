@@ -319,18 +319,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         float p[16], ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = krow(r, hi);
-            p[r] = fast_exp2(s[r] - Ls[cur][qr]);
-            float dpr = dp[r];
-            if (a.drop_scale != 0.0f) {
-                const bool keep = drop_keep(dkey, ((unsigned long long)bh * a.T + it * AT_KEYS + qr) * Sp + sk, a.drop_thresh);
-                dpr = keep ? dpr * a.drop_scale : 0.0f;
-                ds[r] = p[r] * (dpr - Dl[cur][qr]);
+        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[r] - Ls[cur][krow(r, hi)]);
+        if (a.drop_scale != 0.0f) {
+            drop_keep16_keycol(dkey, (unsigned long long)bh * a.T + it * AT_KEYS, Sp, sk, lane, hi, a.drop_thresh, [&](int r, bool keep) {
+                const float dpr = keep ? dp[r] * a.drop_scale : 0.0f;
+                ds[r] = p[r] * (dpr - Dl[cur][krow(r, hi)]);
                 p[r] = keep ? p[r] * a.drop_scale : 0.0f;       // dV uses the dropped probabilities
-            } else {
-                ds[r] = p[r] * (dpr - Dl[cur][qr]);
-            }
+            });
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - Dl[cur][krow(r, hi)]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
