@@ -132,7 +132,7 @@ class DetrModel:
         static = g["static"] if g is not None and g["static"].shape == images.shape else torch.empty_like(images)
         static.copy_(images)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):       # (see training._Segments.begin)
             out = eng.forward(static, training=False)
         self._eval_graph = dict(key=key, static=static, graph=graph, out=out, gen=eng.buf_generation)
         graph.replay()

@@ -64,7 +64,11 @@ class _Segments:
 
     def begin(self):
         self._cur = torch.cuda.CUDAGraph()
-        self._cur.capture_begin(pool=self.pool)
+        # thread_local: only THIS thread's calls are checked against the capture.  In the default (global) mode any thread's
+        # unsafe call aborts the capture -- and the process group's watchdog thread polls its work events with
+        # hipEventQuery at arbitrary times (seen once as a SIGABRT out of a helper thread during the recording of a step
+        # with a live RCCL group: tests/test_gpu_dp.py::test_bench_forced_single_rank_rccl_path)
+        self._cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         hip.zero_(self._pad)               # a segment may record nothing else (after the last gradient bucket): never an empty graph
 
     def cut(self, action):

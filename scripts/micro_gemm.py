@@ -1,7 +1,9 @@
 """Micro-benchmark of the bf16 GEMM kernels on the step's dominant shapes: every case is timed under a list of library tuning
 settings (default: the product dispatch, and DETR_HIP_GEMM_STREAM=2 = tile engine only) with HIP events around `reps`
 back-to-back launches, and the variants' results are compared with the first one.
-usage: python scripts/micro_gemm.py out.json [NAME=VAL[,NAME=VAL] ...]      (extra settings to time, e.g. DETR_HIP_GEMM_TILE=1)
+usage: python scripts/micro_gemm.py out.json [--cold] [NAME=VAL[,NAME=VAL] ...]      (extra settings to time, e.g. DETR_HIP_GEMM_TILE=1)
+--cold: every launch is timed on its own after a 600 MB flush of L2 / Infinity Cache (back-to-back launches of one shape run out
+of the 256 MB Infinity Cache, which the training step's operands do not)
 (The round-3 LDS-DMA experiment -- profiles/r03_micro_gemm_dma_experiment.txt -- was produced with an earlier form of this script.)"""
 import json
 import os
@@ -16,6 +18,9 @@ from detr_tf import _hip as hip
 
 hip.load()
 dev = "cuda"
+COLD = "--cold" in sys.argv
+if COLD:
+    sys.argv.remove("--cold")
 hip.ensure_workspace(dev)
 torch.manual_seed(0)
 bf = torch.bfloat16
@@ -51,13 +56,23 @@ def run(case, mode, reps=30):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ts = []
-        for _ in range(3):
-            e0.record()
-            for _ in range(reps):
+        if COLD:
+            for _ in range(7):
+                FLUSH.zero_()
+                e0.record()
                 hip.gemm(*args, **kws)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) / reps * 1e3)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts = [sorted(ts)[len(ts) // 2]]
+        else:
+            for _ in range(3):
+                e0.record()
+                for _ in range(reps):
+                    hip.gemm(*args, **kws)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / reps * 1e3)
         if kw.get("wgrad"):
             C.zero_()
             hip.gemm(*args, **kws)
@@ -69,6 +84,7 @@ def run(case, mode, reps=30):
 
 
 hip.COMPUTE_BF16 = 1
+FLUSH = torch.empty(600 * 1024 * 1024 // 4, device=dev) if COLD else None
 cases = [
     ("l3 conv3 dgrad", 33600, 256, 1024, 1, 1, dict(mask=1)),
     ("l3 conv1 fwd", 33600, 256, 1024, 1, 0, dict(bias=1, act=1)),
