@@ -625,7 +625,12 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
         // reuse) pays only for the long split-K weight gradients (K >= 16384, N >= 128) and for unsplit K >= 1024 GEMMs
         // that still fill the chip with 128x128 tiles (M33600 N256 K1024: 54 vs 60 us)
         const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
-        const bool small = (split > 1) ? !(d->N >= 128 && d->K >= 16384) : !(d->K >= 1024 && t128 >= 512);
+        // round 3, cold-cache sweeps (scripts/micro_wgrad.py, micro_gemm.py --cold; profiles/r03_micro_*): the layer4 weight
+        // gradients (M, N >= 512, K = 8400) gain 15-25 % on 128x128 tiles (512x2048: 64 -> 53 us, 1024x2048: 109 -> 80), and so do
+        // the wide K = 512 GEMMs of layer3's first block (M33600 N1024: 100 -> 89 us, with residual + mask 163 -> 151)
+        const bool big_split = (d->N >= 128 && d->K >= 16384) || (d->M >= 512 && d->N >= 512 && d->K >= 4096);
+        const bool big_plain = (d->K >= 1024 && t128 >= 512) || (d->K >= 512 && d->N >= 512 && t128 >= 1024);
+        const bool small = (split > 1) ? !big_split : !big_plain;
         if (force == 2) tile = 2;
         else if (force == 5) tile = 4;
         else if (force == 3 || (force == 0 && small)) tile = 0;

@@ -35,6 +35,7 @@ def operands(M, N, K, ak, bk):
 def run(case, mode, reps=30):
     name, M, N, K, ak, bk, kw = case
     A, B = case_ops[name]
+    torch.manual_seed(M + N + K)              # the same epilogue operands under every mode
     cdt = torch.float32 if kw.get("c32") else bf
     C = torch.zeros(M, N, device=dev, dtype=cdt)
     res = torch.randn(M, N, device=dev).to(torch.float32 if kw.get("r32") else bf) if kw.get("res") else None
