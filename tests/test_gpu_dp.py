@@ -172,6 +172,28 @@ def test_bench_forced_single_rank_rccl_path(hip):
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and np.isfinite(j["loss"]) and j["value"] > 0
     assert j["config"]["launch"].startswith("hipGraph replay") and j["config"]["parallelism"] == "dp1"
+    # the gradient exchange is instrumented: HIP events at every bucket hand-over / completion
+    assert j["ranks_seen"] == 1 and j["comm_ms"] > 0 and 0 <= j["exposed_comm_ms"] < 1e3
+    assert [b["bucket"] for b in j["comm"]["buckets"]] == [0, 1, 2, 3] and j["comm"]["steps"] == 3
+
+
+def test_bench_two_ranks_gloo_prints_the_comm_fields(hip):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on the
+    one GPU over gloo: the JSON line carries comm_ms / exposed_comm_ms / ranks_seen and the per-bucket all-reduce timings, so the
+    first real multi-GPU line can be read (how much of the exchange the backward hides)."""
+    import json
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                    str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "128",
+                    "--width", "160", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-kernel-events", "--launch", "eager"])
+    assert r.returncode == 0, r.stderr[:1500] + "\n...\n" + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly rank 0 prints"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "weak"
+    assert j["ranks_seen"] == 2 and j["comm_ms"] > 0 and j["exposed_comm_ms"] >= 0
+    c = j["comm"]
+    assert c["steps"] == 3 and len(c["buckets"]) == 4 and abs(sum(b["mbytes"] for b in c["buckets"]) - 166.0) < 8.0
+    assert all(b["allreduce_ms"] > 0 and b["handover_to_done_ms"] >= b["allreduce_ms"] * 0.5 for b in c["buckets"])
 
 
 def test_bench_refuses_rank_count_mismatch(hip):
