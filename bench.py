@@ -71,7 +71,7 @@ def _pick_threads(requested):
     return max(1, min(avail, 32))        # torch-CPU convs stop scaling (and thrash) far below 256 threads
 
 
-def cpu_baseline(height, width, threads=0, budget_s=28.0):
+def cpu_baseline(height, width, threads=0, budget_s=14.0):
     """The oracle (kind "port": CPU restatement of the reference, torch-CPU fp32 + SciPy matcher) timed on the host cores on
     bounded samples.  `value` = batch-1 train steps of the metric's shape (images/s); `c1_forward_480x640` and
     `c2_forward_loss` are the two CPU-runnable BASELINE.json configs."""
