@@ -535,12 +535,15 @@ def gemm_group(calls):
         PROFILER.end(infos[0][0], sum(i[1] for i in infos), ev0, f"group{n}: " + infos[0][2], sum(i[3] for i in infos))
 
 
+SPLIT_TARGET_128 = int(os.environ.get("DETR_HIP_SPLIT_TARGET", "512"))     # workgroups a 128x128-tile split-K launch aims for (A/B hook)
+
+
 def pick_split_k(M, N, K, max_split=1024):
     """Reduction-heavy GEMMs (weight gradients): split K so that enough workgroups exist to fill 256 CUs."""
     if COMPUTE_BF16 and ((N >= 128 and K >= 16384) or (M >= 512 and N >= 512 and K >= 4096)):   # 128x128 tiles (gemm_f32.hip), ~512 workgroups
         tiles = -(-M // 128) * -(-N // 128)
         ktiles = -(-K // 32)
-        return int(max(1, min(max(1, 512 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
+        return int(max(1, min(max(1, SPLIT_TARGET_128 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
     # 64x64 tiles (fp32 always; bf16 for small outputs, see gemm_f32.hip): ~1024 workgroups measured best
     tiles = -(-M // 64) * -(-N // 64)
     want = max(1, 1024 // max(tiles, 1))

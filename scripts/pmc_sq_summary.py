@@ -24,7 +24,7 @@ ctrs = sorted({c for v in res.values() for c in v})
 rows = sorted(res.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0, 0))[1])
 print("# sums over all launches of each kernel; see the module docstring for the normalisation")
 print(f"{'kernel':100s} {'n':>5} " + " ".join(f"{c[:18]:>19}" for c in ctrs) + "   mfma_busy   frac_of_wave_cycles: " + " ".join(c[3:][:14] for c in ctrs if c.startswith("SQ_WAIT") or c.startswith("SQ_ACTIVE")))
-for k, v in rows[:30]:
+for k, v in rows[:60]:
     vals = [v.get(c, (0, 0))[1] for c in ctrs]
     g = v.get("GRBM_GUI_ACTIVE", (0, 1))[1] or 1
     wc = v.get("SQ_WAVE_CYCLES", (0, 0))[1] or 1
