@@ -535,7 +535,10 @@ def gemm_group(calls):
         PROFILER.end(infos[0][0], sum(i[1] for i in infos), ev0, f"group{n}: " + infos[0][2], sum(i[3] for i in infos))
 
 
-SPLIT_TARGET_128 = int(os.environ.get("DETR_HIP_SPLIT_TARGET", "512"))     # workgroups a 128x128-tile split-K launch aims for (A/B hook)
+# workgroups a split-K launch aims for (A/B hooks).  128x128 tiles: 512 -> 256 measured -0.23 ms per step on the same box (half
+# the partial slabs to write and reduce; scripts/micro_wgrad.py shows the same 3-7 % per launch with cold caches)
+SPLIT_TARGET_128 = int(os.environ.get("DETR_HIP_SPLIT_TARGET", "256"))
+SPLIT_TARGET_64 = int(os.environ.get("DETR_HIP_SPLIT_TARGET64", "1024"))
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -546,7 +549,7 @@ def pick_split_k(M, N, K, max_split=1024):
         return int(max(1, min(max(1, SPLIT_TARGET_128 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
     # 64x64 tiles (fp32 always; bf16 for small outputs, see gemm_f32.hip): ~1024 workgroups measured best
     tiles = -(-M // 64) * -(-N // 64)
-    want = max(1, 1024 // max(tiles, 1))
+    want = max(1, SPLIT_TARGET_64 // max(tiles, 1))
     ktiles = -(-K // (32 if COMPUTE_BF16 else 16))
     cap = ktiles // 8 if ktiles >= 64 else ktiles // 4      # short reductions: 4 k-tiles per split are enough
     return int(max(1, min(want, max_split, cap)))

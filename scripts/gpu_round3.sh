@@ -15,7 +15,7 @@ for w in "$@"; do
     model) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_training.py tests/test_golden.py tests/test_gpu_dp.py -m gpu -q --no-header -p no:cacheprovider > $OUT/model.log 2>&1; echo "model rc=$?" >> $OUT/summary.txt; tail -60 $OUT/model.log ;;
     smoke) timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt; tail -3 $OUT/smoke.log ;;
     bench) timeout 900 python bench.py --steps 20 --warmup 3 --dump-shapes $OUT/shapes.json > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench.log > $OUT/bench_line.json; tail -2 $OUT/bench.log | cut -c1-1800 ;;
-    ab_split) for v in 512 256; do DETR_HIP_SPLIT_TARGET=$v timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --dump-shapes $OUT/shapes_split$v.json > $OUT/bench_split$v.log 2>&1; echo "split$v rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_split$v.log | cut -c1-330; done ;;
+    ab_split) for v in ${AB_SPLITS:-256,1024 128,1024 256,512 384,1024}; do DETR_HIP_SPLIT_TARGET=${v%,*} DETR_HIP_SPLIT_TARGET64=${v#*,} timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --dump-shapes "$OUT/shapes_split_$v.json" > "$OUT/bench_split_$v.log" 2>&1; echo "split $v rc=$?" >> $OUT/summary.txt; tail -n 1 "$OUT/bench_split_$v.log" | cut -c1-330; done ;;
     bench_quick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --dump-shapes $OUT/shapes.json > $OUT/bench_quick.log 2>&1; echo "bench_quick rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_quick.log > $OUT/bench_quick_line.json; tail -2 $OUT/bench_quick.log | cut -c1-1200 ;;
     bench_dp2) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 1 --batch 2 --height 256 --width 320 --dist-backend gloo --no-cpu-baseline --no-kernel-events > $OUT/bench_dp2_gloo.log 2>&1; echo "bench dp2 rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_dp2_gloo.log | cut -c1-1500 ;;
     micro) timeout 900 python scripts/micro_gemm.py $OUT/micro.json ${MICRO_ARGS:-} > $OUT/micro.log 2>&1; echo "micro rc=$?" >> $OUT/summary.txt; tail -70 $OUT/micro.log ;;
