@@ -87,6 +87,7 @@ enum TuneKey {
     T_STEM_ROWS,
     T_ATTN_WAVES,
     T_ATTN_SPLIT,
+    T_GEMM_K64,
     T_COUNT
 };
 int tune(TuneKey k);

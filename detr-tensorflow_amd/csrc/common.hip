@@ -25,6 +25,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_STEM_ROWS",
     "DETR_HIP_ATTN_WAVES",
     "DETR_HIP_ATTN_SPLIT",
+    "DETR_HIP_GEMM_K64",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {

@@ -33,15 +33,18 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-template <int BM, int BN>
+// BK: depth of one K tile (32, or 64 for the all-bf16 long-K variant: half the barrier-separated iterations per K);
+// rows are padded by 8 bf16 (16 B): row r starts at 16-byte slot (BK/8 + 1) * r -- 5 r or 9 r, both odd, so 16 consecutive
+// rows fall into 16 different slots mod 16 and the b128 fragment reads are conflict-free
+template <int BM, int BN, int BK = BF_BK>
 struct BfSmem {
-    unsigned short A[2][BM][BF_LD];
-    unsigned short B[2][BN][BF_LD];
+    unsigned short A[2][BM][BK + 8];
+    unsigned short B[2][BN][BK + 8];
 };
 
-template <int BM, int BN, int WGN>
+template <int BM, int BN, int WGN, int BK = BF_BK>
 struct BfSmemBytes {
-    static constexpr int TILES = (int)sizeof(BfSmem<BM, BN>);
+    static constexpr int TILES = (int)sizeof(BfSmem<BM, BN, BK>);
     static constexpr int STAGE = 4 * 32 * (BN / WGN + 4) * 4;
     static constexpr int VALUE = TILES > STAGE ? TILES : STAGE;
 };
@@ -139,10 +142,14 @@ struct LoaderMNt {
 
 // ---- operands that are ALREADY bf16 in memory (the per-step bf16 shadow of the weights, engine.py): no conversion,
 // half the bytes; same LDS images as LoaderKb / LoaderMNt.  K (k-contiguous) must be a multiple of 8, MN of 4.
-// [mn][k], k contiguous: 16-byte chunks of 8 k; thread t: rows (t >> 2) + 64*i, k offset (t & 3) * 8
-template <int BMN>
+// [mn][k], k contiguous: 16-byte chunks of 8 k, CPR = BK / 8 of them per row; thread t: rows t / CPR + (256 / CPR) * i, k offset
+// (t % CPR) * 8  (BK = 32: rows (t >> 2) + 64 i)
+template <int BMN, int BK = BF_BK>
 struct LoaderKh {
-    static constexpr int NV = BMN / 64;
+    static constexpr int CPR = BK / 8;
+    static constexpr int RPP = 256 / CPR;             // rows per pass of the 256 threads
+    static constexpr int NV = BMN / RPP;
+    static_assert(BMN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
     typedef uint4 Reg;
     static constexpr int NREG = NV;
     BufSrc src;
@@ -152,10 +159,10 @@ struct LoaderKh {
                                          long long extent_elems = 0) {
         src.init_bytes(p, (extent_elems > 0 ? extent_elems : (long long)(MN - 1) * ld + K) * 2);
         tid = tid_;
-        k8 = (tid & 3) * 8;
+        k8 = (tid % CPR) * 8;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int g = mn0 + (tid >> 2) + 64 * i;
+            const int g = mn0 + tid / CPR + RPP * i;
             off[i] = g < MN ? (unsigned)((long long)g * ld * 2) : BUF_OOB;
         }
     }
@@ -164,9 +171,10 @@ struct LoaderKh {
 #pragma unroll
         for (int i = 0; i < NV; ++i) r[i] = src.ld16((off[i] != BUF_OOB && k + 8 <= K) ? off[i] + base + 2u * (unsigned)k : BUF_OOB);
     }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const uint4 (&r)[NV]) const {
+    template <int LD>
+    __device__ __forceinline__ void store(unsigned short (*S)[LD], const uint4 (&r)[NV]) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<uint4 *>(&S[(tid >> 2) + 64 * i][k8]) = r[i];
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<uint4 *>(&S[tid / CPR + RPP * i][k8]) = r[i];
     }
 };
 
@@ -176,10 +184,10 @@ struct LoaderKh {
 // two 8-byte ones; register 2i / 2i + 1 then hold units 2p / 2p + 1 of pair p = tid + 256 i.  Needs MN % 8 == 0, a row stride
 // % 8 == 0 and a tile origin % 8 == 0 (checked by the host dispatch); a caller that sums the registers per column group
 // (the fused bias gradient of gemm_bf16c_body) uses the narrow form: a pair spans two column groups.
-template <int BMN, bool WIDE = false>
+template <int BMN, bool WIDE = false, int BK = BF_BK>
 struct LoaderMNth {
     static constexpr int NB = BMN / 16;
-    static constexpr int NU = BMN / 32;
+    static constexpr int NU = BMN * BK / 1024;       // 8-byte units per thread and tile (BK k x BMN / 4 / 256)
     static_assert(!WIDE || NU % 2 == 0, "wide units come in pairs");
     typedef uint2 Reg;
     static constexpr int NREG = NU;
@@ -212,7 +220,8 @@ struct LoaderMNth {
             }
         }
     }
-    __device__ __forceinline__ void store(unsigned short (*S)[BF_LD], const uint2 (&r)[NU]) const {
+    template <int LD>
+    __device__ __forceinline__ void store(unsigned short (*S)[LD], const uint2 (&r)[NU]) const {
         unsigned short *flat = &S[0][0];
         if constexpr (WIDE) {
 #pragma unroll
@@ -226,8 +235,8 @@ struct LoaderMNth {
 };
 
 // MFMA fragment (8 consecutive k of row `row_base + (lane & 31)`) out of a transpose-read image
-template <int BMN>
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned short (*S)[BF_LD], int row_base, int ks, int lane) {
+template <int BMN, int LD>
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned short (*S)[LD], int row_base, int ks, int lane) {
     constexpr int NB = BMN / 16;
     const int g = lane >> 4, t = lane & 15;
     const int ib = (row_base >> 4) + (g & 1);
@@ -241,17 +250,17 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short (*S)[BF_LD], int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// one 32-deep K tile: 2 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.
+// one BK-deep K tile: BK / 16 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.
 // operand map: lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31].
-template <int BM, int BN, int WGM, int WGN, bool ATR = false, bool BTR = false>
-__device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BF_LD], const unsigned short (*Bs)[BF_LD],
+template <int BM, int BN, int WGM, int WGN, bool ATR = false, bool BTR = false, int BK = BF_BK>
+__device__ __forceinline__ void mma_ktile_bf16(const unsigned short (*As)[BK + 8], const unsigned short (*Bs)[BK + 8],
                                                f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
                                                int wm, int wn, int lane) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     const int l31 = lane & 31;
     const int kh = (lane >> 5) * 8;
 #pragma unroll
-    for (int ks = 0; ks < BF_BK; ks += 16) {
+    for (int ks = 0; ks < BK; ks += 16) {
         bf16x8 a[T::TM], b[T::TN];
 #pragma unroll
         for (int mi = 0; mi < T::TM; ++mi) {

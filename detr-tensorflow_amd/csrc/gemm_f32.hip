@@ -201,11 +201,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_group_kernel(GemmGroupA
 }
 
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
+// BK = 64 (all-bf16 operands only): the same pipeline over K tiles twice as deep -- half the barrier-separated iterations,
+// each with twice the MFMA work behind one LDS round trip.  The split ranges stay in units of 32 (the host's slab arithmetic,
+// gemm_effective_split, does not depend on the variant); a range that is not a multiple of 64 ends in a half-empty tile whose
+// missing half is never requested (out-of-range offsets -> zeros).
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16, int BK = BF_BK>
 __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id, const int zidx) {
     using T = TileCfg<BM, BN, WGM, WGN>;
-    __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN>::VALUE];
-    BfSmem<BM, BN> &sm = *reinterpret_cast<BfSmem<BM, BN> *>(smem_raw);
+    static_assert(BK == BF_BK || (A16 && B16), "the 64-deep K tile exists for bf16 operands only");
+    __shared__ __attribute__((aligned(16))) char smem_raw[BfSmemBytes<BM, BN, WGN, BK>::VALUE];
+    BfSmem<BM, BN, BK> &sm = *reinterpret_cast<BfSmem<BM, BN, BK> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int tn = id % g.tiles_n, tm = id / g.tiles_n;
@@ -219,15 +224,18 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     float *C = g.C + z0 * g.sC0 + z1 * g.sC1 + (long long)split * g.part_stride;
     const int nkt = (g.K + BF_BK - 1) / BF_BK;
     const int per = (nkt + g.split_k - 1) / g.split_k;
-    const int kt0 = split * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
+    const int kt0_32 = split * per;
+    const int kt1_32 = min(nkt, kt0_32 + per);
+    if (kt0_32 >= kt1_32) return;
+    const int kbeg = kt0_32 * BF_BK;
+    const int kend = min(g.K, kt1_32 * BF_BK);   // requests past this split's K range resolve to the out-of-range offset: no traffic
+    const int kt0 = 0, kt1 = (kend - kbeg + BK - 1) / BK;      // K tiles of THIS variant's depth, relative to kbeg
 
     // MN-contiguous: transpose-read image.  A16: the A operand is bf16 in memory (bf16 activation storage)
-    using LA = typename std::conditional<A16, typename std::conditional<AK, LoaderKh<BM>, LoaderMNth<BM, true>>::type,
+    using LA = typename std::conditional<A16, typename std::conditional<AK, LoaderKh<BM, BK>, LoaderMNth<BM, true, BK>>::type,
                                          typename std::conditional<AK, LoaderKb<BM>, LoaderMNt<BM>>::type>::type;
     // B16: the B operand is already bf16 in memory (per-step weight shadow): half the bytes, no conversion
-    using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN>, LoaderMNth<BN, true>>::type,
+    using LB = typename std::conditional<B16, typename std::conditional<BKC, LoaderKh<BN, BK>, LoaderMNth<BN, true, BK>>::type,
                                          typename std::conditional<BKC, LoaderKb<BN>, LoaderMNt<BN>>::type>::type;
     constexpr int NRA = LA::NREG;
     constexpr int NRB = LB::NREG;
@@ -267,19 +275,18 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     // was one HBM / L2 round trip however deep the register pipeline.
     typename LA::Reg ra0[NRA], ra1[NRA];
     typename LB::Reg rb0[NRB], rb1[NRB];
-    const int kend = min(g.K, kt1 * BF_BK);      // requests past this split's K range resolve to the out-of-range offset: no traffic
-    la.load(kt0 * BF_BK, kend, ra0);
-    lb.load(kt0 * BF_BK, kend, rb0);
+    la.load(kbeg + kt0 * BK, kend, ra0);
+    lb.load(kbeg + kt0 * BK, kend, rb0);
     if (do_rs) rs_add(ra0);
     la.store(sm.A[0], ra0);
     lb.store(sm.B[0], rb0);
     // (the requests are unconditional -- past the last tile they fall outside the buffer descriptor or fetch a tile
     //  that is never stored: with conditional requests the compiler cannot tell how many are outstanding and waits for
     //  vmcnt(0) before every LDS store, which puts the full round trip back into each iteration)
-    la.load((kt0 + 1) * BF_BK, kend, ra0);
-    lb.load((kt0 + 1) * BF_BK, kend, rb0);
-    la.load((kt0 + 2) * BF_BK, kend, ra1);
-    lb.load((kt0 + 2) * BF_BK, kend, rb1);
+    la.load(kbeg + (kt0 + 1) * BK, kend, ra0);
+    lb.load(kbeg + (kt0 + 1) * BK, kend, rb0);
+    la.load(kbeg + (kt0 + 2) * BK, kend, ra1);
+    lb.load(kbeg + (kt0 + 2) * BK, kend, rb1);
     lds_barrier();
     // one iteration: `rp` holds tile kt+1 (stored now, then refilled with tile kt+3), LDS[cur] holds tile kt
     auto iter = [&](const int kt, const int cur, typename LA::Reg (&rpa)[NRA], typename LB::Reg (&rpb)[NRB]) {
@@ -292,10 +299,10 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
             for (int i = 0; i < NRB; ++i) ablate_keep(rpb[i]);
         }
         if constexpr ((DETR_ABLATE & 2) == 0) {
-            la.load((kt + 3) * BF_BK, kend, rpa);
-            lb.load((kt + 3) * BF_BK, kend, rpb);
+            la.load(kbeg + (kt + 3) * BK, kend, rpa);
+            lb.load(kbeg + (kt + 3) * BK, kend, rpb);
         }
-        mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC, BK>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
     };
     {   // whole pairs in the loop, an odd last tile after it: every path into the loop header carries the same
@@ -317,6 +324,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : (BM * BN
     int tile, z;
     gemm_work_item(g, tile, z);
     gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, A16, B16>(g, tile, z);
+}
+// all-bf16 operands, 64-deep K tiles (36 KB / 72 KB of LDS: 4 / 2 workgroups per CU)
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_bf16c_k64_kernel(GemmArgs g) {
+    int tile, z;
+    gemm_work_item(g, tile, z);
+    gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, true, true, 64>(g, tile, z);
 }
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MINW : 1) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
@@ -467,12 +481,21 @@ static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
+static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk, bool deep = false) {
     GemmArgs a = g;
     a.tiles_m = cdiv(g.M, BM);
     a.tiles_n = cdiv(g.N, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
     dim3 block(GEMM_THREADS);
+    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 128)) {
+        if (deep && g.a16 && g.b16) {
+            if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_k64_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
+            else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16c_k64_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
+            else if (!ak && bk) hipLaunchKernelGGL((gemm_bf16c_k64_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gemm_bf16c_k64_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+            return 0;
+        }
+    }
 #define DETR_BF16_LAUNCH(A16_, B16_)                                                                                          \
     do {                                                                                                                          \
         if (ak && bk) hipLaunchKernelGGL((gemm_bf16c_kernel<BM, BN, WGM, WGN, true, true, A16_, B16_>), grid, block, 0, s, a);        \
@@ -497,7 +520,7 @@ using namespace detr;
 struct GemmPlan {
     GemmArgs g;
     int batch, split;
-    bool ak, bk, bf16c, partial;
+    bool ak, bk, bf16c, partial, deep;
     int tile;                 // 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64
     long long part;
     EpiArgs final_e;
@@ -644,6 +667,16 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     else if (force == 6) tile = 5;
     else if (d->N <= 32) tile = 3;
     else tile = 0;      // measured (profiles/tune_r1.txt): 64x64 (8 waves/SIMD) beats 128x64 by 2-10 % and 128x128 by 15-50 % in fp32
+    // 64-deep K tiles (all-bf16 operands, tiles 0 / 1): DETR_HIP_GEMM_K64 = 0 rule below, 1 every eligible GEMM, 2 never.
+    // Measured (scripts/micro_gemm.py, profiles/r03_micro_gemm_k64.txt): 64x64 tiles gain 10-23 % from K >= 512 per split on (M8400
+    // N512 K2048: 47.0 -> 39.2 us, M800 N256 K2048 cold: 28.0 -> 21.6); UNSPLIT 128x128 tiles lose 20-35 % (72 KB of LDS: two
+    // workgroups per CU instead of three -- M33600 N1024 K512: 73 -> 92 us), split ones gain 0-7 % (cold: 82.0 -> 76.1 us)
+    {
+        const int k64 = tune(T_GEMM_K64);
+        const int per_split = cdiv(d->K, split);
+        p.deep = bf16c && g.a16 && g.b16 && (tile == 0 || tile == 1) && k64 != 2 &&
+                 (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)));
+    }
     p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
     p.part = part; p.final_e = final_e; p.d = d;
     return 0;
@@ -700,8 +733,8 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     if (p.bf16c) {
         if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
-        else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk);
-        else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk);
+        else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk, p.deep);
+        else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk, p.deep);
     } else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 3) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);

@@ -19,6 +19,7 @@ for w in "$@"; do
     bench_quick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --dump-shapes $OUT/shapes.json > $OUT/bench_quick.log 2>&1; echo "bench_quick rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_quick.log > $OUT/bench_quick_line.json; tail -2 $OUT/bench_quick.log | cut -c1-1200 ;;
     bench_dp2) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 1 --batch 2 --height 256 --width 320 --dist-backend gloo --no-cpu-baseline --no-kernel-events > $OUT/bench_dp2_gloo.log 2>&1; echo "bench dp2 rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench_dp2_gloo.log | cut -c1-1500 ;;
     micro) timeout 900 python scripts/micro_gemm.py $OUT/micro.json ${MICRO_ARGS:-} > $OUT/micro.log 2>&1; echo "micro rc=$?" >> $OUT/summary.txt; tail -70 $OUT/micro.log ;;
+    micro_cold) timeout 900 python scripts/micro_gemm.py $OUT/micro_cold.json --cold ${MICRO_ARGS:-} > $OUT/micro_cold.log 2>&1; echo "micro_cold rc=$?" >> $OUT/summary.txt; tail -70 $OUT/micro_cold.log ;;
     micro_wgrad) timeout 900 python scripts/micro_wgrad.py $OUT/micro_wgrad.json > $OUT/micro_wgrad.log 2>&1; echo "micro_wgrad rc=$?" >> $OUT/summary.txt; grep -v amdgpu $OUT/micro_wgrad.log | cut -c1-400 ;;
     micro_attn) timeout 600 python scripts/micro_attn.py > $OUT/micro_attn.log 2>&1; echo "micro_attn rc=$?" >> $OUT/summary.txt; tail -12 $OUT/micro_attn.log ;;
     prof16) (cd /tmp && export TMPDIR=/tmp DETR_HIP_WGRAD_STREAM=0 && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt

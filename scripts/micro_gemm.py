@@ -106,6 +106,10 @@ cases = [
     ("l3 down wgrad", 1024, 512, 33600, 0, 0, dict(wgrad=1, c32=1)),
     ("l4 conv3 wgrad", 512, 2048, 8400, 0, 0, dict(wgrad=1, c32=1)),
     ("ffn lin2 wgrad", 256, 2048, 8400, 0, 0, dict(wgrad=1, c32=1)),
+    ("dec ffn lin2 fwd", 800, 256, 2048, 1, 1, dict(bias=1, res=1, r32=1, c32=1)),
+    ("dec ffn lin1 dgrad", 800, 256, 2048, 1, 0, dict(res=1, r32=1, c32=1)),
+    ("enc proj wgrad", 256, 256, 8400, 0, 0, dict(wgrad=1, c32=1)),
+    ("ffn lin1 wgrad", 2048, 256, 8400, 0, 0, dict(wgrad=1, c32=1)),
     ("ffn lin1 fwd K256", 8400, 2048, 256, 1, 1, dict(bias=1, act=1)),
     ("ffn lin2 dgrad K256", 8400, 2048, 256, 1, 0, dict(mask=1, alpha=1.0 / 0.9)),
 ]

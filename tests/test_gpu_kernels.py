@@ -25,7 +25,7 @@ def _reset_library_tuning():
     import os
     yield
     from detr_tf import _hip
-    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT")
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1361,6 +1361,50 @@ def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bia
     diff = (stream - generic).abs()
     assert float((diff > 0).double().mean()) < 2e-3, float((diff > 0).double().mean())
     assert float((diff / (generic.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
+
+
+@pytest.mark.parametrize("tile", [3, 1])
+@pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K,split", [(200, 136, 2048, 1), (72, 264, 1000, 1), (136, 72, 8 * 331, 5), (264, 200, 8 * 1001, 7)])
+def test_gemm_bf16_deep_k_tiles_are_bit_identical(hip, tile, ak, bk, M, N, K, split):
+    """The all-bf16 tile GEMM with 64-deep K tiles (DETR_HIP_GEMM_K64=1: every eligible call) against the 32-deep variant (=2):
+    each wave feeds its MFMAs the same k in the same order, so outputs must be IDENTICAL bits -- both operand layouts, 64x64 and
+    128x128 tiles, K and split ranges that are not multiples of 64 (half-empty last tiles), ragged M / N, the fused bias
+    gradient (rowsum_a) of an M-contiguous A, and the deterministic split-K slabs."""
+    hip.ensure_workspace(DEV)                        # split-K through the slab workspace (the atomic fallback has no fixed order)
+    torch.manual_seed(M + N + K)
+    A = g(torch.randn(M, K) if ak else torch.randn(K, M)).to(torch.bfloat16)
+    Bm = g((torch.randn(N, K) if bk else torch.randn(K, N)) / K ** 0.5).to(torch.bfloat16)
+    bias = g(torch.randn(N))
+    outs = []
+    for mode in ("1", "2"):
+        hip.set_tuning("DETR_HIP_GEMM_K64", mode)
+        hip.set_tuning("DETR_HIP_GEMM_TILE", str(tile))
+        try:
+            use_rs = (not ak) and split > 1
+            C = torch.full((M, N), 0.5, device=DEV) if split > 1 else torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            rs = torch.zeros(M, device=DEV) if use_rs else None
+            kw = dict(split_k=split, compute=1)
+            if split == 1:
+                kw.update(bias=bias, act=1)
+            if use_rs:
+                kw.update(rowsum_a=rs)
+            hip.gemm(M, N, K, A, K if ak else M, ak, Bm, K if bk else N, bk, C, N, **kw)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning("DETR_HIP_GEMM_K64", None)
+            hip.set_tuning("DETR_HIP_GEMM_TILE", None)
+        outs.append((C.float().cpu(), None if rs is None else rs.cpu()))
+    (deep, rs_deep), (ref32, rs32) = outs
+    A64 = A.double().cpu() if ak else A.double().cpu().t()
+    B64 = Bm.double().cpu().t() if bk else Bm.double().cpu()
+    want = A64 @ B64
+    want = torch.relu(want + bias.double().cpu()) if split == 1 else want + 0.5
+    assert float((ref32.double() - want).abs().max()) < (2.0 ** -7 if split == 1 else 1e-3) * float(want.abs().max())
+    assert torch.equal(deep, ref32), float((deep - ref32).abs().max())
+    if rs_deep is not None:
+        assert torch.equal(rs_deep, rs32)
+        assert float((rs_deep.double() - A64.sum(1)).abs().max()) < 1e-3 * float(A64.sum(1).abs().max() + 1)
 
 
 @pytest.mark.parametrize("split", [1, 2, 4])
