@@ -88,6 +88,7 @@ enum TuneKey {
     T_ATTN_WAVES,
     T_ATTN_SPLIT,
     T_GEMM_K64,
+    T_EPI_WIDE,
     T_COUNT
 };
 int tune(TuneKey k);

@@ -26,6 +26,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_ATTN_WAVES",
     "DETR_HIP_ATTN_SPLIT",
     "DETR_HIP_GEMM_K64",
+    "DETR_HIP_EPI_WIDE",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
         cur ^= 1;
     }
     float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
-    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+    epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         cur ^= 1;
     }
     float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
-    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+    epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
         f32x16 one[1][1];
         one[0][0] = acc[t];
         float *dw = a.dw + (long long)t * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
-        epilogue<64, 64, 2, 2>(one, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+        epilogue<64, 64, 2, 2, false>(one, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
     }
 }
 
@@ -1289,6 +1289,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     a.M = d->N * a.Hd * a.Wd;
     e.ldr = a.Cd;
     e.ldmask = a.Cd;
+    // all-bf16 epilogue streams (channel counts are % 16, rows 16-byte aligned): 8 columns per lane (gemm_core.h epilogue_wide16);
+    // the stride-2 input-gradient classes below address their rows through the remap and keep the 4-column form
+    e.wide16 = e.c16 && e.vec && (!d->residual || e.r16) && (!d->mask || e.m16) && tune(T_EPI_WIDE) != 2;
     a.e = e;
     a.w16 = (d->w_dtype == 1);
     a.x16 = (d->x_dtype == 1);
@@ -1333,6 +1336,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
                 c.kh0 = (ph + d->pad) & 1; c.kw0 = (pw + d->pad) & 1;
                 c.nth = c.kh0 ? 1 : 2; c.ntw = c.kw0 ? 1 : 2;
                 c.e.remap_w2 = c.Wp; c.e.remap_h2 = c.Hp; c.e.remap_W = a.Wd; c.e.remap_H = a.Hd;
+                c.e.wide16 = 0;
                 c.e.remap_ph = ph; c.e.remap_pw = pw;
                 launch(c);
             }

@@ -48,6 +48,9 @@ struct EpiArgs {
     // leading dimensions in elements); the arithmetic of the epilogue stays fp32, the result is rounded once (RNE)
     int c16 = 0, r16 = 0, m16 = 0;
     const uint32_t *drop_step = nullptr;
+    // 1: all-bf16 epilogue streams (C, and residual / mask when present) with rows that are 16-byte aligned and a multiple of 8
+    // wide, no atomics, no row remap -> epilogue_wide16 (8 columns per lane, every request of a strip in flight at once)
+    int wide16 = 0;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
@@ -322,12 +325,113 @@ __device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiA
     return v;
 }
 
+// All-bf16 form of the epilogue (EpiArgs.wide16).  Measured with the main loop compiled out (scripts/experiments, round 3): the
+// rolled 4-column loop below is a chain of dependent round trips -- LDS read, residual / mask request, wait, store, next item --
+// and at 8-12 waves per CU (128x128 tiles, the direct-A kernel) it ran the output streams at 1-2 TB/s: 30 us of the 67 us of
+// M33600 N256 K1024 + mask, 100 us of 142 us for M33600 N1024 K512 + residual + mask.  Here a lane owns 8 consecutive columns
+// (16-byte bf16 accesses, a wave instruction covers whole 128 / 256-byte row segments), the residual and mask rows of ALL passes
+// of a 32-row strip are requested before the accumulators are even staged, and the per-column scale / bias are loaded once.
+// The arithmetic per element is epi_one, unchanged: results are bit-identical to the 4-column form.
 template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                                float *stage_base, float *C, long long ldc, int M, int N, int m0, int n0,
+                                                int wm, int wn, int lane, int wave, const EpiArgs &e) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    using S = StageCfg<BN, WGN>;
+    constexpr int LPR = T::WTN / 8;                    // lanes per staged row
+    constexpr int RPP = 64 / LPR;                      // rows per pass of the wave
+    constexpr int NP = 32 / RPP;                       // passes per 32-row strip (WTN / 16)
+    static_assert(LPR >= 2 && LPR <= 64 && NP >= 1, "wave tile width 16 .. 512");
+    float *stage = stage_base + wave * S::FLOATS_PER_WAVE;
+    const int l31 = lane & 31;
+    const int rh = (lane >> 5) * 4;
+    const int c8 = (lane % LPR) * 8;
+    const int rsub = lane / LPR;
+    const int col = n0 + wn * T::WTN + c8;
+    const bool col_ok = col < N;                       // N % 8 == 0: the 8 columns are inside or outside together
+    const uint32_t dkey = e.drop_scale != 0.0f ? drop_key(e.drop_seed, e.drop_step) : 0u;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.0f; bi[j] = 0.0f; }
+    if (col_ok && e.scale) {
+        const float4 a = *reinterpret_cast<const float4 *>(e.scale + col), b = *reinterpret_cast<const float4 *>(e.scale + col + 4);
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (col_ok && e.bias) {
+        const float4 a = *reinterpret_cast<const float4 *>(e.bias + col), b = *reinterpret_cast<const float4 *>(e.bias + col + 4);
+        bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
+    }
+    const unsigned short *res16 = reinterpret_cast<const unsigned short *>(e.residual);
+    const unsigned short *msk16 = reinterpret_cast<const unsigned short *>(e.mask);
+    unsigned short *C16 = reinterpret_cast<unsigned short *>(C);
+#pragma unroll
+    for (int mi = 0; mi < T::TM; ++mi) {
+        const int rowbase = m0 + wm * T::WTM + mi * 32 + rsub;
+        uint4 rr[NP], mm[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int row = rowbase + p * RPP;
+            const bool ok = col_ok && row < M;
+            rr[p] = make_uint4(0u, 0u, 0u, 0u);
+            mm[p] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + (long long)row * e.ldr + col);
+            if (ok && msk16) mm[p] = *reinterpret_cast<const uint4 *>(msk16 + (long long)row * e.ldmask + col);
+        }
+        __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + rh) * S::LD + ni * 32 + l31] = acc[mi][ni][r];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int rl = rsub + p * RPP;
+            const int row = rowbase + p * RPP;
+            if (!(col_ok && row < M)) continue;
+            const float4 a0 = *reinterpret_cast<const float4 *>(stage + rl * S::LD + c8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(stage + rl * S::LD + c8 + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const unsigned rw[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
+            const unsigned mw[4] = {mm[p].x, mm[p].y, mm[p].z, mm[p].w};
+            bool keep[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep[j] = true;
+            if (e.drop_scale != 0.0f) {                // element index row * N + col is a multiple of 8: four pair hashes
+                const unsigned long long di = ((unsigned long long)row * N + col) >> 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t h = drop_hash(dkey, di + j);
+                    keep[2 * j] = (h & 0xFFFFu) >= e.drop_thresh;
+                    keep[2 * j + 1] = (h >> 16) >= e.drop_thresh;
+                }
+            }
+            unsigned ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o0 = epi_one(av[2 * j], sc[2 * j], bi[2 * j], e, bf16_bits_to_f32(rw[j] & 0xFFFFu), bf16_bits_to_f32(mw[j] & 0xFFFFu), keep[2 * j]);
+                const float o1 = epi_one(av[2 * j + 1], sc[2 * j + 1], bi[2 * j + 1], e, bf16_bits_to_f32(rw[j] >> 16), bf16_bits_to_f32(mw[j] >> 16), keep[2 * j + 1]);
+                ow[j] = f32_to_bf16_pair(o0, o1);
+            }
+            *reinterpret_cast<uint4 *>(C16 + (long long)row * ldc + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+// ALLOW_WIDE = false: callers whose output can never take the all-bf16 form (weight gradients: fp32, accumulated) keep the
+// 4-column code alone -- the second form would only cost them registers and code
+template <int BM, int BN, int WGM, int WGN, bool ALLOW_WIDE = true>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
                                          float *stage_base, float *C, long long ldc, int M, int N, int m0, int n0,
                                          int wm, int wn, int lane, int wave, const EpiArgs &e) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     using S = StageCfg<BN, WGN>;
+    if constexpr (ALLOW_WIDE) {
+        if (e.wide16) {                                // (kernel argument: uniform over the grid)
+            epilogue_wide16<BM, BN, WGM, WGN>(acc, stage_base, C, ldc, M, N, m0, n0, wm, wn, lane, wave, e);
+            return;
+        }
+    }
     constexpr int VPR = T::WTN / 4;                    // float4 per staged row
     constexpr int ITERS = (32 * VPR) / 64;
     float *stage = stage_base + wave * S::FLOATS_PER_WAVE;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, c
         cur ^= 1;
     }
     if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, 0);
-    epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
+    epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
@@ -609,6 +609,12 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
               (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
               (!d->residual || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
               (!d->mask || (aligned16(d->mask) && d->ldmask % 4 == 0));
+
+    // all-bf16 epilogue streams, 16-byte rows: the 8-columns-per-lane epilogue (gemm_core.h epilogue_wide16); DETR_HIP_EPI_WIDE=2: off
+    g.e.wide16 = g.e.c16 && split == 1 && batch == 1 && (!d->residual || g.e.r16) && (!d->mask || g.e.m16) && d->N % 8 == 0 &&
+                 d->ldc % 8 == 0 && aligned16(d->C) && (!d->residual || (d->ldr % 8 == 0 && aligned16(d->residual))) &&
+                 (!d->mask || (d->ldmask % 8 == 0 && aligned16(d->mask))) && (!d->scale || aligned16(d->scale)) &&
+                 (!d->bias || aligned16(d->bias)) && tune(T_EPI_WIDE) != 2;
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
     DETR_REQUIRE(!(bf16c && d->a_dtype == 1 && !ak) || (d->lda % 8 == 0 && d->M % 8 == 0 && aligned16(d->A)),

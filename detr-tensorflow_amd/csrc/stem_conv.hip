@@ -393,7 +393,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
         }
     }
     float *dw = a.dw + (long long)blockIdx.z * a.part_stride;
-    epilogue<BM, BN, 2, 2>(acc, reinterpret_cast<float *>(smem_raw), dw, 64, STEM_K, 64, k0, 0, wm, wn, lane, wave, a.e);
+    epilogue<BM, BN, 2, 2, false>(acc, reinterpret_cast<float *>(smem_raw), dw, 64, STEM_K, 64, k0, 0, wm, wn, lane, wave, a.e);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ def _reset_library_tuning():
     import os
     yield
     from detr_tf import _hip
-    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64")
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64", "DETR_HIP_EPI_WIDE")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1405,6 +1405,66 @@ def test_gemm_bf16_deep_k_tiles_are_bit_identical(hip, tile, ak, bk, M, N, K, sp
     if rs_deep is not None:
         assert torch.equal(rs_deep, rs32)
         assert float((rs_deep.double() - A64.sum(1)).abs().max()) < 1e-3 * float(A64.sum(1).abs().max() + 1)
+
+
+@pytest.mark.parametrize("tile", [3, 1, 2, 5])
+@pytest.mark.parametrize("M,N,K,epi", [(200, 136, 256, "bias_relu"), (75, 264, 96, "res_mask"), (1000, 256, 64, "drop_res"),
+                                        (333, 72, 520, "scale_bias_res_mask_relu"), (130, 8, 32, "plain")])
+def test_gemm_wide_bf16_epilogue_is_bit_identical(hip, tile, M, N, K, epi):
+    """The all-bf16 epilogue (gemm_core.h epilogue_wide16: 8 columns per lane, every residual / mask row of a strip requested up
+    front) against the 4-columns-per-lane form (DETR_HIP_EPI_WIDE=2): the per-element arithmetic is the same function, so the
+    outputs must be IDENTICAL bits -- every tile shape of the bf16 engine, ragged M and N (N % 8 == 0), all epilogue items."""
+    torch.manual_seed(M + N + K)
+    b16 = torch.bfloat16
+    A = g(torch.randn(M, K)).to(b16)
+    Bm = g(torch.randn(N, K) / K ** 0.5).to(b16)
+    bias, scale = g(torch.randn(N)), g(torch.rand(N) + 0.5)
+    res, msk = g(torch.randn(M, N)).to(b16), g(torch.randn(M, N)).to(b16)
+    step = torch.tensor([0x2468ace, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+    kw = dict(compute=1)
+    if "bias" in epi:
+        kw.update(bias=bias)
+    if "scale" in epi:
+        kw.update(scale=scale, alpha=0.75)
+    if "relu" in epi:
+        kw.update(act=1)
+    if "res" in epi:
+        kw.update(residual=res, ldr=N)
+    if "mask" in epi:
+        kw.update(mask=msk, ldmask=N)
+    if "drop" in epi:
+        kw.update(dropout_p=0.1, dropout_seed=9, dropout_step=step)
+    outs = []
+    for mode in (None, "2"):
+        hip.set_tuning("DETR_HIP_EPI_WIDE", mode)
+        hip.set_tuning("DETR_HIP_GEMM_TILE", str(tile))
+        hip.set_tuning("DETR_HIP_GEMM_STREAM", "2")
+        try:
+            C = torch.full((M, N), 7.0, device=DEV, dtype=b16)
+            hip.gemm(M, N, K, A, K, 1, Bm, K, 1, C, N, **kw)
+            torch.cuda.synchronize()
+        finally:
+            for k in ("DETR_HIP_EPI_WIDE", "DETR_HIP_GEMM_TILE", "DETR_HIP_GEMM_STREAM"):
+                hip.set_tuning(k, None)
+        outs.append(C.float().cpu())
+    wide, narrow = outs
+    want = A.double().cpu() @ Bm.double().cpu().t()
+    if "scale" in epi:
+        want = want * scale.double().cpu()
+    if "bias" in epi:
+        want = want + bias.double().cpu()
+    if "scale" in epi:
+        want = want * 0.75
+    if "drop" not in epi:
+        if "res" in epi:
+            want = want + res.double().cpu()
+        if "relu" in epi:
+            want = torch.relu(want)
+        if "mask" in epi:
+            want = torch.where(msk.double().cpu() > 0, want, torch.zeros_like(want))
+        assert float((narrow.double() - want).abs().max()) < 2.0 ** -7 * float(want.abs().max())
+    assert float(narrow.abs().max()) > 0
+    assert torch.equal(wide, narrow), float((wide - narrow).abs().max())
 
 
 @pytest.mark.parametrize("split", [1, 2, 4])
