@@ -1289,8 +1289,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     a.M = d->N * a.Hd * a.Wd;
     e.ldr = a.Cd;
     e.ldmask = a.Cd;
-    // all-bf16 epilogue streams (channel counts are % 16, rows 16-byte aligned): 8 columns per lane (gemm_core.h epilogue_wide16);
-    // the stride-2 input-gradient classes below address their rows through the remap and keep the 4-column form
+    // all-bf16 epilogue streams (channel counts are % 16, rows 16-byte aligned): 8 columns per lane (gemm_core.h epilogue_wide16)
     e.wide16 = e.c16 && e.vec && (!d->residual || e.r16) && (!d->mask || e.m16) && tune(T_EPI_WIDE) != 2;
     a.e = e;
     a.w16 = (d->w_dtype == 1);
@@ -1336,7 +1335,6 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
                 c.kh0 = (ph + d->pad) & 1; c.kw0 = (pw + d->pad) & 1;
                 c.nth = c.kh0 ? 1 : 2; c.ntw = c.kw0 ? 1 : 2;
                 c.e.remap_w2 = c.Wp; c.e.remap_h2 = c.Hp; c.e.remap_W = a.Wd; c.e.remap_H = a.Hd;
-                c.e.wide16 = 0;
                 c.e.remap_ph = ph; c.e.remap_pw = pw;
                 launch(c);
             }

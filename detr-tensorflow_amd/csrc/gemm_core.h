@@ -49,7 +49,7 @@ struct EpiArgs {
     int c16 = 0, r16 = 0, m16 = 0;
     const uint32_t *drop_step = nullptr;
     // 1: all-bf16 epilogue streams (C, and residual / mask when present) with rows that are 16-byte aligned and a multiple of 8
-    // wide, no atomics, no row remap -> epilogue_wide16 (8 columns per lane, every request of a strip in flight at once)
+    // wide, no atomics -> epilogue_wide16 (8 columns per lane, every request of a strip in flight at once)
     int wide16 = 0;
 };
 
@@ -364,18 +364,26 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
     const unsigned short *res16 = reinterpret_cast<const unsigned short *>(e.residual);
     const unsigned short *msk16 = reinterpret_cast<const unsigned short *>(e.mask);
     unsigned short *C16 = reinterpret_cast<unsigned short *>(C);
+    auto prow_of = [&](const int row) -> long long {      // output-row remap of the stride-2 input-gradient classes (EpiArgs)
+        if (e.remap_w2 <= 0) return row;
+        const int w2 = row % e.remap_w2, t2 = row / e.remap_w2;
+        const int h2 = t2 % e.remap_h2, n2 = t2 / e.remap_h2;
+        return ((long long)n2 * e.remap_H + 2 * h2 + e.remap_ph) * e.remap_W + 2 * w2 + e.remap_pw;
+    };
 #pragma unroll
     for (int mi = 0; mi < T::TM; ++mi) {
         const int rowbase = m0 + wm * T::WTM + mi * 32 + rsub;
         uint4 rr[NP], mm[NP];
+        long long prow[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int row = rowbase + p * RPP;
             const bool ok = col_ok && row < M;
+            prow[p] = prow_of(row);
             rr[p] = make_uint4(0u, 0u, 0u, 0u);
             mm[p] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-            if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + (long long)row * e.ldr + col);
-            if (ok && msk16) mm[p] = *reinterpret_cast<const uint4 *>(msk16 + (long long)row * e.ldmask + col);
+            if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + prow[p] * e.ldr + col);
+            if (ok && msk16) mm[p] = *reinterpret_cast<const uint4 *>(msk16 + prow[p] * e.ldmask + col);
         }
         __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
 #pragma unroll
@@ -398,7 +406,7 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) keep[j] = true;
             if (e.drop_scale != 0.0f) {                // element index row * N + col is a multiple of 8: four pair hashes
-                const unsigned long long di = ((unsigned long long)row * N + col) >> 1;
+                const unsigned long long di = ((unsigned long long)prow[p] * N + col) >> 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t h = drop_hash(dkey, di + j);
@@ -413,7 +421,7 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
                 const float o1 = epi_one(av[2 * j + 1], sc[2 * j + 1], bi[2 * j + 1], e, bf16_bits_to_f32(rw[j] >> 16), bf16_bits_to_f32(mw[j] >> 16), keep[2 * j + 1]);
                 ow[j] = f32_to_bf16_pair(o0, o1);
             }
-            *reinterpret_cast<uint4 *>(C16 + (long long)row * ldc + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            *reinterpret_cast<uint4 *>(C16 + prow[p] * ldc + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
     }
 }
