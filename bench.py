@@ -416,7 +416,7 @@ def main():
         if main_tables[0] is not None:
             (fam, dom, rows), mix = main_tables
             roofline = roofline_entry(fam, dom, rows, ev_steps, args.precision,
-                                      "r02_traffic_bf16.json" if args.precision == "bf16" else "r03_traffic.json")
+                                      "r03_traffic_bf16.json" if args.precision == "bf16" else "r03_traffic.json")
             step_roofline = {"what": "SURVEY 8d mixed roofline: sum over the instrumented GEMM / conv / attention launches of "
                                      "max(FLOPs / MFMA peak of the launch's dtype, algorithmic bytes / 8 TB/s)",
                              "mixed_ms": round(mix["mixed_ms"], 3), "instrumented_kernel_ms": round(mix["covered_ms"], 3),

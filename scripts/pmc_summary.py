@@ -42,7 +42,7 @@ if len(sys.argv) >= 4:
     def fold(name):
         """rocprofv3 kernel name -> the family name detr_tf/_hip.py reports: one kernel BODY with every template instantiation
         pooled (layouts, storage types, tile sizes; grouped launches folded into their base kernel)."""
-        m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group)?_kernel<", name)
+        m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group|_k64)?_kernel<", name)
         if m:
             return f"{m.group(1)}_kernel"
         if "detr::gemm_stream_bf16_kernel" in name:
