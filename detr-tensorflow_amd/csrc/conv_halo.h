@@ -17,21 +17,27 @@
 
 namespace detr {
 
-constexpr int CH_TH = 8, CH_TW = 32;                     // output pixels of a workgroup tile
-constexpr int CH_PW = CH_TW + 2, CH_PH = CH_TH + 2;      // input patch (1 pixel border)
-constexpr int CH_PIX = CH_PH * CH_PW;                    // 340 patch pixels
-constexpr int CH_GRAN = CH_PIX * 4;                      // 16-byte granules (8 channels) of a 32-channel chunk
-constexpr int CH_NG = (CH_GRAN + 255) / 256;             // granules per thread (the last round is partial)
-constexpr int CH_PATCH_BYTES = CH_PIX * BF_LD * 2;       // 27200
+// Tile: TH x 32 output pixels.  TH = 8 (256 pixels, 4 MFMA row blocks per wave, 2 workgroups per CU) or TH = 4 (128 pixels, 2 row
+// blocks, 33 + 20 KB of LDS and <= 168 VGPRs: 3 workgroups per CU; half the pixels per kernel-tile fetch, twice the workgroups).
+constexpr int CH_TW = 32;                                // output pixels of a tile row = one MFMA row block
+constexpr int CH_PW = CH_TW + 2;                         // input patch width (1 pixel border)
+template <int TH>
+struct HaloGeom {
+    static constexpr int PH = TH + 2;                    // patch rows
+    static constexpr int PIX = PH * CH_PW;               // 340 / 204 patch pixels
+    static constexpr int GRAN = PIX * 4;                 // 16-byte granules (8 channels) of a 32-channel chunk
+    static constexpr int NG = (GRAN + 255) / 256;        // granules per thread (the last round is partial)
+    static constexpr int RB = TH / 2;                    // 32-pixel row blocks per wave
+};
 
-template <int BN>
+template <int BN, int TH>
 struct ConvHaloSmem {
-    unsigned short P[2][CH_PIX][BF_LD];                  // input patch of chunk c in P[c & 1]
+    unsigned short P[2][HaloGeom<TH>::PIX][BF_LD];       // input patch of chunk c in P[c & 1]
     unsigned short B[2][BN][BF_LD];                      // kernel tile of step s in B[s & 1]
 };
-template <int BN>
+template <int BN, int TH>
 struct ConvHaloSmemBytes {
-    static constexpr int TILES = (int)sizeof(ConvHaloSmem<BN>);
+    static constexpr int TILES = (int)sizeof(ConvHaloSmem<BN, TH>);
     static constexpr int STAGE = StageCfg<BN, 2>::BYTES;
     static constexpr int VALUE = TILES > STAGE ? TILES : STAGE;
 };
@@ -42,8 +48,8 @@ struct ConvHaloSmemBytes {
 // before its LDS round trip.  (The generic epilogue of gemm_core.h walks a strip in a rolled loop with the bias / mask
 // loads inside: with 4 strips per wave and only 8 waves per CU that was 16 dependent L2 round trips per workgroup --
 // 71 of the 103 us of the C = 64 launch, ablation build 31.)
-template <int BN>
-__device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[4][BN / 64], float *stage_base, unsigned short *dst,
+template <int BN, int TH>
+__device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 64], float *stage_base, unsigned short *dst,
                                               const ConvArgs &a, int n, int h0, int w0, int n0, int wm, int wn, int lane,
                                               int wave) {
     constexpr int TN = BN / 64, WTN = BN / 2;
@@ -65,8 +71,8 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[4][BN / 64], f
     const unsigned short *mask = reinterpret_cast<const unsigned short *>(e.mask);
     const int wn_ok = a.Wd - w0;                        // valid pixels of a tile row
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int h = h0 + 4 * wm + mi;
+    for (int mi = 0; mi < TH / 2; ++mi) {
+        const int h = h0 + (TH / 2) * wm + mi;
         const bool row_ok = h < a.Hd;
         const long long prow0 = ((long long)n * a.Hd + h) * a.Wd + w0;
         uint4 mk[ITERS];
@@ -106,11 +112,13 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[4][BN / 64], f
 }
 
 // ConvArgs as for conv3x3_bf16c_kernel (stride 1, pad 1, bf16 src / w / dst); Hp / Wp carry the tile counts along H / W.
-template <int BN, bool DGRAD>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(ConvArgs a) {
-    using T = TileCfg<CH_TH * CH_TW, BN, 2, 2>;          // wave tile: 4 pixel rows x BN / 2 channels
+template <int BN, bool DGRAD, int TH = 8>
+__global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf16_kernel(ConvArgs a) {
+    using T = TileCfg<TH * CH_TW, BN, 2, 2>;             // wave tile: TH / 2 pixel rows x BN / 2 channels
+    using G = HaloGeom<TH>;
+    constexpr int CH_PIX = G::PIX, CH_GRAN = G::GRAN, CH_NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) char halo_smem[];
-    ConvHaloSmem<BN> &sm = *reinterpret_cast<ConvHaloSmem<BN> *>(halo_smem);
+    ConvHaloSmem<BN, TH> &sm = *reinterpret_cast<ConvHaloSmem<BN, TH> *>(halo_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(Conv
     t /= a.Wp;
     const int thi = t % a.Hp;
     const int n = t / a.Hp;
-    const int h0 = thi * CH_TH, w0 = twi * CH_TW, n0 = tn * BN;
+    const int h0 = thi * TH, w0 = twi * CH_TW, n0 = tn * BN;
     const int nchunks = a.Cs / BF_BK;
     const long long tapstride = (long long)a.Ci * a.Co;
 
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(Conv
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int l31 = lane & 31, kh8 = (lane >> 5) * 8;
-    // A fragment of tile row (4 * wm + mi), patch offset (dh, dw), k-step ks: patch row ((4 * wm + mi + dh) * 34 + l31 + dw)
-    const unsigned short *pa_base = &sm.P[0][0][0] + ((4 * wm) * CH_PW + l31) * BF_LD + kh8;
+    // A fragment of tile row (RB * wm + mi), patch offset (dh, dw), k-step ks: patch row ((RB * wm + mi + dh) * 34 + l31 + dw)
+    const unsigned short *pa_base = &sm.P[0][0][0] + ((G::RB * wm) * CH_PW + l31) * BF_LD + kh8;
     auto mma_tap = [&](int pbuf, int bbuf, int tp) {
         const int dh = tp / 3, dw = tp - 3 * (tp / 3);
         const unsigned short *pa = pa_base + pbuf * (CH_PIX * BF_LD) + (dh * CH_PW + dw) * BF_LD;
@@ -252,29 +260,40 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_halo_bf16_kernel(Conv
         if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
     __syncthreads();
-    halo_epilogue<BN>(acc, reinterpret_cast<float *>(halo_smem), reinterpret_cast<unsigned short *>(a.dst), a, n, h0, w0, n0, wm, wn, lane, wave);
+    halo_epilogue<BN, TH>(acc, reinterpret_cast<float *>(halo_smem), reinterpret_cast<unsigned short *>(a.dst), a, n, h0, w0, n0, wm, wn, lane, wave);
 }
 
-template <int BN>
-static int launch_conv_halo(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+template <int BN, int TH>
+static int launch_conv_halo_t(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     ConvArgs a = a0;
-    a.Hp = cdiv(a.Hd, CH_TH);
+    a.Hp = cdiv(a.Hd, TH);
     a.Wp = cdiv(a.Wd, CH_TW);
     a.tiles_m = a.N * a.Hp * a.Wp;
     a.tiles_n = cdiv(a.Cd, BN);
-    constexpr int smem = ConvHaloSmemBytes<BN>::VALUE;
+    constexpr int smem = ConvHaloSmemBytes<BN, TH>::VALUE;
     static bool reserved[2] = {false, false};
-    const void *fn = dgrad ? reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, true>)
-                           : reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, false>);
+    const void *fn = dgrad ? reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, true, TH>)
+                           : reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, false, TH>);
     if (!reserved[dgrad ? 1 : 0]) {
         hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         DETR_REQUIRE(err == hipSuccess, "conv3x3 (halo): cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(err));
         reserved[dgrad ? 1 : 0] = true;
     }
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
-    if (dgrad) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, true>), grid, block, smem, s, a);
-    else hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, false>), grid, block, smem, s, a);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, true, TH>), grid, block, smem, s, a);
+    else hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, false, TH>), grid, block, smem, s, a);
     return 0;
+}
+
+// Tile height.  Measured (scripts/micro_conv.py, profiles/r03_micro_conv_halo_tiles.txt): 4-row tiles win 10-13 % on the 128- and
+// 256-channel maps (100x167: 58.7 -> 52.0 us forward, 50x84: 61.6 -> 53.4; three workgroups per CU, 4 % instead of 12 % padded rows on
+// the 50-row map, 624 instead of 336 workgroups) and lose on the 64-channel forward (64.3 -> 69.9 us: HBM / epilogue bound, twice the
+// kernel-tile fetches).  DETR_HIP_CONV_HALO = 3 forces 4-row tiles, 4 forces 8-row tiles; 0 = this rule.
+template <int BN>
+static int launch_conv_halo(const ConvArgs &a, bool dgrad, hipStream_t s) {
+    const int mode = tune(T_CONV_HALO);
+    const bool th4 = mode == 3 || (mode != 4 && a.Cd >= 128);
+    return th4 ? launch_conv_halo_t<BN, 4>(a, dgrad, s) : launch_conv_halo_t<BN, 8>(a, dgrad, s);
 }
 
 }  // namespace detr

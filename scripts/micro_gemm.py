@@ -110,6 +110,15 @@ cases = [
     ("dec ffn lin1 dgrad", 800, 256, 2048, 1, 0, dict(res=1, r32=1, c32=1)),
     ("enc proj wgrad", 256, 256, 8400, 0, 0, dict(wgrad=1, c32=1)),
     ("ffn lin1 wgrad", 2048, 256, 8400, 0, 0, dict(wgrad=1, c32=1)),
+    ("l3 conv3 fwd K256", 33600, 1024, 256, 1, 0, dict(bias=1, res=1, act=1)),
+    ("l3 conv1 dgrad K256", 33600, 1024, 256, 1, 1, dict(res=1, mask=1)),
+    ("l3 conv1 fwd b0 K512", 33600, 256, 512, 1, 0, dict(bias=1, act=1)),
+    ("l2 conv3 fwd K128", 133600, 512, 128, 1, 0, dict(bias=1, res=1, act=1)),
+    ("l2 conv1 dgrad K128", 133600, 512, 128, 1, 1, dict(res=1, mask=1)),
+    ("l2 conv1 fwd K256", 133600, 128, 256, 1, 0, dict(bias=1, act=1)),
+    ("l2 conv3 dgrad K256", 133600, 128, 256, 1, 1, dict(mask=1)),
+    ("l1 conv3 fwd K64", 534400, 256, 64, 1, 0, dict(bias=1, res=1, act=1)),
+    ("l1 conv1 fwd K256", 534400, 64, 256, 1, 0, dict(bias=1, act=1)),
     ("ffn lin1 fwd K256", 8400, 2048, 256, 1, 1, dict(bias=1, act=1)),
     ("ffn lin2 dgrad K256", 8400, 2048, 256, 1, 0, dict(mask=1, alpha=1.0 / 0.9)),
 ]

@@ -1066,13 +1066,14 @@ def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stri
         assert torch.equal(d16, b16(d32))
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 19, 45, 64), (1, 8, 32, 128), (2, 25, 70, 256), (1, 40, 33, 64), (3, 9, 31, 128)])
-def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C):
-    """The halo-staged stride-1 kernel (csrc/conv_halo.h: bf16 x / w / y, 8 x 32 pixel tiles, one staged input patch per
-    32-channel chunk) -- forward (+ BN shift, ReLU) and input gradient (+ ReLU mask) against fp64 on the same bf16 operands
-    (one bf16 rounding) and against the tile kernel on the same call (DETR_HIP_CONV_HALO=2): the two sum the (tap, chunk)
-    products in different orders, i.e. may differ by one bf16 ulp on a small fraction of the outputs.  The shapes cover
-    ragged tile rows / columns, several tiles per image and several images."""
+@pytest.mark.parametrize("rows", ["3", "4"])
+@pytest.mark.parametrize("N,H,W,C", [(2, 19, 45, 64), (1, 8, 32, 128), (2, 25, 70, 256), (1, 40, 33, 64), (3, 9, 31, 128), (1, 13, 42, 512)])
+def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C, rows):
+    """The halo-staged stride-1 kernel (csrc/conv_halo.h: bf16 x / w / y, 4 x 32 (DETR_HIP_CONV_HALO=3) and 8 x 32 (=4) pixel
+    tiles, one staged input patch per 32-channel chunk) -- forward (+ BN shift, ReLU) and input gradient (+ ReLU mask) against
+    fp64 on the same bf16 operands (one bf16 rounding) and against the tile kernel on the same call (DETR_HIP_CONV_HALO=2): the two
+    sum the (tap, chunk) products in different orders, i.e. may differ by one bf16 ulp on a small fraction of the outputs.  The
+    shapes cover ragged tile rows / columns, several tiles per image, several images and the 512-channel maps of layer4."""
     torch.manual_seed(N + H + W + C)
     b16 = lambda t: g(t.float()).to(torch.bfloat16)
     x, dy = _bf(torch.randn(N, H, W, C)), _bf(torch.randn(N, H, W, C))
@@ -1085,7 +1086,7 @@ def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C):
     xd, dyd, wd, md, sd = b16(x), b16(dy), b16(w), b16(msk), g(shift.float())
     outs = {}
     for mode in ("0", "2"):
-        hip.set_tuning("DETR_HIP_CONV_HALO", mode)
+        hip.set_tuning("DETR_HIP_CONV_HALO", rows if mode == "0" else mode)
         y = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
         dx = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
         hip.conv3x3(0, xd, wd, y, N, H, W, C, H, W, C, 1, bias=sd, act=1, compute=1)
