@@ -61,6 +61,12 @@ __device__ __forceinline__ void ablate_keep(const T &v) {      // keeps a loaded
 // spaces, and on gfx9 loads and stores share vmcnt -- it therefore drains every outstanding global load, which would
 // serialise an operand prefetch that is meant to stay in flight across the barrier.
 #if defined(__HIPCC__)
+// Ordering of LDS accesses INSIDE one wave (a wave-private staging region written by some lanes and read by others): the wave runs in
+// lockstep, so a fence on the LDS counter is enough -- no workgroup barrier, the other waves are not involved.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();

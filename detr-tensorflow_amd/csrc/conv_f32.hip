@@ -791,7 +791,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
         f32x16 one[1][1];
         one[0][0] = acc[t];
         float *dw = a.dw + (long long)t * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
-        epilogue<64, 64, 2, 2, false>(one, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
+        epilogue<64, 64, 2, 2, false>(one, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e, t == 0);
     }
 }
 

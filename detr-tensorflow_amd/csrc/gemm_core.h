@@ -385,13 +385,16 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
             if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + prow[p] * e.ldr + col);
             if (ok && msk16) mm[p] = *reinterpret_cast<const uint4 *>(msk16 + prow[p] * e.ldmask + col);
         }
-        __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
+        // the staging region is wave-private: only the first strip needs the workgroup (the main loop / a row-sum finish of the
+        // other waves may still be reading the LDS it aliases); later strips and the write -> read turn-around are wave-local
+        if (mi == 0) __syncthreads();
+        else wave_lds_sync();
 #pragma unroll
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 stage[((r & 3) + 8 * (r >> 2) + rh) * S::LD + ni * 32 + l31] = acc[mi][ni][r];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int rl = rsub + p * RPP;
@@ -431,7 +434,7 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
 template <int BM, int BN, int WGM, int WGN, bool ALLOW_WIDE = true>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
                                          float *stage_base, float *C, long long ldc, int M, int N, int m0, int n0,
-                                         int wm, int wn, int lane, int wave, const EpiArgs &e) {
+                                         int wm, int wn, int lane, int wave, const EpiArgs &e, const bool wg_sync = true) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     using S = StageCfg<BN, WGN>;
     if constexpr (ALLOW_WIDE) {
@@ -449,13 +452,16 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TileCfg<BM, BN, WGM
     const uint32_t dkey = e.drop_scale != 0.0f ? drop_key(e.drop_seed, e.drop_step) : 0u;
 #pragma unroll
     for (int mi = 0; mi < T::TM; ++mi) {
-        __syncthreads();                               // previous strip fully read (also: main loop done with LDS)
+        // (wave-private staging region: see epilogue_wide16; `wg_sync` = false: the caller's previous epilogue call on the same
+        //  region already went through the workgroup barrier -- the nine taps of the fused weight gradient)
+        if (mi == 0 && wg_sync) __syncthreads();
+        else wave_lds_sync();
 #pragma unroll
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 stage[((r & 3) + 8 * (r >> 2) + rh) * S::LD + ni * 32 + l31] = acc[mi][ni][r];
-        __syncthreads();
+        wave_lds_sync();
         const int rowbase = m0 + wm * T::WTM + mi * 32;
         // kept rolled on purpose: the body only touches LDS / global memory, and a small body lets the
         // compiler fully unroll the register-indexing mi / ni / r loops above (otherwise acc spills to scratch)
