@@ -1315,7 +1315,9 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     auto launch = [&](const ConvArgs &c) {
         const long long big = (long long)cdiv(c.M, 128) * cdiv(c.Cd, 128);
         if (d->compute == 1 && c.Cs % 32 == 0 && c.Cd % 32 == 0) {
-            if (force == 3 || (force == 0 && (c.Cd <= 128 || big < 512)))   // measured: profiles/tune_bf16_r1d.txt
+            // measured: profiles/tune_bf16_r1d.txt; round 3 (scripts/micro_conv.py, with the wide epilogue): the stride-2 forward at 128
+            // channels 83 -> 72 us (cold 113 -> 97) and its input-gradient classes 173 -> 165 us on 128x128 tiles
+            if (force == 3 || (force == 0 && (c.Cd < 128 || big < 256)))
                 launch_conv_bf16<64, 64, 2, 2>(c, dgrad, s);
             else launch_conv_bf16<128, 128, 2, 2>(c, dgrad, s);
         } else if (force == 1) launch_conv<128, 128, 2, 2>(c, dgrad, s);
