@@ -29,6 +29,9 @@ struct ConvArgs {
     int par_on, Hp, Wp, ph, pw, kh0, kw0, nth, ntw;
     int w16;                     // the kernel tensor is bf16 in memory (bf16 compute only)
     int x16;                     // the source tensor (x for fwd, dy for dgrad) is bf16 in memory
+    // all four parity classes in ONE launch of the halo kernel's class form (conv_halo.h): class k = 0..3 is (ph, pw) =
+    // (1,1), (0,1), (1,0), (0,0) -- heaviest first --, owns workgroups [cls_off[k], cls_off[k + 1]) and cls_hp / cls_wp tiles along H / W
+    int cls_off[5], cls_hp[4], cls_wp[4];
 };
 
 }  // namespace detr
@@ -1326,10 +1329,21 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     };
     if (dgrad && d->stride == 2 && tune(T_DGRAD_S2_CLASSES) != 2) {
         // one launch per destination-pixel parity class: 1 + 2 + 2 + 4 tap-GEMMs instead of 9 with 3/4 of the rows masked
+        // all-bf16 tensors: the class form of the halo-staged kernel (conv_halo.h; DETR_HIP_DGRAD_S2_CLASSES = 3: tile kernel)
+        const bool halo_cls = d->compute == 1 && d->pad == 1 && a.w16 && a.x16 && e.c16 && a.Cs % 32 == 0 && a.Cd % 64 == 0 &&
+                              a.Cd <= 512 && (!d->mask || e.m16) && !d->residual && !d->scale && !d->bias && d->alpha == 1.0f &&
+                              d->act == 0 && tune(T_DGRAD_S2_CLASSES) != 3 && tune(T_CONV_HALO) != 2;
+        if (halo_cls) {
+            if (a.Cd >= 128) { if (launch_conv_halo_s2classes<128>(a, s)) return -1; }
+            else if (launch_conv_halo_s2classes<64>(a, s)) return -1;
+            DETR_LAUNCH_CHECK("conv3x3 (halo, stride-2 classes)");
+            return 0;
+        }
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
                 ConvArgs c = a;
                 c.par_on = 1; c.ph = ph; c.pw = pw;
+
                 c.Hp = (a.Hd + 1 - ph) / 2;
                 c.Wp = (a.Wd + 1 - pw) / 2;
                 c.M = d->N * c.Hp * c.Wp;

@@ -48,10 +48,12 @@ struct ConvHaloSmemBytes {
 // before its LDS round trip.  (The generic epilogue of gemm_core.h walks a strip in a rolled loop with the bias / mask
 // loads inside: with 4 strips per wave and only 8 waves per CU that was 16 dependent L2 round trips per workgroup --
 // 71 of the 103 us of the C = 64 launch, ablation build 31.)
-template <int BN, int TH>
+// S2C (stride-2 input-gradient class, see the kernel): tile coordinates are CLASS coordinates (h2, w2); the pixel written (and the
+// mask pixel read) is (2 h2 + ph, 2 w2 + pw) of the [Hd][Wd] tensor.
+template <int BN, int TH, bool S2C = false>
 __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 64], float *stage_base, unsigned short *dst,
                                               const ConvArgs &a, int n, int h0, int w0, int n0, int wm, int wn, int lane,
-                                              int wave) {
+                                              int wave, int ph = 0, int pw = 0) {
     constexpr int TN = BN / 64, WTN = BN / 2;
     constexpr int LD = WTN + 4;                         // floats per staged row (16-byte aligned rows)
     constexpr int L8 = WTN / 8;                         // lanes per pixel
@@ -69,18 +71,19 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
         bi[0] = b0.x; bi[1] = b0.y; bi[2] = b0.z; bi[3] = b0.w; bi[4] = b1.x; bi[5] = b1.y; bi[6] = b1.z; bi[7] = b1.w;
     }
     const unsigned short *mask = reinterpret_cast<const unsigned short *>(e.mask);
-    const int wn_ok = a.Wd - w0;                        // valid pixels of a tile row
+    const int PS = S2C ? 2 : 1;                         // pixel step of the output tensor per tile pixel
+    const int wn_ok = S2C ? (a.Wd - pw + 1) / 2 - w0 : a.Wd - w0;        // valid pixels of a tile row
 #pragma unroll
     for (int mi = 0; mi < TH / 2; ++mi) {
-        const int h = h0 + (TH / 2) * wm + mi;
+        const int h = S2C ? 2 * (h0 + (TH / 2) * wm + mi) + ph : h0 + (TH / 2) * wm + mi;
         const bool row_ok = h < a.Hd;
-        const long long prow0 = ((long long)n * a.Hd + h) * a.Wd + w0;
+        const long long prow0 = ((long long)n * a.Hd + h) * a.Wd + (S2C ? 2 * w0 + pw : w0);
         uint4 mk[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int tw = it * RPI + rsub;
             mk[it] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-            if (mask && row_ok && tw < wn_ok) mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + tw) * e.ldmask + col);
+            if (mask && row_ok && tw < wn_ok) mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + PS * tw) * e.ldmask + col);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();                // the previous strip's reads are done
@@ -105,15 +108,21 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
                 v[j] = (m > 0.0f) ? v[j] : 0.0f;
             }
             if (row_ok && tw < wn_ok)
-                *reinterpret_cast<uint4 *>(dst + (prow0 + tw) * a.Cd + col) =
+                *reinterpret_cast<uint4 *>(dst + (prow0 + PS * tw) * a.Cd + col) =
                     make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7]));
         }
     }
 }
 
 // ConvArgs as for conv3x3_bf16c_kernel (stride 1, pad 1, bf16 src / w / dst); Hp / Wp carry the tile counts along H / W.
-template <int BN, bool DGRAD, int TH = 8>
+// S2C: the four pixel-parity classes (ph, pw) of the STRIDE-2 input gradient in one launch (ConvArgs.cls_*).  dx[2 h2 + ph, 2 w2 + pw] only receives the taps kh = ph + 1
+// (mod 2), kw = pw + 1 (mod 2), reading dy[h2 + dh, w2 + dw] with dh, dw in {0, 1}: a stride-1 "2 x 2" convolution over dy in class
+// coordinates.  The kernel walks FOUR taps per chunk (patch offsets (1..2, 1..2) of the same haloed dy patch) for every class; the taps
+// a class does not have request no kernel tile (out-of-range offsets) and skip their MFMAs -- wave-uniform, the pipeline keeps its
+// static shape.  (The tile kernel ran the four class launches of a conv at 220-330 TFLOP/s: gathered operands, 1-4 short tap-GEMMs.)
+template <int BN, bool DGRAD, int TH = 8, bool S2C = false>
 __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf16_kernel(ConvArgs a) {
+    static_assert(!S2C || DGRAD, "the class form exists for the input gradient only");
     using T = TileCfg<TH * CH_TW, BN, 2, 2>;             // wave tile: TH / 2 pixel rows x BN / 2 channels
     using G = HaloGeom<TH>;
     constexpr int CH_PIX = G::PIX, CH_GRAN = G::GRAN, CH_NG = G::NG;
@@ -121,13 +130,22 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
     ConvHaloSmem<BN, TH> &sm = *reinterpret_cast<ConvHaloSmem<BN, TH> *>(halo_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    int ph = 0, pw = 0, Hp = a.Hp, Wp = a.Wp;
+    if constexpr (S2C) {                                 // the four classes share the launch: [cls_off[k], cls_off[k + 1])
+        const int k = (id >= a.cls_off[1]) + (id >= a.cls_off[2]) + (id >= a.cls_off[3]);
+        id -= a.cls_off[k];
+        ph = (k == 0 || k == 2) ? 1 : 0;
+        pw = (k == 0 || k == 1) ? 1 : 0;
+        Hp = a.cls_hp[k];
+        Wp = a.cls_wp[k];
+    }
     const int tn = id % a.tiles_n;
     int t = id / a.tiles_n;
-    const int twi = t % a.Wp;
-    t /= a.Wp;
-    const int thi = t % a.Hp;
-    const int n = t / a.Hp;
+    const int twi = t % Wp;
+    t /= Wp;
+    const int thi = t % Hp;
+    const int n = t / Hp;
     const int h0 = thi * TH, w0 = twi * CH_TW, n0 = tn * BN;
     const int nchunks = a.Cs / BF_BK;
     const long long tapstride = (long long)a.Ci * a.Co;
@@ -164,9 +182,16 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
     constexpr int NRB = LB::NREG;
     LB lb;
     lb.init(a.w, a.Co, n0, a.Cd, a.Cs, true, tid, 9 * tapstride);
+    // S2C: step tp in 0..3 = patch offset (1 + (tp >> 1), 1 + (tp & 1)); the class has the tap iff (offset 1 or parity 1) on each axis;
+    // offset 1 reads dy[h2] (kernel row 1 for parity 0, row 2 for parity 1), offset 2 reads dy[h2 + 1] (kernel row 0)
+    auto s2_tap_ok = [&](int tp) -> bool { return ((tp >> 1) == 0 || ph == 1) && ((tp & 1) == 0 || pw == 1); };
+    auto s2_tap_w = [&](int tp) -> int {
+        const int kh = (tp >> 1) == 0 ? (ph ? 2 : 1) : 0, kw = (tp & 1) == 0 ? (pw ? 2 : 1) : 0;
+        return kh * 3 + kw;
+    };
     auto b_load = [&](int c, int tp, typename LB::Reg (&rb)[NRB]) {      // step (chunk c, patch offset tp = 3 * dh + dw)
-        const bool live = c < nchunks;
-        const int wt = DGRAD ? 8 - tp : tp;                                // dgrad: the kernel tap is the flipped offset
+        const bool live = c < nchunks && (!S2C || s2_tap_ok(tp));
+        const int wt = S2C ? s2_tap_w(tp) : (DGRAD ? 8 - tp : tp);        // dgrad: the kernel tap is the flipped offset
         lb.load(c * BF_BK, live ? a.Cs : 0, rb, live ? (unsigned)(wt * tapstride * 2) : 0u);
     };
 
@@ -182,7 +207,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
     // A fragment of tile row (RB * wm + mi), patch offset (dh, dw), k-step ks: patch row ((RB * wm + mi + dh) * 34 + l31 + dw)
     const unsigned short *pa_base = &sm.P[0][0][0] + ((G::RB * wm) * CH_PW + l31) * BF_LD + kh8;
     auto mma_tap = [&](int pbuf, int bbuf, int tp) {
-        const int dh = tp / 3, dw = tp - 3 * (tp / 3);
+        const int dh = S2C ? 1 + (tp >> 1) : tp / 3, dw = S2C ? 1 + (tp & 1) : tp - 3 * (tp / 3);
         const unsigned short *pa = pa_base + pbuf * (CH_PIX * BF_LD) + (dh * CH_PW + dw) * BF_LD;
         const unsigned short(*Bs)[BF_LD] = sm.B[bbuf];
 #pragma unroll
@@ -251,7 +276,30 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
             if constexpr ((DETR_ABLATE & 8) == 0) lds_barrier();
         }
     };
-    {
+    // S2C: four steps per chunk (step parity = tp & 1 in every chunk); the patch of chunk c + 1 -- requested one chunk ago -- is stored at
+    // the top of chunk c (its buffer was last read in chunk c - 1) and the patch of chunk c + 2 is requested right behind it
+    auto chunk4 = [&](const int c) {
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int cur = tp & 1;
+            if ((tp & 1) == 0) {
+                lb.store(sm.B[cur ^ 1], rb0);
+                b_load(c + (tp + 3) / 4, (tp + 3) % 4, rb0);
+            } else {
+                lb.store(sm.B[cur ^ 1], rb1);
+                b_load(c + (tp + 3) / 4, (tp + 3) % 4, rb1);
+            }
+            if (tp == 0) {
+                patch_store((c + 1) & 1, rp);
+                patch_load(c + 2, rp);
+            }
+            if (s2_tap_ok(tp)) mma_tap(c & 1, cur, tp);
+            lds_barrier();
+        }
+    };
+    if constexpr (S2C) {
+        for (int c = 0; c < nchunks; ++c) chunk4(c);
+    } else {
         int c = 0;
         for (; c + 2 <= nchunks; c += 2) {
             chunk(c, std::integral_constant<int, 0>{});
@@ -260,7 +308,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
         if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
     __syncthreads();
-    halo_epilogue<BN, TH>(acc, reinterpret_cast<float *>(halo_smem), reinterpret_cast<unsigned short *>(a.dst), a, n, h0, w0, n0, wm, wn, lane, wave);
+    halo_epilogue<BN, TH, S2C>(acc, reinterpret_cast<float *>(halo_smem), reinterpret_cast<unsigned short *>(a.dst), a, n, h0, w0, n0, wm, wn, lane, wave, ph, pw);
 }
 
 template <int BN, int TH>
@@ -282,6 +330,33 @@ static int launch_conv_halo_t(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
     if (dgrad) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, true, TH>), grid, block, smem, s, a);
     else hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, false, TH>), grid, block, smem, s, a);
+    return 0;
+}
+
+// the four pixel-parity classes of a stride-2 input gradient in one launch (4-row tiles; heaviest class first)
+template <int BN>
+static int launch_conv_halo_s2classes(const ConvArgs &a0, hipStream_t s) {
+    constexpr int TH = 4;
+    ConvArgs a = a0;
+    a.tiles_n = cdiv(a.Cd, BN);
+    a.cls_off[0] = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int ph = (k == 0 || k == 2) ? 1 : 0, pw = (k == 0 || k == 1) ? 1 : 0;
+        const int Hc = (a.Hd - ph + 1) / 2, Wc = (a.Wd - pw + 1) / 2;        // pixels of the class along H / W
+        a.cls_hp[k] = cdiv(Hc, TH);
+        a.cls_wp[k] = cdiv(Wc, CH_TW);
+        a.cls_off[k + 1] = a.cls_off[k] + a.N * a.cls_hp[k] * a.cls_wp[k] * a.tiles_n;
+    }
+    if (a.cls_off[4] <= 0) return 0;
+    constexpr int smem = ConvHaloSmemBytes<BN, TH>::VALUE;
+    static bool reserved = false;
+    const void *fn = reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, true, TH, true>);
+    if (!reserved) {
+        hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        DETR_REQUIRE(err == hipSuccess, "conv3x3 (halo, stride-2 classes): cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(err));
+        reserved = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, true, TH, true>), dim3((unsigned)a.cls_off[4]), dim3(GEMM_THREADS), smem, s, a);
     return 0;
 }
 

@@ -25,7 +25,7 @@ def _reset_library_tuning():
     import os
     yield
     from detr_tf import _hip
-    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64", "DETR_HIP_EPI_WIDE")
+    leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_DGRAD_S2_CLASSES", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64", "DETR_HIP_EPI_WIDE")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1102,6 +1102,45 @@ def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C, rows):
         diff = (halo - tile).abs()
         assert float((diff > 0).double().mean()) < 5e-3, (what, float((diff > 0).double().mean()))
         assert float((diff / (tile.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7, what
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 19, 45, 64), (1, 8, 64, 128), (2, 25, 70, 256), (1, 41, 33, 64), (1, 14, 42, 512), (3, 9, 31, 128)])
+def test_conv3x3_stride2_dgrad_halo_classes(hip, N, H, W, C):
+    """Stride-2 input gradient on bf16 tensors: the pixel-parity classes on the halo-staged kernel (csrc/conv_halo.h, class form:
+    four taps per chunk over the dy patch, missing taps skipped, output pixels (2 h2 + ph, 2 w2 + pw)) against fp64 on the same bf16
+    operands (one bf16 rounding) and against the tile kernel's class launches (DETR_HIP_DGRAD_S2_CLASSES=3; other summation order:
+    one bf16 ulp on a small fraction).  Odd and even input sizes (classes of different sizes, a last dy row / column without a
+    successor), ragged tiles, several images, 64 ... 512 channels, with the ReLU mask."""
+    torch.manual_seed(N + H + W + C)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    dy = _bf(torch.randn(N, Ho, Wo, C))
+    w = _bf(torch.randn(3, 3, C, C) / (3 * C ** 0.5))
+    msk = _bf(torch.randn(N, H, W, C))
+    w_oihw = w.permute(3, 2, 0, 1).contiguous()
+    ref = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2), w_oihw, stride=2, padding=1,
+                                               output_padding=(H + 2 - 3 - 2 * (Ho - 1), W + 2 - 3 - 2 * (Wo - 1))).permute(0, 2, 3, 1)
+    assert ref.shape == (N, H, W, C)
+    ref = torch.where(msk > 0, ref, torch.zeros_like(ref))
+    dyd, wd, md = b16(dy), b16(w), b16(msk)
+    outs = {}
+    for mode in (None, "3"):
+        hip.set_tuning("DETR_HIP_DGRAD_S2_CLASSES", mode)
+        try:
+            dx = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.conv3x3(1, dyd, wd, dx, N, H, W, C, Ho, Wo, C, 2, mask=md, compute=1)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning("DETR_HIP_DGRAD_S2_CLASSES", None)
+        outs[mode] = dx.float().cpu().double()
+    halo, tile = outs[None], outs["3"]
+    scale = float(ref.abs().max())
+    assert scale > 0
+    assert float(((tile - ref).abs() / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.1
+    assert float(((halo - ref).abs() / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.1, "more than one bf16 rounding from fp64"
+    diff = (halo - tile).abs()
+    assert float((diff > 0).double().mean()) < 5e-3
+    assert float((diff / (tile.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7
 
 
 @pytest.mark.parametrize("compute", [0, 1])
