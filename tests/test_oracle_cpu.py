@@ -260,3 +260,36 @@ def test_host_side_of_the_c_abi_under_address_sanitizer():
     r = subprocess.run(["make", "-C", pkg, "-j", str(os.cpu_count() or 2), "asan-check"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "host_abi_check: 0 failed expectation(s)" in r.stdout
+
+
+def test_profile_plumbing_of_the_bench_roofline():
+    """bench.py's `roofline.traffic` comes from profiles/r03_traffic_bf16.json, which scripts/pmc_summary.py writes by folding rocprofv3
+    kernel names into the family names detr_tf/_hip.py reports.  A kernel body that gets a new name (as the 64-deep K-tile variant
+    did) must still fold into its family, or the field silently turns null: every GEMM kernel of the committed kernel-stats profile
+    folds, the traffic file has the bench's dominant family, and the per-launch traffic is of the order of the algorithmic bytes."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        import pmc_summary
+    finally:
+        sys.path.pop(0)
+    names = []
+    with open(os.path.join(root, "profiles", "r03_rocprofv3_kernel_stats_bf16.txt")) as f:
+        for line in f:
+            m = re.search(r"(void )?detr::\w+.*", line)
+            if m and "detr::gemm_" in line:
+                names.append(m.group(0))
+    assert len(names) >= 10
+    assert all(pmc_summary.fold(n) in ("gemm_bf16c_kernel", "gemm_f32_kernel", "gemm_stream_bf16_kernel") for n in names), \
+        [n for n in names if pmc_summary.fold(n) is None]
+    assert pmc_summary.fold("detr::layernorm_fwd_kernel(float const*)") is None
+    traffic = json.load(open(os.path.join(root, "profiles", "r03_traffic_bf16.json")))
+    line = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    fam = line["roofline"]["kernel"].split("detr::")[1].split(" ")[0]
+    assert fam in traffic["per_symbol"], (fam, list(traffic["per_symbol"]))
+    t = traffic["per_symbol"][fam]["traffic_bytes_per_launch"]
+    assert 0.5 < t / line["roofline"]["algorithmic_bytes_per_launch"] < 3.0
+    with open(os.path.join(root, "bench.py")) as f:
+        assert "r03_traffic_bf16.json" in f.read()
