@@ -30,9 +30,10 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // out[r*ldc + c] += alpha * scale[c] * sum_s ws[s*part_stride + r*cols + c]   (gemm_f32.hip)
+// ts_bm > 0: tile-ordered slabs (gemm_core.h: store_slab_ts), tiles of ts_bm x ts_bn, ts_tiles_n per tile row
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
                           float alpha, const float *scale, hipStream_t stream, const float *rs_ws = nullptr,
-                          float *rs_out = nullptr, float rs_alpha = 1.0f);
+                          float *rs_out = nullptr, float rs_alpha = 1.0f, int ts_bm = 0, int ts_bn = 0, int ts_tiles_n = 0);
 
 // Minimum waves per SIMD requested for the 64x64-tile bf16 GEMM / conv kernels (second __launch_bounds__ argument):
 // tuning knob (make DEFS=-DDETR_GEMM64_MINW=6).  Measured: 6 (<= 64 VGPRs, 8 workgroups / CU instead of 5) buys the
@@ -95,6 +96,7 @@ enum TuneKey {
     T_ATTN_SPLIT,
     T_GEMM_K64,
     T_EPI_WIDE,
+    T_SLAB_TS,           // 2: split-K slabs stay row-major (A/B of the tile-ordered form, round 4)
     T_COUNT
 };
 int tune(TuneKey k);

@@ -27,6 +27,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_ATTN_SPLIT",
     "DETR_HIP_GEMM_K64",
     "DETR_HIP_EPI_WIDE",
+    "DETR_HIP_SLAB_TS",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {
@@ -94,6 +95,7 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_reduce_desc, rows)); DETR_PUT(DETR_OFF(detr_reduce_desc, cols)); DETR_PUT(DETR_OFF(detr_reduce_desc, C));
         DETR_PUT(DETR_OFF(detr_reduce_desc, ldc)); DETR_PUT(DETR_OFF(detr_reduce_desc, alpha)); DETR_PUT(DETR_OFF(detr_reduce_desc, scale));
         DETR_PUT(DETR_OFF(detr_reduce_desc, rs_ws)); DETR_PUT(DETR_OFF(detr_reduce_desc, rs_out)); DETR_PUT(DETR_OFF(detr_reduce_desc, rs_alpha));
+        DETR_PUT(DETR_OFF(detr_reduce_desc, ts_bm)); DETR_PUT(DETR_OFF(detr_reduce_desc, ts_bn)); DETR_PUT(DETR_OFF(detr_reduce_desc, ts_tiles_n));
         break;
     case 1:   // detr_gemm_desc
         DETR_PUT((int32_t)sizeof(detr_gemm_desc));

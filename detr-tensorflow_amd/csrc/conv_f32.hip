@@ -212,6 +212,7 @@ struct ConvWgradArgs {
     int tiles_m, tiles_n;
     EpiArgs e;
     int s16;                 // x and dy are bf16 in memory (bf16 activation storage; bf16 compute only)
+    int slab_ts;             // partial slabs in tile order (gemm_core.h: store_slab_ts; tile = (tap * tiles_m + tm) * tiles_n + tn)
 };
 
 template <int BM>
@@ -334,6 +335,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (WGM == 2 && WGN == 2) {
+        if (a.slab_ts) {
+            float *slab = a.dw + (long long)blockIdx.z * a.part_stride + ((long long)(tap * a.tiles_m + tm) * a.tiles_n + tn) * (BM * BN);
+            store_slab_ts<BM, BN, WGM, WGN>(acc, slab, wave, lane);
+            return;
+        }
     }
     float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
     epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
@@ -615,6 +623,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
         __syncthreads();
         cur ^= 1;
     }
+    if constexpr (WGM == 2 && WGN == 2) {
+        if (a.slab_ts) {
+            float *slab = a.dw + (long long)blockIdx.z * a.part_stride + ((long long)(tap * a.tiles_m + tm) * a.tiles_n + tn) * (BM * BN);
+            store_slab_ts<BM, BN, WGM, WGN>(acc, slab, wave, lane);
+            return;
+        }
+    }
     float *dw = a.dw + (long long)tap * a.Ci * a.Co + (long long)blockIdx.z * a.part_stride;
     epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), dw, a.Co, a.Ci, a.Co, ci0, co0, wm, wn, lane, wave, a.e);
 }
@@ -787,6 +802,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             iter(u + 1, 1, rx1, rd1);
         }
         if (u < u_end) iter(u, 0, rx0, rd0);
+    }
+    if (a.slab_ts) {       // nine 64 x 64 tiles in accumulator-register order: 36 lane-linear 16-byte stores per lane, no LDS
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f32x16 one[1][1];
+            one[0][0] = acc[t];
+            float *slab = a.dw + (long long)blockIdx.z * a.part_stride + ((long long)(t * a.tiles_m + tm) * a.tiles_n + tn) * (64 * 64);
+            store_slab_ts<64, 64, 2, 2>(one, slab, wave, lane);
+        }
+        return;
     }
     __syncthreads();
 #pragma unroll
@@ -1148,6 +1173,10 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     float *dw_final = a.dw;
     const EpiArgs final_e = a.e;
     a.part_stride = 0;
+    a.slab_ts = 0;
+    // whole tiles (channel counts are multiples of the tile): the tile-ordered slab has exactly the row-major slab's size
+    const bool ts = partial && WGM == 2 && WGN == 2 && a.Ci % BM == 0 && a.Co % BN == 0 && (!final_e.scale || aligned16(final_e.scale)) &&
+                    tune(T_SLAB_TS) != 2;
     if (partial) {
         a.dw = ws;
         a.part_stride = part;
@@ -1155,6 +1184,7 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
         a.e.scale = nullptr;
         a.e.atomic = 0;
         a.e.vec = 1;
+        a.slab_ts = ts ? 1 : 0;
     } else if (split == 1) {
         a.e.atomic = 1;   // accumulate onto dw
     }
@@ -1162,7 +1192,8 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     if (bf16c && a.s16) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
-    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
+    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s, nullptr, nullptr, 1.0f,
+                                      ts ? BM : 0, ts ? BN : 0, a.tiles_n);
 }
 
 // fused-tap bf16 weight gradient (stride 1, pad 1, channel counts % 64 == 0)
@@ -1180,6 +1211,8 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
     float *dw_final = a.dw;
     const EpiArgs final_e = a.e;
     a.part_stride = 0;
+    a.slab_ts = 0;
+    const bool ts = partial && (!final_e.scale || aligned16(final_e.scale)) && tune(T_SLAB_TS) != 2;
     if (partial) {
         a.dw = ws;
         a.part_stride = part;
@@ -1187,13 +1220,15 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
         a.e.scale = nullptr;
         a.e.atomic = 0;
         a.e.vec = 1;
+        a.slab_ts = ts ? 1 : 0;
     } else {
         a.e.atomic = 1;   // accumulate onto dw (split == 1, or the atomic fallback without a workspace)
     }
     dim3 grid((unsigned)tiles, 1, (unsigned)split), block(GEMM_THREADS);
     if (a.s16) hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<true>, grid, block, 0, s, a, ups, chunks);
     else hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<false>, grid, block, 0, s, a, ups, chunks);
-    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s);
+    if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s, nullptr, nullptr, 1.0f,
+                                      ts ? 64 : 0, ts ? 64 : 0, a.tiles_n);
 }
 
 }  // namespace detr

@@ -429,6 +429,42 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile-ordered split-K slabs (round 4).  A split's partial tile is private scratch that only the reduce launch ever reads, so
+// it does not have to be row-major: every lane stores its accumulator quads as they sit in the MFMA C/D registers -- float4
+// unit ((wave * TM + mi) * TN + ni) * 4 + q of the tile, lane-linear -- 16-byte stores that cover 1 KB per wave instruction, no
+// LDS transposition, no barrier, no address arithmetic per element.  (Ablation, profiles/r02_ablation_tile_kernels.txt: with
+// the K loop compiled out the row-major slab epilogue alone was 32 of the 58 us of M256 N1024 K33600.)  The reduce kernel
+// (gemm_f32.hip: splitk_reduce_body) walks the slabs in the same unit order and un-permutes on its way to C: unit u of tile
+// (tm, tn) holds rows tm*BM + wm*WTM + mi*32 + 8*q + 4*(lane >> 5) + {0,1,2,3} of column tn*BN + wn*WTN + ni*32 + (lane & 31).
+// The slab of one split is tiles_m * tiles_n * BM * BN floats (edge tiles padded).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void store_slab_ts(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                              float *slab_tile, int wave, int lane) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    float4 *p = reinterpret_cast<float4 *>(slab_tile) + (size_t)wave * (T::TM * T::TN * 256) + lane;
+#pragma unroll
+    for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                p[((mi * T::TN + ni) * 4 + q) * 64] = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
+                                                                  acc[mi][ni][4 * q + 3]);
+}
+// unit -> (row, column) inside a BM x BN tile of a 2 x 2 wave grid (the only grid the split-K kernels use)
+__host__ __device__ __forceinline__ void slab_ts_unit(int u, int BM, int BN, int &row0, int &col) {
+    const int TN = BN >> 6, TM = BM >> 6;
+    const int lane = u & 63, q = (u >> 6) & 3;
+    int rest = u >> 8;
+    const int ni = rest % TN; rest /= TN;
+    const int mi = rest % TM;
+    const int w = rest / TM;
+    row0 = (w >> 1) * (BM >> 1) + mi * 32 + 8 * q + 4 * (lane >> 5);
+    col = (w & 1) * (BN >> 1) + ni * 32 + (lane & 31);
+}
+
 // ALLOW_WIDE = false: callers whose output can never take the all-bf16 form (weight gradients: fp32, accumulated) keep the
 // 4-column code alone -- the second form would only cost them registers and code
 template <int BM, int BN, int WGM, int WGN, bool ALLOW_WIDE = true>

@@ -26,6 +26,7 @@ struct GemmArgs {
     int b16;                     // B operand is bf16 in memory (bf16 compute only)
     int a16;                     // A operand is bf16 in memory (bf16 activation storage)
     int split_xcd;               // split-K: remap the whole (split, tile) space over the XCDs (0 = per-split tile remap only, A/B hook)
+    int slab_ts;                 // split-K partials as tile-ordered slabs (gemm_core.h: store_slab_ts); part_stride counts padded tiles
 };
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
@@ -183,6 +184,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, c
         cur ^= 1;
     }
     if (do_rs) rowsum_finish<BM, 1>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, 0);
+    if constexpr (WGM == 2 && WGN == 2) {
+        if (g.slab_ts) {             // (kernel argument: uniform over the grid)
+            store_slab_ts<BM, BN, WGM, WGN>(acc, C + (long long)id * (BM * BN), wave, lane);
+            return;
+        }
+    }
     epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -316,6 +323,12 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     }
     __syncthreads();
     if (do_rs) rowsum_finish<BM, NRS>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, (!AK && A16) ? 2 : 1);
+    if constexpr (WGM == 2 && WGN == 2) {
+        if (g.slab_ts) {             // split-K partial: the accumulator registers as they are, 16-byte lane-linear stores
+            store_slab_ts<BM, BN, WGM, WGN>(acc, C + (long long)id * (BM * BN), wave, lane);
+            return;
+        }
+    }
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
@@ -345,6 +358,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MI
 struct ReduceOne {
     const float *ws; int splits; long long part_stride; int rows, cols; float *C; long long ldc;
     float alpha; const float *scale; int vec; const float *rs_ws; float *rs_out; float rs_alpha; int nblocks;
+    int ts_bm, ts_bn, ts_tn;     // tile-ordered slabs (0: row-major)
 };
 struct ReduceGroupArgs { ReduceOne r[GEMM_MAX_GROUP]; };
 
@@ -353,7 +367,8 @@ __device__ __forceinline__ void splitk_reduce_body(const float *__restrict__ ws,
                                                    int rows, int cols, float *__restrict__ C, long long ldc,
                                                    float alpha, const float *__restrict__ scale, int vec,
                                                    const float *__restrict__ rs_ws, float *__restrict__ rs_out,
-                                                   float rs_alpha, const int bid, const int nbid) {
+                                                   float rs_alpha, const int bid, const int nbid,
+                                                   const int ts_bm = 0, const int ts_bn = 0, const int ts_tn = 1) {
     constexpr int OUT = 256 / G;
     __shared__ float4 red[G][OUT];
     if (rs_ws) {     // fused bias gradient: partial row sums [splits][rows] -> rs_out[rows] (fixed summation order)
@@ -364,7 +379,49 @@ __device__ __forceinline__ void splitk_reduce_body(const float *__restrict__ ws,
         }
     }
     const int lo = threadIdx.x % OUT, grp = threadIdx.x / OUT;
-    if (vec) {
+    if (ts_bm > 0) {
+        // tile-ordered slabs: unit i (a float4 = 4 consecutive ROWS of one column, gemm_core.h: slab_ts_unit) is summed over the
+        // splits in the same order as a row-major element would be (k = grp, grp + G, ..., then the G groups in order), so the
+        // result is bit-identical to the row-major path; reads are lane-linear, the four stores of a wave cover 128-byte runs
+        const int upt = (ts_bm * ts_bn) >> 2;
+        const long long total = part_stride >> 2;
+        for (long long base = (long long)bid * OUT; base < total; base += (long long)nbid * OUT) {
+            const long long i = base + lo;
+            const bool valid = i < total;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const float *p = ws + i * 4;
+#pragma unroll 4
+                for (int k = grp; k < splits; k += G) {
+                    const float4 v = *reinterpret_cast<const float4 *>(p + k * part_stride);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+            red[grp][lo] = s;
+            __syncthreads();
+            if (grp == 0 && valid) {
+#pragma unroll
+                for (int q = 1; q < G; ++q) {
+                    const float4 t = red[q][lo];
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                const int tile = (int)(i / upt), u = (int)(i - (long long)tile * upt);
+                int row0, col;
+                slab_ts_unit(u, ts_bm, ts_bn, row0, col);
+                row0 += (tile / ts_tn) * ts_bm;
+                col += (tile % ts_tn) * ts_bn;
+                if (col < cols) {
+                    const float sc = scale ? scale[col] : 1.0f;
+                    const float sv[4] = {s.x, s.y, s.z, s.w};
+                    float *dst = C + (long long)row0 * ldc + col;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (row0 + j < rows) dst[(long long)j * ldc] += alpha * sc * sv[j];
+                }
+            }
+            __syncthreads();
+        }
+    } else if (vec) {
         const int c4n = cols >> 2;
         const long long total = (long long)rows * c4n;
         for (long long base = (long long)bid * OUT; base < total; base += (long long)nbid * OUT) {
@@ -415,16 +472,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
                                                             int rows, int cols, float *__restrict__ C, long long ldc,
                                                             float alpha, const float *__restrict__ scale, int vec,
                                                             const float *__restrict__ rs_ws, float *__restrict__ rs_out,
-                                                            float rs_alpha) {
+                                                            float rs_alpha, int ts_bm, int ts_bn, int ts_tn) {
     splitk_reduce_body<G>(ws, splits, part_stride, rows, cols, C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha, blockIdx.x,
-                          gridDim.x);
+                          gridDim.x, ts_bm, ts_bn, ts_tn);
 }
 template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroupArgs R) {
     const ReduceOne &r = R.r[blockIdx.y];
     if ((int)blockIdx.x >= r.nblocks) return;
     splitk_reduce_body<G>(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, r.vec, r.rs_ws, r.rs_out,
-                          r.rs_alpha, blockIdx.x, r.nblocks);
+                          r.rs_alpha, blockIdx.x, r.nblocks, r.ts_bm, r.ts_bn, r.ts_tn);
 }
 
 constexpr int REDUCE_MANY = 16;
@@ -434,15 +491,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceManyArgs 
     const ReduceOne &r = R.r[blockIdx.y];
     if ((int)blockIdx.x >= r.nblocks) return;
     splitk_reduce_body<G>(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, r.vec, r.rs_ws, r.rs_out,
-                          r.rs_alpha, blockIdx.x, r.nblocks);
+                          r.rs_alpha, blockIdx.x, r.nblocks, r.ts_bm, r.ts_bn, r.ts_tn);
 }
 
+// `small` (16 instead of 4 split groups per block) is a function of (rows, cols, splits) alone -- the summation order, and with it
+// the bits of the result, must not depend on the slab layout
 static void reduce_plan(ReduceOne &r, bool &small) {
     r.vec = (r.cols % 4 == 0) && (r.ldc % 4 == 0) && (r.part_stride % 4 == 0) && aligned16(r.ws) && aligned16(r.C) &&
             (!r.scale || aligned16(r.scale));
-    const long long total = (long long)r.rows * (r.vec ? r.cols / 4 : r.cols);
-    small = r.vec && total <= 65536 && r.splits >= 8;
-    long long grid = r.vec ? (total + (small ? 15 : 63)) / (small ? 16 : 64) : (total + 255) / 256;
+    const bool ts = r.ts_bm > 0;
+    const bool vec_like = r.vec || ts;
+    const long long total = (long long)r.rows * (vec_like ? r.cols / 4 : r.cols);
+    small = vec_like && total <= 65536 && r.splits >= 8;
+    const long long units = ts ? r.part_stride / 4 : total;
+    long long grid = vec_like ? (units + (small ? 15 : 63)) / (small ? 16 : 64) : (units + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
     r.nblocks = (int)grid;
@@ -450,20 +512,19 @@ static void reduce_plan(ReduceOne &r, bool &small) {
 
 void launch_splitk_reduce(const float *ws, int splits, long long part_stride, int rows, int cols, float *C, long long ldc,
                           float alpha, const float *scale, hipStream_t stream, const float *rs_ws, float *rs_out,
-                          float rs_alpha) {
-    const int vec = (cols % 4 == 0) && (ldc % 4 == 0) && (part_stride % 4 == 0) && aligned16(ws) && aligned16(C) &&
-                    (!scale || aligned16(scale));
-    const long long total = (long long)rows * (vec ? cols / 4 : cols);
-    const bool small = vec && total <= 65536 && splits >= 8;
-    long long grid = vec ? (total + (small ? 15 : 63)) / (small ? 16 : 64) : (total + 255) / 256;
-    if (grid > 8192) grid = 8192;
-    if (grid < 1) grid = 1;
+                          float rs_alpha, int ts_bm, int ts_bn, int ts_tiles_n) {
+    ReduceOne r;
+    r.ws = ws; r.splits = splits; r.part_stride = part_stride; r.rows = rows; r.cols = cols; r.C = C; r.ldc = ldc;
+    r.alpha = alpha; r.scale = scale; r.rs_ws = rs_ws; r.rs_out = rs_out; r.rs_alpha = rs_alpha;
+    r.ts_bm = ts_bm; r.ts_bn = ts_bn; r.ts_tn = ts_tiles_n > 0 ? ts_tiles_n : 1;
+    bool small;
+    reduce_plan(r, small);
     if (small)
-        hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
-                           C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
+        hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((unsigned)r.nblocks), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
+                           C, ldc, alpha, scale, r.vec, rs_ws, rs_out, rs_alpha, r.ts_bm, r.ts_bn, r.ts_tn);
     else
-        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
-                           C, ldc, alpha, scale, vec, rs_ws, rs_out, rs_alpha);
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)r.nblocks), dim3(256), 0, stream, ws, splits, part_stride, rows, cols,
+                           C, ldc, alpha, scale, r.vec, rs_ws, rs_out, rs_alpha, r.ts_bm, r.ts_bn, r.ts_tn);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -522,10 +583,62 @@ struct GemmPlan {
     int batch, split;
     bool ak, bk, bf16c, partial, deep;
     int tile;                 // 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64
-    long long part;
+    long long part;           // floats per split slab (row-major: M*N; tile-ordered: the padded tile grid)
+    int ts_bm, ts_bn, ts_tn;  // tile-ordered slabs (0: row-major)
     EpiArgs final_e;
     const detr_gemm_desc *d;
 };
+
+// Tile shape of a GEMM: 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64.  Shared by the
+// launch path and by the scratch-size query (the tile-ordered split-K slabs are padded to whole tiles).
+static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
+    const bool bf16c = d->compute == 1;
+    const int force = tune(T_GEMM_TILE);     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
+    int tile = 0;
+    if (bf16c) {
+        // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
+        // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (3 waves/SIMD, 4x the operand
+        // reuse) pays only for the long split-K weight gradients (K >= 16384, N >= 128) and for unsplit K >= 1024 GEMMs
+        // that still fill the chip with 128x128 tiles (M33600 N256 K1024: 54 vs 60 us)
+        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
+        // round 3, cold-cache sweeps (scripts/micro_wgrad.py, micro_gemm.py --cold; profiles/r03_micro_*): the layer4 weight
+        // gradients (M, N >= 512, K = 8400) gain 15-25 % on 128x128 tiles (512x2048: 64 -> 53 us, 1024x2048: 109 -> 80), and so do
+        // the wide K = 512 GEMMs of layer3's first block (M33600 N1024: 100 -> 89 us, with residual + mask 163 -> 151)
+        const bool big_split = (d->N >= 128 && d->K >= 16384) || (d->M >= 512 && d->N >= 512 && d->K >= 4096);
+        const bool big_plain = (d->K >= 1024 && t128 >= 512) || (d->K >= 512 && d->N >= 512 && t128 >= 1024);
+        const bool small = (split > 1) ? !big_split : !big_plain;
+        if (force == 2) tile = 2;
+        else if (force == 5) tile = 4;
+        else if (force == 3 || (force == 0 && small)) tile = 0;
+        else if (force == 0 && split > 1 && d->M <= 64) tile = 4;     // 64 output rows: half of a 128-row tile would be padding (M64 N256 K534400: 84 -> 74 us)
+        else tile = 1;
+    } else if (force == 1) tile = 1;
+    else if (force == 2) tile = 2;
+    else if (force == 3) tile = 0;
+    else if (force == 4) tile = 3;
+    else if (force == 5) tile = 4;
+    else if (force == 6) tile = 5;
+    else if (d->N <= 32) tile = 3;
+    else tile = 0;      // measured (profiles/tune_r1.txt): 64x64 (8 waves/SIMD) beats 128x64 by 2-10 % and 128x128 by 15-50 % in fp32
+    return tile;
+}
+// BM x BN of a tile id; ts_ok: the kernel runs a 2 x 2 wave grid (store_slab_ts / slab_ts_unit)
+static void gemm_tile_dims(bool bf16c, int tile, int &bm, int &bn, bool &ts_ok) {
+    ts_ok = true;
+    if (tile == 1) { bm = 128; bn = 128; }
+    else if (tile == 2) { bm = 128; bn = 64; }
+    else if (tile == 4 && bf16c) { bm = 64; bn = 128; }
+    else if (tile == 0) { bm = 64; bn = 64; }
+    else { bm = bn = 0; ts_ok = false; }          // fp32 128x32 / 64x256 / 256x64: 4x1 / 1x4 wave grids keep row-major slabs
+}
+// Split-K slab layout: tile-ordered when the reduce launch can keep its 16-byte form (the same conditions as its row-major
+// `vec` path: the summation order -- the bits of the result -- must not depend on the layout).  DETR_HIP_SLAB_TS=2: row-major.
+static bool gemm_slab_ts(const detr_gemm_desc *d, int split, int batch, int tile, int &bm, int &bn) {
+    bool ok;
+    gemm_tile_dims(d->compute == 1, tile, bm, bn, ok);
+    return ok && split > 1 && batch == 1 && d->N % 4 == 0 && d->ldc % 4 == 0 && aligned16(d->C) && (!d->scale || aligned16(d->scale)) &&
+           tune(T_SLAB_TS) != 2;
+}
 
 // split count a GEMM really runs with: no empty splits (recomputed from the K tiles each split gets)
 static int gemm_effective_split(const detr_gemm_desc *d) {
@@ -543,7 +656,11 @@ extern "C" int64_t detr_hip_workspace_bytes_gemm(const detr_gemm_desc *d) {
     const int batch = d->batch > 0 ? d->batch : 1;
     const int split = gemm_effective_split(d);
     if (split <= 1 || batch != 1) return 0;          // (batched split-K accumulates with atomics: no scratch)
-    return (int64_t)split * ((int64_t)d->M * d->N + (d->rowsum_a ? d->M : 0)) * 4;
+    int bm, bn;
+    int64_t part = (int64_t)d->M * d->N;
+    if (gemm_slab_ts(d, split, batch, gemm_pick_tile(d, split, batch), bm, bn))      // tile-ordered slabs: whole tiles
+        part = (int64_t)cdiv(d->M, bm) * cdiv(d->N, bn) * bm * bn;
+    return (int64_t)split * (part + (d->rowsum_a ? d->M : 0)) * 4;
 }
 
 static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
@@ -621,9 +738,19 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
                  "gemm: an M-contiguous bf16 A operand needs lda %% 8 == 0, M %% 8 == 0 and a 16-byte aligned base (16-byte requests)");
     DETR_REQUIRE(!(bf16c && d->b_dtype == 1 && !bk) || (d->ldb % 8 == 0 && d->N % 8 == 0 && aligned16(d->B)),
                  "gemm: an N-contiguous bf16 B operand needs ldb %% 8 == 0, N %% 8 == 0 and a 16-byte aligned base (16-byte requests)");
-    const long long part = (long long)d->M * d->N;
-    const bool partial = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace) &&
-                         d->workspace_bytes >= (long long)split * (part + (d->rowsum_a ? d->M : 0)) * 4;
+    const int tile = gemm_pick_tile(d, split, batch);
+    // deterministic split-K: partial slabs in the caller's workspace.  Tile-ordered slabs (whole tiles: a little more scratch than
+    // split*M*N -- detr_hip_workspace_bytes_gemm reports it) when the workspace holds them, row-major slabs when it only holds
+    // the documented split*M*N floats, fp32 atomics without a workspace.
+    long long part = (long long)d->M * d->N;
+    int ts_bm = 0, ts_bn = 0;
+    const long long rs_extra = d->rowsum_a ? d->M : 0;
+    bool ts = gemm_slab_ts(d, split, batch, tile, ts_bm, ts_bn);
+    const long long part_ts = ts ? (long long)cdiv(d->M, ts_bm) * cdiv(d->N, ts_bn) * ts_bm * ts_bn : 0;
+    const bool ws_ok = split > 1 && batch == 1 && d->workspace && aligned16(d->workspace);
+    if (ts && !(ws_ok && d->workspace_bytes >= (long long)split * (part_ts + rs_extra) * 4)) ts = false;
+    if (ts) part = part_ts;
+    const bool partial = ws_ok && d->workspace_bytes >= (long long)split * (part + rs_extra) * 4;
     DETR_REQUIRE(!(d->rowsum_a && split > 1 && !partial), "gemm: rowsum_a with split_k needs the workspace path");
     g.rowsum = d->rowsum_a;
     g.rowsum_alpha = d->rowsum_alpha;
@@ -631,8 +758,10 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     g.b16 = d->b_dtype == 1;
     g.a16 = d->a_dtype == 1;
     g.split_xcd = tune(T_SPLIT_XCD) != 2;
+    g.slab_ts = 0;
+    p.ts_bm = p.ts_bn = 0; p.ts_tn = 1;
     EpiArgs final_e = g.e;
-    if (partial) {      // deterministic split-K: plain stores of the partial tiles, reduced by a second launch
+    if (partial) {      // plain stores of the partial tiles, reduced by a second launch
         g.C = d->workspace;
         g.ldc = d->N;
         g.part_stride = part;
@@ -640,39 +769,15 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
         g.e.scale = nullptr;
         g.e.atomic = 0;
         g.e.vec = (d->N % 4 == 0);
+        if (ts) {
+            g.slab_ts = 1;
+            p.ts_bm = ts_bm; p.ts_bn = ts_bn; p.ts_tn = cdiv(d->N, ts_bn);
+        }
         if (d->rowsum_a) {       // partial row sums go behind the tile slabs
             g.rowsum = d->workspace + (long long)split * part;
             g.rowsum_partial = 1;
         }
     }
-    // tile selection
-    const int force = tune(T_GEMM_TILE);     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
-    int tile = 0;
-    if (bf16c) {
-        // measured (profiles/tune_bf16_r1c.txt, buffer-descriptor loaders + transpose-read LDS images): the 64x64 tile
-        // (7-8 waves/SIMD) wins every non-split shape and the short reductions; 128x128 (3 waves/SIMD, 4x the operand
-        // reuse) pays only for the long split-K weight gradients (K >= 16384, N >= 128) and for unsplit K >= 1024 GEMMs
-        // that still fill the chip with 128x128 tiles (M33600 N256 K1024: 54 vs 60 us)
-        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch;
-        // round 3, cold-cache sweeps (scripts/micro_wgrad.py, micro_gemm.py --cold; profiles/r03_micro_*): the layer4 weight
-        // gradients (M, N >= 512, K = 8400) gain 15-25 % on 128x128 tiles (512x2048: 64 -> 53 us, 1024x2048: 109 -> 80), and so do
-        // the wide K = 512 GEMMs of layer3's first block (M33600 N1024: 100 -> 89 us, with residual + mask 163 -> 151)
-        const bool big_split = (d->N >= 128 && d->K >= 16384) || (d->M >= 512 && d->N >= 512 && d->K >= 4096);
-        const bool big_plain = (d->K >= 1024 && t128 >= 512) || (d->K >= 512 && d->N >= 512 && t128 >= 1024);
-        const bool small = (split > 1) ? !big_split : !big_plain;
-        if (force == 2) tile = 2;
-        else if (force == 5) tile = 4;
-        else if (force == 3 || (force == 0 && small)) tile = 0;
-        else if (force == 0 && split > 1 && d->M <= 64) tile = 4;     // 64 output rows: half of a 128-row tile would be padding (M64 N256 K534400: 84 -> 74 us)
-        else tile = 1;
-    } else if (force == 1) tile = 1;
-    else if (force == 2) tile = 2;
-    else if (force == 3) tile = 0;
-    else if (force == 4) tile = 3;
-    else if (force == 5) tile = 4;
-    else if (force == 6) tile = 5;
-    else if (d->N <= 32) tile = 3;
-    else tile = 0;      // measured (profiles/tune_r1.txt): 64x64 (8 waves/SIMD) beats 128x64 by 2-10 % and 128x128 by 15-50 % in fp32
     // 64-deep K tiles (all-bf16 operands, tiles 0 / 1): DETR_HIP_GEMM_K64 = 0 rule below, 1 every eligible GEMM, 2 never.
     // Measured (scripts/micro_gemm.py, profiles/r03_micro_gemm_k64.txt): 64x64 tiles gain 10-23 % from K >= 512 per split on (M8400
     // N512 K2048: 47.0 -> 39.2 us, M800 N256 K2048 cold: 28.0 -> 21.6); UNSPLIT 128x128 tiles lose 20-35 % (72 KB of LDS: two
@@ -754,12 +859,14 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         o->C = d->C; o->ldc = d->ldc; o->alpha = p.final_e.alpha; o->scale = p.final_e.scale;
         o->rs_ws = d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr;
         o->rs_out = d->rowsum_a; o->rs_alpha = d->rowsum_alpha;
+        o->ts_bm = p.ts_bm; o->ts_bn = p.ts_bn; o->ts_tiles_n = p.ts_tn;
         return 0;
     }
     if (d->defer_out) d->defer_out->splits = 0;
     if (p.partial) {
         launch_splitk_reduce(d->workspace, p.split, p.part, d->M, d->N, d->C, d->ldc, p.final_e.alpha, p.final_e.scale, s,
-                             d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr, d->rowsum_a, d->rowsum_alpha);
+                             d->rowsum_a ? d->workspace + (long long)p.split * p.part : nullptr, d->rowsum_a, d->rowsum_alpha,
+                             p.ts_bm, p.ts_bn, p.ts_tn);
         DETR_LAUNCH_CHECK("gemm split-k reduce");
     }
     return 0;
@@ -847,6 +954,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
                     o->C = d->C; o->ldc = d->ldc; o->alpha = p[i].final_e.alpha; o->scale = p[i].final_e.scale;
                     o->rs_ws = d->rowsum_a ? d->workspace + (long long)p[i].split * p[i].part : nullptr;
                     o->rs_out = d->rowsum_a; o->rs_alpha = d->rowsum_alpha;
+                    o->ts_bm = p[i].ts_bm; o->ts_bn = p[i].ts_bn; o->ts_tiles_n = p[i].ts_tn;
                 }
                 continue;
             }
@@ -856,6 +964,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
             r.C = d->C; r.ldc = d->ldc; r.alpha = p[i].final_e.alpha; r.scale = p[i].final_e.scale;
             r.rs_ws = d->rowsum_a ? d->workspace + (long long)p[i].split * p[i].part : nullptr;
             r.rs_out = d->rowsum_a; r.rs_alpha = d->rowsum_alpha;
+            r.ts_bm = p[i].ts_bm; r.ts_bn = p[i].ts_bn; r.ts_tn = p[i].ts_tn;
             bool small;
             reduce_plan(r, small);
             all_small = all_small && small;
@@ -872,7 +981,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
             for (int i = 0; i < nr; ++i) {
                 const ReduceOne &r = R.r[i];
                 launch_splitk_reduce(r.ws, r.splits, r.part_stride, r.rows, r.cols, r.C, r.ldc, r.alpha, r.scale, s, r.rs_ws, r.rs_out,
-                                     r.rs_alpha);
+                                     r.rs_alpha, r.ts_bm, r.ts_bn, r.ts_tn);
             }
             DETR_LAUNCH_CHECK("gemm group split-k reduce (sequential)");
         }
@@ -906,6 +1015,10 @@ extern "C" int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_
             ReduceOne r;
             r.ws = d.ws; r.splits = d.splits; r.part_stride = d.part_stride; r.rows = d.rows; r.cols = d.cols; r.C = d.C; r.ldc = d.ldc;
             r.alpha = d.alpha; r.scale = d.scale; r.rs_ws = d.rs_ws; r.rs_out = d.rs_out; r.rs_alpha = d.rs_alpha;
+            r.ts_bm = d.ts_bm; r.ts_bn = d.ts_bn; r.ts_tn = d.ts_tiles_n > 0 ? d.ts_tiles_n : 1;
+            DETR_REQUIRE(d.ts_bm == 0 || ((d.ts_bm == 64 || d.ts_bm == 128) && (d.ts_bn == 64 || d.ts_bn == 128) && d.ts_tiles_n > 0 &&
+                                          d.part_stride % ((long long)d.ts_bm * d.ts_bn) == 0),
+                         "splitk_reduce_many: entry %d has a malformed tile-ordered slab description", i);
             bool small;
             reduce_plan(r, small);
             if (small != (pass == 0)) continue;

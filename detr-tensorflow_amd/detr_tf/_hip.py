@@ -19,7 +19,8 @@ f32p = c_void_p
 class ReduceDesc(Structure):
     _fields_ = [("ws", c_void_p), ("splits", c_int32), ("part_stride", c_int64), ("rows", c_int32), ("cols", c_int32),
                 ("C", c_void_p), ("ldc", c_int64), ("alpha", c_float), ("scale", c_void_p),
-                ("rs_ws", c_void_p), ("rs_out", c_void_p), ("rs_alpha", c_float)]
+                ("rs_ws", c_void_p), ("rs_out", c_void_p), ("rs_alpha", c_float),
+                ("ts_bm", c_int32), ("ts_bn", c_int32), ("ts_tiles_n", c_int32)]       # ABI 5: tile-ordered slabs
 
 
 class GemmDesc(Structure):
@@ -164,7 +165,7 @@ _SIGNATURES_I64 = {
     "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
-ABI_VERSION = 4
+ABI_VERSION = 5
 # order of detr_hip_struct_layout's `which`
 LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 
@@ -418,6 +419,7 @@ def set_tuning(name, value):
     else:
         os.environ[name] = str(value)
     _check(load().detr_hip_reload_tuning(), "detr_hip_reload_tuning")
+    _WS_NEED.clear()        # the cached scratch sizes depend on the tuning variables (tile / split plans, slab layout)
 
 
 def _stream():
@@ -468,10 +470,16 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     d.dropout_step = ptr(dropout_step)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
     d.rowsum_a, d.rowsum_alpha = ptr(rowsum_a), rowsum_alpha
+    # scratch of the deterministic split-K path: what the LIBRARY asks for (detr_hip_workspace_bytes_gemm -- the tile-ordered
+    # slabs of round 4 are padded to whole tiles, so split_k * M * N floats is no longer the whole story), per-shape cached
+    ws_need = 0
+    if split_k > 1 and batch == 1 and workspace is None and (WORKSPACE is not None or DEFER is not None):
+        ws_need = (_ws_query("detr_hip_workspace_bytes_gemm",
+                             ("gemm", M, N, K, int(a_kcontig), int(b_kcontig), split_k, d.compute, d.a_dtype, d.b_dtype, ldc % 4,
+                              (d.C or 0) % 16, rowsum_a is not None, scale is not None and (d.scale or 0) % 16), byref(d)) + 255) & ~255
     if workspace is None and WORKSPACE is not None and split_k > 1 and batch == 1 and DEFER is None:
-        # immediate deterministic split-K: the shared scratch must hold every member's slabs (upper bound of
-        # detr_hip_workspace_bytes_gemm: the library may run fewer, never more, splits than requested)
-        need_workspace(split_k * (M * N + (M if rowsum_a is not None else 0)) * 4 * (ws_slice[1] if ws_slice else 1))
+        # immediate deterministic split-K: the shared scratch must hold every member's (256-byte aligned) share
+        need_workspace(ws_need * (ws_slice[1] if ws_slice else 1))
     ws = workspace if workspace is not None else WORKSPACE
     if ws is None:
         d.workspace, d.workspace_bytes = None, 0
@@ -483,7 +491,7 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
         d.workspace, d.workspace_bytes = ws.data_ptr() + idx * share, share
     rd = None
     if DEFER is not None and split_k > 1 and batch == 1 and workspace is None:
-        slab = _defer_slab(split_k * (M * N + M) * 4)
+        slab = _defer_slab(ws_need)
         if slab is not None:
             rd = ReduceDesc()
             d.workspace, d.workspace_bytes = slab

@@ -98,8 +98,23 @@ class DetrModel:
         # (ParamStore.load / load_dict notify the engine: frozen-BN refold + weights-version bump)
         if isinstance(path_or_dict, str) and os.path.exists(path_or_dict + ".index"):
             from .weights import load_tf_checkpoint_params
-            params, _unused = load_tf_checkpoint_params(path_or_dict, self.wanted_shapes())
-            return self.engine.load_params(params)
+            params, unused = load_tf_checkpoint_params(path_or_dict, self.wanted_shapes())
+            missing = self.engine.load_params(params)
+            # `.expect_partial()` of the reference (weights.py:35) covers the fine-tuning heads only: everything else of the
+            # network must come out of the file, or the model silently keeps its random initialisation
+            heads = ("class_embed", "bbox_embed", "cls_layer", "pos_layer")
+            lost = sorted(n for n in (missing or ()) if not n.startswith(heads))
+            self.last_load_report = dict(missing=sorted(missing or ()), unused=sorted(unused))
+            if lost:
+                shown = ", ".join(lost[:8]) + (" ..." if len(lost) > 8 else "")
+                extra = ", ".join(sorted(unused)[:8]) + (" ..." if len(unused) > 8 else "")
+                raise ValueError(f"{path_or_dict}: {len(lost)} network parameters were not found in the checkpoint ({shown}); "
+                                 f"{len(unused)} checkpoint variables matched no parameter by name and shape ({extra})")
+            if unused:
+                import warnings
+                warnings.warn(f"{path_or_dict}: {len(unused)} checkpoint variables were not used: " +
+                              ", ".join(sorted(unused)[:8]) + (" ..." if len(unused) > 8 else ""))
+            return missing
         return self.engine.P.load(self._npz(path_or_dict)) if isinstance(path_or_dict, str) else self.engine.load_params(path_or_dict)
 
     def save_weights(self, path):

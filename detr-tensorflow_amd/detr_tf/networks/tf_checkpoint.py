@@ -334,7 +334,10 @@ def load_tf_checkpoint(prefix):
     renamed = set()
     for name, full, key in parse_object_graph(graph):
         if name == "VARIABLE_VALUE" and key in bundle and full:
-            out[full[:-2] if full.endswith(":0") else full] = bundle[key]
+            var = full[:-2] if full.endswith(":0") else full
+            if var in out:      # non-unique eager names would silently drop a tensor
+                raise ValueError(f"{prefix}: two checkpoint entries carry the variable name {var!r} ({key} and another one)")
+            out[var] = bundle[key]
             renamed.add(key)
     for k, v in bundle.items():
         if k not in renamed and isinstance(v, np.ndarray):

@@ -224,22 +224,32 @@ class ParamStore:
     def load_dict(self, params):
         """params: name -> array, names per SURVEY.md A.6 (BN vectors as <prefix>/{weight,bias,running_mean,running_var})."""
         missing = []
+        # every shape is checked BEFORE the first copy: a mismatch must not leave the store half overwritten (no BN refold, no
+        # weights-version bump -> stale recorded graphs / bf16 shadow / folded kernels)
+        staged = []
         for k in self.shapes:
             if k in params:
                 v = torch.as_tensor(np.asarray(params[k]), dtype=torch.float32)
                 if tuple(v.shape) != tuple(self.shapes[k]):
                     raise ValueError(f"{k}: shape {tuple(v.shape)} != {self.shapes[k]}")
-                self.views[k].copy_(v)
+                staged.append((self.views[k], v))
             else:
                 missing.append(k)
         for p in self.bn:
             for i, leaf in enumerate(self.bn_leaves):
                 if f"{p}/{leaf}" in params:
-                    self.bn_raw[p][i].copy_(torch.as_tensor(np.asarray(params[f"{p}/{leaf}"]), dtype=torch.float32))
+                    v = torch.as_tensor(np.asarray(params[f"{p}/{leaf}"]), dtype=torch.float32)
+                    if v.numel() != self.bn_raw[p][i].numel():
+                        raise ValueError(f"{p}/{leaf}: {v.numel()} values != {self.bn_raw[p][i].numel()}")
+                    staged.append((self.bn_raw[p][i], v.reshape(self.bn_raw[p][i].shape)))
                 else:
                     missing.append(f"{p}/{leaf}")
-        if self.on_change is not None:
-            self.on_change()
+        try:
+            for dst, v in staged:
+                dst.copy_(v)
+        finally:
+            if self.on_change is not None:
+                self.on_change()
         return missing
 
     def state_dict(self):

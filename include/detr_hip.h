@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 4
+#define DETR_HIP_ABI_VERSION 5
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -68,6 +68,11 @@ typedef struct detr_reduce_desc {
     const float *ws; int32_t splits; int64_t part_stride; int32_t rows, cols;
     float *C; int64_t ldc; float alpha; const float *scale;
     const float *rs_ws; float *rs_out; float rs_alpha;
+    /* ABI 5: slab layout.  ts_bm == 0: row-major slabs (ws[s*part_stride + r*cols + c]).  ts_bm > 0: tile-ordered slabs as the
+     * split kernels of this library write them when the workspace holds detr_hip_workspace_bytes_* bytes -- tiles of
+     * ts_bm x ts_bn (ts_tiles_n of them per tile row), each a lane-linear image of the MFMA accumulator registers
+     * (csrc/gemm_core.h: store_slab_ts); part_stride then counts the padded tile grid. */
+    int32_t ts_bm, ts_bn, ts_tiles_n;
 } detr_reduce_desc;
 
 typedef struct {

@@ -178,7 +178,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in detr_hip.h but not exported"
     assert sorted(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.detr_hip_abi_version() == _hip.ABI_VERSION == 4
+    assert lib.detr_hip_abi_version() == _hip.ABI_VERSION == 5
 
 
 def _hip_lib():
@@ -225,6 +225,13 @@ def test_workspace_bytes_queries_and_tuning_reload():
     assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 0
     d.split_k, d.K = 1000, 64 * 32                   # more splits than K tiles: the library runs 64
     assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 64 * 256 * 1024 * 4
+    # round 4: the partial slabs are tile-ordered images of the MFMA accumulators -- whole 64x64 / 128x128 tiles, so a ragged output
+    # needs a little more than split*M*N floats (DETR_HIP_SLAB_TS=2 keeps row-major slabs: the documented minimum)
+    d.M, d.N, d.K, d.split_k = 100, 92, 64 * 32, 8
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 8 * (2 * 2 * 64 * 64) * 4
+    _hip.set_tuning("DETR_HIP_SLAB_TS", 2)
+    assert lib.detr_hip_workspace_bytes_gemm(byref(d)) == 8 * 100 * 92 * 4
+    _hip.set_tuning("DETR_HIP_SLAB_TS", None)
     d.M = 0
     assert lib.detr_hip_workspace_bytes_gemm(byref(d)) < 0
     c = _hip.Conv3x3Desc()
