@@ -165,6 +165,12 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
     peak_tf = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
     bound = "mfma" if tflops / peak_tf >= gbs / PEAK_HBM_GBS else "hbm"
     traffic = traffic_src = None
+    # (the newest committed PMC summary of this precision: profiles/rNN_traffic[_bf16].json)
+    for rnd in ("r04", "r03"):
+        cand = traffic_file.replace("r03", rnd)
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            traffic_file = cand
+            break
     tpath = os.path.join(ROOT, "profiles", traffic_file)
     if os.path.exists(tpath):
         with open(tpath) as f:          # measured offline by separate rocprofv3 --pmc passes
@@ -186,10 +192,39 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
     return r
 
 
+def metric_name(args):
+    """BASELINE.json's metric string for the default workload; another --backbone / --height / --width / --batch / --queries names
+    itself (the C4 / C5 lines printed the R50 800x1333 bs=8 string)."""
+    what = "training step" if args.mode == "train" else "forward+set-loss"
+    net = "R101" if args.backbone == "resnet101" else "R50"
+    q = "" if args.queries == 100 else f" {args.queries} queries"
+    return f"images/sec {what}, DETR-{net} {args.height}x{args.width} bs={args.batch}/GPU{q}"
+
+
+def attention_valu_bound(B, L, heads=8, p_drop=0.1):
+    """VALU-issue floor of the encoder self-attention FORWARD at d_head = 32 (north_star's 80 % MFMA target): per score
+    the softmax + dropout costs a fixed number of VALU instructions whatever the MFMA does.  Counted from the ISA of
+    attn_fwd_bf16_kernel's key loop (scripts/isa/sched.py): `valu_per_tile` VALU instructions per 32x32 score tile and wave
+    (16 scores per lane: exp2, max3 / add trees, the pair-hash dropout flags, bf16 packing; round 4: ~295 of the ~360 instructions of a
+    tile), 2 issue cycles each on a SIMD-32
+    (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cyc), 1024 SIMDs at 2.4 GHz; the MFMA floor of the same tile is 4 x
+    v_mfma_f32_32x32x16_bf16 = 128 cycles -- with ~295 x 2 = 590 VALU cycles per tile the kernel is VALU-bound by construction:
+    the MFMA pipe cannot be busier than 128 / 590 = 22 % even if the VALU work of one wave hides entirely under another wave's MFMAs
+    (the north_star's 80 % is out of reach at d_head = 32 with softmax + dropout in the loop)."""
+    valu_per_tile, cyc_per_valu, mfma_cyc_per_tile = 295, 2, 4 * 32
+    tiles = B * heads * ((L + 31) // 32) ** 2            # 32-query x 32-key score tiles
+    simds, clk = 1024, 2.4e9
+    valu_ms = tiles * valu_per_tile * cyc_per_valu / simds / clk * 1e3
+    mfma_ms = tiles * mfma_cyc_per_tile / simds / clk * 1e3
+    return {"valu_bound_ms_per_launch": round(valu_ms, 4), "mfma_bound_ms_per_launch": round(mfma_ms, 4),
+            "max_mfma_busy_if_perfect_overlap": round(mfma_ms / max(valu_ms, mfma_ms), 3),
+            "assumptions": f"{valu_per_tile} VALU instr / (32x32 tile, wave) x {cyc_per_valu} cyc, {simds} SIMDs @ 2.4 GHz, B={B} H={heads} L={L}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=800)
@@ -202,7 +237,7 @@ def main():
                     help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 accumulation (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-parity-mode steps of a bf16 run")
-    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C4 / C5 measurements")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
                     help="how a step reaches the GPU: graph = recorded once as hipGraph(s) and replayed (training.GraphedTrainStep), "
@@ -344,6 +379,15 @@ def main():
         value_nodrop = args.batch * 3 / d
         model.engine.dropout_p = args.dropout
     main_tables = family_tables(prof, ev_steps, args.precision) if prof is not None else (None, None)
+    attn_report = None
+    if prof is not None and args.mode == "train":
+        Lf = ((args.height + 31) // 32) * ((args.width + 31) // 32)
+        attn_report = attention_valu_bound(args.batch, Lf, p_drop=args.dropout)
+        for r in prof.by_shape(400):
+            if r["family"] == "attention_fwd" and r["shape"] == f"B{args.batch} H8 T{Lf} S{Lf}":
+                per = r["ms"] / max(r["launches"], 1)
+                attn_report["measured_fwd_ms_per_launch"] = round(per, 4)
+                attn_report["frac_of_valu_bound"] = round(attn_report["valu_bound_ms_per_launch"] / per, 3)
     if prof is not None and args.dump_shapes and rank == 0:
         with open(args.dump_shapes, "w") as f:
             json.dump({"steps": ev_steps, "rows": prof.by_shape(80)}, f, indent=1)
@@ -410,6 +454,39 @@ def main():
                                                          "workload": f"DETR-R50 {prec} eval forward + get_model_inference, ONE 480x640 image (58.3 GFLOP)"}
             m = None
             torch.cuda.empty_cache()
+        # C4 (R101, 1000x1333, batch 8) and C5 (R50, 300 queries, batch 16) train steps in the driver-run line (they only
+        # existed as builder-run files): bf16, eager two-stream launch, 2 warm-up + 5 timed steps each
+        default_workload = (args.backbone == "resnet50" and args.queries == 100 and args.batch == 8 and (args.height, args.width) == (800, 1333))
+        if default_workload and args.precision == "bf16":
+            for key, kw in (("c4_r101_1000x1333_b8_bf16_train", dict(backbone="resnet101", H=1000, W=1333, B=8, Q=100)),
+                            ("c5_r50_300q_b16_bf16_train", dict(backbone="resnet50", H=800, W=1333, B=16, Q=300))):
+                try:
+                    m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision="bf16",
+                                       backbone=kw["backbone"], num_queries=kw["Q"])
+                    o = setup_optimizers(m, cfg)
+                    st = training.GraphedTrainStep(m, o, cfg, launch="eager")
+                    r2 = np.random.default_rng(99)
+                    im = torch.from_numpy(r2.normal(size=(kw["B"], kw["H"], kw["W"], 3)).astype(np.float32)).to(dev)
+                    b2, c2 = make_targets(kw["B"], np.random.default_rng(98))
+                    b2, c2 = torch.from_numpy(b2).to(dev), torch.from_numpy(c2).to(dev)
+                    engine_mod.WGRAD_STREAM = wgrad_stream_default
+                    for i in range(2):
+                        st(im, b2, c2, i)
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(5):
+                        tot = st(im, b2, c2, 2 + i)[1]
+                    torch.cuda.synchronize()
+                    d = (time.perf_counter() - t) / 5
+                    net = "R101" if kw["backbone"] == "resnet101" else "R50"
+                    configs[key] = {"value": round(kw["B"] / d, 2), "unit": "images/sec", "ms_per_step": round(d * 1e3, 3), "steps": 5,
+                                    "loss": round(float(tot), 5), "launch": "eager, 2 HIP streams",
+                                    "metric": f"images/sec training step, DETR-{net} {kw['H']}x{kw['W']} bs={kw['B']}/GPU" + ("" if kw["Q"] == 100 else f" {kw['Q']} queries"),
+                                    "workload": f"DETR-{net} bf16 train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam), {kw['H']}x{kw['W']}, batch {kw['B']}, {kw['Q']} queries, dropout {args.dropout}"}
+                except Exception as e:           # (a report: never fails the headline)
+                    configs[key] = {"error": repr(e)}
+                m = o = st = im = None
+                torch.cuda.empty_cache()
 
     if rank == 0:
         roofline = step_roofline = None
@@ -426,8 +503,7 @@ def main():
                              "frac_of_f32_mfma_peak": round(value / world * STEP_GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
                              if args.precision == "fp32" else None}
         res = {
-            "metric": "images/sec training step, DETR-R50 800x1333 bs=8/GPU" if args.mode == "train"
-                      else "images/sec forward+set-loss, DETR-R50 800x1333 bs=8/GPU",
+            "metric": metric_name(args),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
@@ -444,7 +520,7 @@ def main():
             "fp32": fp32,
             "images_per_sec_fp32_parity_mode": fp32["value"] if fp32 else None,
             "bf16_vs_fp32_loss_rel_dev_first_step": (float(f"{bf16_loss_dev:.3e}") if bf16_loss_dev is not None else None),
-            "roofline": roofline, "step_roofline": step_roofline, "configs": configs,
+            "roofline": roofline, "step_roofline": step_roofline, "attention": attn_report, "configs": configs,
         }
         if dp_timing is not None:      # N > 1: the gradient exchange, from HIP events at each bucket hand-over / completion (rank 0)
             res["comm_ms"] = dp_timing["comm_ms"]

@@ -124,8 +124,10 @@ class GraphedTrainStep:
         self.result = None
         self._gen = -1
         self.choice = "eager" if launch == "eager" else "graph"       # the path steady-state steps take
-        self.probe = None                                              # {"graph_ms", "eager_ms"} once "auto" has decided
+        self.probe = None                                              # {"graph_ms", "eager_ms"} once "auto" has decided (once per stepper)
         self._probe_t = {}
+        self._probe_dirty = False
+        self.total_calls = 0                                           # never reset: the probe schedule of "auto" runs on it
 
     def _signature(self, images, t_bbox, t_class):
         c = self.config
@@ -220,50 +222,74 @@ class GraphedTrainStep:
         return m_outputs, total_loss, log
 
     def _decide(self):
-        tg, te = self._probe_t["graph"], self._probe_t["eager"]
+        """Called ONCE per stepper, by every data-parallel rank at the same call count (the probe schedule counts every call of
+        the stepper and is never restarted by a rank-local re-recording): the MAX all-reduce below therefore cannot interleave
+        with another rank's gradient-bucket collectives.  A rank whose probe window was disturbed (re-recording inside it)
+        contributes +inf and the ranks fall back to the eager path together."""
+        n = self.PROBE_STEPS
+        tg, te = self._probe_t.get("graph_s"), self._probe_t.get("eager_s")
+        tg = float("inf") if tg is None else tg
+        te = float("inf") if te is None else te
         dp = self.model.dp
         if dp is not None and getattr(dp, "active", False):
             import torch.distributed as dist
-            tt = torch.tensor([tg, te], dtype=torch.float64, device=self.model.device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            big = 1.0e30
+            tt = torch.tensor([min(tg, big), min(te, big)], dtype=torch.float64, device=self.model.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=getattr(dp, "group", None))
             tg, te = (float(v) for v in tt.tolist())
-        self.choice = "graph" if tg <= te else "eager"
-        n = self.PROBE_STEPS
-        self.probe = {"graph_ms": round(tg / n * 1e3, 3), "eager_ms": round(te / n * 1e3, 3)}
+            tg = float("inf") if tg >= big else tg
+            te = float("inf") if te >= big else te
+        self.choice = "graph" if (tg <= te and tg != float("inf")) else "eager"
+        ms = lambda t: None if t == float("inf") else round(t / n * 1e3, 3)
+        self.probe = {"graph_ms": ms(tg), "eager_ms": ms(te)}
 
     def __call__(self, images, t_bbox, t_class, epoch_step):
         cfg, model = self.config, self.model
         eng = model.engine
+        self.total_calls += 1
         key = self._signature(images, t_bbox, t_class)
         stale = self.step_graph is not None and self._gen != eng.buf_generation
         if key != self.key or stale:        # new batch shape / trained groups / precision, or the recorded buffers are gone
             self.key, self.calls = key, 0
             self.step_graph = self.apply_graph = self.result = None
-            self.probe, self._probe_t = None, {}
-            self.choice = "eager" if self.launch == "eager" else "graph"
+            self._probe_dirty = True        # (a probe window this falls into does not count; the DECISION, once taken, stands)
+            if self.probe is None:
+                self.choice = "eager" if self.launch == "eager" else "graph"
         self.calls += 1
         eager_only = (self.launch == "eager" or _gradient_aggregate(cfg) > 1 or bool(getattr(cfg, "check_matching", False)))
-        if eager_only or self.calls <= self.eager_steps:
+        if eager_only:
             return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
+        warm = self.calls <= self.eager_steps       # first sighting of a shape: eager (allocates the static memory plan)
         if self.launch != "auto" or self.probe is not None:
-            if self.choice == "graph":
+            if self.choice == "graph" and not warm:
                 return self._replay(images, t_bbox, t_class)
             return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
-        # ---- "auto", still probing: call eager_steps + 1 records, then PROBE_STEPS timed replays, then PROBE_STEPS timed eager steps
-        i = self.calls - self.eager_steps - 1          # 0 = the recording pass
+        # ---- "auto", still probing.  The schedule counts EVERY call of this stepper (total_calls), so that all data-parallel
+        #      ranks reach the decision -- the only collective of the stepper -- at the same call: eager_steps warm-up calls, one
+        #      recording call, PROBE_STEPS timed replays, PROBE_STEPS timed eager steps (all ordinary training steps)
+        i = self.total_calls - self.eager_steps - 1          # 0 = the recording pass
         n = self.PROBE_STEPS
+        if i < 0:
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         if i == 0:
-            return self._replay(images, t_bbox, t_class)
+            self._probe_dirty = False
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step) if warm else \
+                self._replay(images, t_bbox, t_class)
+        if i > 2 * n:                        # (the window was spent in eager-only mode: nothing measured, no collective anywhere)
+            self.choice, self.probe = "eager", {"graph_ms": None, "eager_ms": None}
+            return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         phase = "graph" if i <= n else "eager"
         first, last = (i - 1) % n == 0, (i - 1) % n == n - 1
         if first:
             torch.cuda.synchronize()
+            self._probe_dirty = warm or (phase == "graph" and self.step_graph is None)     # a (re-)recording inside the window
             self._probe_t[phase] = time.perf_counter()
-        out = self._replay(images, t_bbox, t_class) if phase == "graph" else \
+        out = self._replay(images, t_bbox, t_class) if (phase == "graph" and not warm) else \
             train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         if last:
             torch.cuda.synchronize()
-            self._probe_t[phase] = time.perf_counter() - self._probe_t[phase]
+            if not self._probe_dirty:
+                self._probe_t[phase + "_s"] = time.perf_counter() - self._probe_t[phase]
             if phase == "eager":
                 self._decide()
         return out
