@@ -49,6 +49,10 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 #ifndef DETR_ABLATE
 #define DETR_ABLATE 0
 #endif
+// 1: the bf16 tile GEMM K loop in its explicitly pipelined form (gemm_bf16_core.h: KPipe); 0: compiler-scheduled (round 3) -- A/B builds
+#ifndef DETR_KLOOP_PIPE
+#define DETR_KLOOP_PIPE 1
+#endif
 #if defined(__HIPCC__)
 template <typename T>
 __device__ __forceinline__ void ablate_keep(const T &v) {      // keeps a loaded register alive without using it

@@ -55,6 +55,7 @@ struct LoaderKb {
     static constexpr int NV = BMN / 32;
     typedef float4 Reg;
     static constexpr int NREG = NV;
+    static constexpr int NDSW = NV, NVMEM = NV;      // DS write / (vector-path) request instructions per tile
     BufSrc src;
     unsigned off[NV];      // byte offset of the row, BUF_OOB for rows outside the operand
     bool vec;
@@ -102,6 +103,7 @@ struct LoaderMNt {
     static constexpr int NU = BMN / 32;              // float4 per thread and tile (32 k x BMN / 4 / 256)
     typedef float4 Reg;
     static constexpr int NREG = NU;
+    static constexpr int NDSW = NU, NVMEM = NU;
     BufSrc src;
     unsigned ld4b;
     int mn0, MN;
@@ -152,6 +154,7 @@ struct LoaderKh {
     static_assert(BMN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
     typedef uint4 Reg;
     static constexpr int NREG = NV;
+    static constexpr int NDSW = NV, NVMEM = NV;
     BufSrc src;
     unsigned off[NV];
     int k8, tid;
@@ -176,6 +179,27 @@ struct LoaderKh {
 #pragma unroll
         for (int i = 0; i < NV; ++i) *reinterpret_cast<uint4 *>(&S[tid / CPR + RPP * i][k8]) = r[i];
     }
+    // ---- per-tile descriptor form (round 4): the K advance lives in the DESCRIPTOR (base += 2 k0, num_records -= 2 k0: scalar
+    // instructions), the per-lane offsets voff[] = off[] + 2 k8 are loop constants, and a tile at or past `kend` gets an empty
+    // descriptor (no traffic).  What is left per tile is one compare + one select per request for a ragged last tile --
+    // the offset arithmetic of load() was ~5 VALU instructions per request, more than the tile's MFMAs leave room for.
+    const unsigned short *tbase;
+    long long text;
+    __device__ __forceinline__ void init_tiles(const float *p, long long ld, int MN, int K) {
+        tbase = reinterpret_cast<const unsigned short *>(p);
+        text = ((long long)(MN - 1) * ld + K) * 2;
+    }
+    __device__ __forceinline__ void load_tile(int k0, int kend, uint4 (&r)[NV]) const {
+        long long left = (k0 < kend) ? text - 2ll * k0 : 0;
+        left = left < 0 ? 0 : left;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(tbase + k0), 0, (int)(unsigned)left, 0x00020000);
+        const bool inside = k0 + k8 < kend;            // (K % 8 == 0: a 16-byte chunk is inside or outside as a whole)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned vo = off[i] != BUF_OOB ? off[i] + 2u * (unsigned)k8 : BUF_OOB;      // loop constant
+            r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, inside ? vo : BUF_OOB, 0, 0));
+        }
+    }
 };
 
 // [k][mn], mn contiguous: transpose-read image, 8-byte units of 4 mn (same unit map as LoaderMNt).
@@ -191,6 +215,7 @@ struct LoaderMNth {
     static_assert(!WIDE || NU % 2 == 0, "wide units come in pairs");
     typedef uint2 Reg;
     static constexpr int NREG = NU;
+    static constexpr int NDSW = WIDE ? NU / 2 : NU, NVMEM = WIDE ? NU / 2 : NU;
     BufSrc src;
     unsigned ld2b;
     int mn0, MN, tid;
@@ -217,6 +242,41 @@ struct LoaderMNth {
                 const int k = k0 + 4 * (u / (16 * NB)) + ((u >> 2) & 3);
                 const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
                 r[i] = src.ld8((k < K && col + 4 <= MN) ? base + (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB);
+            }
+        }
+    }
+    // ---- per-tile descriptor form (see LoaderKh): base += k0 rows, num_records shrinks with it, so rows at or past `kend` fall outside
+    // the descriptor by themselves (ld >= MN) and the per-lane offsets are loop constants: ZERO vector instructions per request
+    const unsigned short *tbase;
+    long long text;
+    __device__ __forceinline__ void init_tiles(const float *p, long long ld_, int kend) {
+        tbase = reinterpret_cast<const unsigned short *>(p);
+        text = ((long long)(kend - 1) * ld_ + MN) * 2;          // the descriptor ends with row kend - 1 (this split's last row)
+    }
+    __device__ __forceinline__ void load_tile(int k0, int, uint2 (&r)[NU]) const {
+        long long left = text - (long long)k0 * ld2b;
+        left = left < 0 ? 0 : left;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(tbase) + (long long)k0 * (ld2b >> 1), 0,
+                                                                           (int)(unsigned)left, 0x00020000);
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < NU / 2; ++i) {
+                const int u = 2 * (tid + 256 * i);
+                const int kr = 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+                const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+                const unsigned vo = (col + 8 <= MN) ? (unsigned)kr * ld2b + 2u * (unsigned)col : BUF_OOB;       // loop constant
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+                r[2 * i] = make_uint2(v.x, v.y);
+                r[2 * i + 1] = make_uint2(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int u = tid + 256 * i;
+                const int kr = 4 * (u / (16 * NB)) + ((u >> 2) & 3);
+                const int col = mn0 + 16 * ((u >> 4) & (NB - 1)) + 4 * (u & 3);
+                const unsigned vo = (col + 4 <= MN) ? (unsigned)kr * ld2b + 2u * (unsigned)col : BUF_OOB;
+                r[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0));
             }
         }
     }
@@ -248,6 +308,62 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short (*S)[LD], int row
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- explicitly pipelined K tile (round 4; DETR_KLOOP_PIPE) -----------------------------------------------------------------
+// SQ counters of the split-K weight-gradient launches (one 4-wave workgroup per CU = ONE wave per SIMD, profiles/r03_rocprofv3_pmc_sq_bf16.txt):
+// a K tile costs a wave ~2500 cycles for 512 cycles of MFMA -- 37 % issuing, 33 % parked on s_waitcnt, 30 % issue stalls -- because
+// the compiler's order is [LDS stores of the next tile] -> [fragment reads] -> wait -> [MFMAs], i.e. every phase's latency is exposed
+// when no second wave is there to cover it.  Here the iteration is written, and pinned with sched_group_barrier, as
+//   reads(step 0), reads(step 1) | MFMA(step 0) with the next tile's LDS stores between them | reads(step 2) |
+//   MFMA(step 1) with the tile-after-next's global requests between them | reads(step 3) | MFMA(step 2) | MFMA(step 3)
+// so that fragment reads run one k-step ahead of the MFMAs that consume them and stores / requests ride in the MFMA shadows.
+// Every accumulator sees its k-steps in the same order as before: results are bit-identical to mma_ktile_bf16.
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int BK>
+struct KPipe {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    static constexpr int NS = BK / 16;
+    static constexpr int READS = T::TM * (ATR ? 2 : 1) + T::TN * (BTR ? 2 : 1);     // DS read instructions per k-step
+    static constexpr int MF = T::TM * T::TN;                                           // MFMAs per k-step
+    struct Frags { bf16x8 a[T::TM], b[T::TN]; };
+    __device__ __forceinline__ static void read(const unsigned short (*As)[BK + 8], const unsigned short (*Bs)[BK + 8], int ks, int wm, int wn,
+                                                int lane, Frags &f) {
+        const int l31 = lane & 31, kh = (lane >> 5) * 8;
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi) {
+            if constexpr (ATR) f.a[mi] = frag_tr<BM>(As, wm * T::WTM + mi * 32, ks, lane);
+            else f.a[mi] = *reinterpret_cast<const bf16x8 *>(&As[wm * T::WTM + mi * 32 + l31][ks + kh]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni) {
+            if constexpr (BTR) f.b[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
+            else f.b[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh]);
+        }
+    }
+    __device__ __forceinline__ static void mma(const Frags &f, f32x16 (&acc)[T::TM][T::TN]) {
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+    }
+};
+// sched_group_barrier masks (LLVM AMDGPU): 0x2 VALU, 0x8 MFMA, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+template <int N> __device__ __forceinline__ void sgb_ds_read() { if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x100, N, 0); }
+template <int N> __device__ __forceinline__ void sgb_ds_write() { if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x200, N, 0); }
+template <int N> __device__ __forceinline__ void sgb_vmem() { if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x20, N, 0); }
+template <int N> __device__ __forceinline__ void sgb_valu() { if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(0x2, N, 0); }
+__device__ __forceinline__ void sgb_mfma() { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
+// MFMA i of MF gets items [i * TOTAL / MF, (i + 1) * TOTAL / MF) of a TOTAL-item side stream
+template <int TOTAL, int MF, int I> struct SgbShare { static constexpr int N = ((I + 1) * TOTAL) / MF - (I * TOTAL) / MF; };
+template <int MF, int NW, int NG, int NV, int I = 0>
+__device__ __forceinline__ void sgb_mfma_block() {       // MF MFMAs, each followed by its share of NW DS writes, NV VALU and NG VMEM requests
+    if constexpr (I < MF) {
+        sgb_mfma();
+        sgb_ds_write<SgbShare<NW, MF, I>::N>();
+        sgb_valu<SgbShare<NV, MF, I>::N>();
+        sgb_vmem<SgbShare<NG, MF, I>::N>();
+        sgb_mfma_block<MF, NW, NG, NV, I + 1>();
+    }
 }
 
 // one BK-deep K tile: BK / 16 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.

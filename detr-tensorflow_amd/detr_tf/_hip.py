@@ -119,6 +119,8 @@ _SIGNATURES = {
     "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p],
+    "detr_hip_maxpool3x3s2_bwd_y_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p],
     "detr_hip_cvt_bf16": [f32p, c_void_p, c_int64, c_void_p],
     "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
     "detr_hip_scale_cols_bf16_group": [c_void_p, c_int32, c_void_p],

@@ -924,8 +924,11 @@ class DetrEngine:
         H1, W1 = stem.shape[1], stem.shape[2]
         H2, W2 = pool.shape[1], pool.shape[2]
         d_stem = self.buf("scratch:d_stem", stem.shape, adt)
-        hip.call("detr_hip_maxpool3x3s2_bwd_bf16" if adt == torch.bfloat16 else "detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(),
-                 amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
+        if adt == torch.bfloat16:      # the ReLU mask is read off the POOLED output (equal to x at every arg-max): no pass over `stem`
+            hip.call("detr_hip_maxpool3x3s2_bwd_y_bf16", g.data_ptr(), amax.data_ptr(), pool.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64,
+                     H2, W2)
+        else:
+            hip.call("detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(), amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
         M1 = B * H1 * W1
         hip.stem_conv(2, self.images, d_stem, G[f"{self._stem['conv']}/kernel"], B, self._shape[1], self._shape[2], H1, W1,
                       scale=self.bn_scale[self._stem["bn"]], split=max(1, min(512, M1 // 4096)))

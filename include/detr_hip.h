@@ -218,6 +218,10 @@ int detr_hip_maxpool3x3s2_fwd_bf16(const uint16_t *x, uint16_t *y, uint8_t *argm
                                    int32_t C, int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_maxpool3x3s2_bwd_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *x, uint16_t *dx, int32_t N,
                                    int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
+/* the same gradient from the POOLED output y instead of the pooling input x (C % 8 == 0, 16-byte aligned tensors): at a window's
+ * arg-max x equals y bit for bit, so the ReLU mask (x > 0) of resnet_backbone.py:24-26 can be read at a quarter of the pixels */
+int detr_hip_maxpool3x3s2_bwd_y_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *y, uint16_t *dx, int32_t N,
+                                     int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_fwd_f32(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C,
                                 int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -1064,6 +1064,10 @@ def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stri
         xb, gb = b16(x), b16(gp)
         hip.call("detr_hip_maxpool3x3s2_bwd_bf16", gb.data_ptr(), a16.data_ptr(), xb.data_ptr(), d16.data_ptr(), N, H, W, C, H2, W2)
         assert torch.equal(d16, b16(d32))
+        # round 4: the same gradient with the ReLU mask read off the POOLED output (x == y at every arg-max), no pass over x
+        d16y = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.call("detr_hip_maxpool3x3s2_bwd_y_bf16", gb.data_ptr(), a16.data_ptr(), p16.data_ptr(), d16y.data_ptr(), N, H, W, C, H2, W2)
+        assert torch.equal(d16y, d16) and float(d16.float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("rows", ["3", "4"])
