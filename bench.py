@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps (the last ones) whose launches carry HIP events")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
+    ap.add_argument("--phase-events", action="store_true", help="after the timed region: 5 eager steps with HIP events at the phase "
+                    "boundaries of the launch sequence (backbone / encoder / decoder / heads / set loss, forward and backward, optimiser)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves and relay rank 0's line
@@ -378,6 +380,20 @@ def main():
         d, _ = timed(3)
         value_nodrop = args.batch * 3 / d
         model.engine.dropout_p = args.dropout
+    phases = None
+    if args.phase_events and args.mode == "train":
+        acc = {}
+        for i in range(5):
+            model.engine.phase_events = []
+            engine_mod.WGRAD_STREAM = wgrad_stream_default
+            training.train_step(model, images, tb, tc, opt, cfg, 1000 + i)
+            torch.cuda.synchronize()
+            evs = model.engine.phase_events
+            model.engine.phase_events = None
+            for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
+                acc.setdefault(n0, []).append(e0.elapsed_time(e1))
+        phases = {k: round(sorted(v)[len(v) // 2], 3) for k, v in acc.items()}          # median ms; main-stream spans
+        phases["sum"] = round(sum(phases.values()), 3)
     main_tables = family_tables(prof, ev_steps, args.precision) if prof is not None else (None, None)
     attn_report = None
     if prof is not None and args.mode == "train":
@@ -520,7 +536,7 @@ def main():
             "fp32": fp32,
             "images_per_sec_fp32_parity_mode": fp32["value"] if fp32 else None,
             "bf16_vs_fp32_loss_rel_dev_first_step": (float(f"{bf16_loss_dev:.3e}") if bf16_loss_dev is not None else None),
-            "roofline": roofline, "step_roofline": step_roofline, "attention": attn_report, "configs": configs,
+            "roofline": roofline, "step_roofline": step_roofline, "attention": attn_report, "phases_ms": phases, "configs": configs,
         }
         if dp_timing is not None:      # N > 1: the gradient exchange, from HIP events at each bucket hand-over / completion (rank 0)
             res["comm_ms"] = dp_timing["comm_ms"]

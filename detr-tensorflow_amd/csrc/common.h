@@ -53,6 +53,7 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 #ifndef DETR_KLOOP_PIPE
 #define DETR_KLOOP_PIPE 1
 #endif
+
 #if defined(__HIPCC__)
 template <typename T>
 __device__ __forceinline__ void ablate_keep(const T &v) {      // keeps a loaded register alive without using it

@@ -113,6 +113,7 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_gemm_desc, rowsum_a)); DETR_PUT(DETR_OFF(detr_gemm_desc, rowsum_alpha)); DETR_PUT(DETR_OFF(detr_gemm_desc, b_dtype));
         DETR_PUT(DETR_OFF(detr_gemm_desc, a_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, c_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, r_dtype));
         DETR_PUT(DETR_OFF(detr_gemm_desc, m_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, dropout_step)); DETR_PUT(DETR_OFF(detr_gemm_desc, defer_out));
+        DETR_PUT(DETR_OFF(detr_gemm_desc, maskbits_out)); DETR_PUT(DETR_OFF(detr_gemm_desc, ld_maskbits_out));
         break;
     case 2:   // detr_conv3x3_desc
         DETR_PUT((int32_t)sizeof(detr_conv3x3_desc));

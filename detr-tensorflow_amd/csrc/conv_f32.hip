@@ -1071,53 +1071,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16x8_kernel(const uint4 *__
 
 
 
-// Same gradient WITHOUT reading the pooling input (round 4).  The ReLU mask (x > 0) is only ever applied where a window's
-// arg-max sits, and there x equals the pooled value bit for bit -- so (x[p] > 0) == (y[o] > 0) for every (pixel p, window o) pair
-// that carries a gradient.  Reading y (a quarter of the pixels, lines the dy / arg-max reads of the same windows touch anyway)
-// instead of x takes a 273 MB stream out of the 650 MB this kernel moved at B = 8, 800 x 1333.
-__global__ __launch_bounds__(256) void maxpool_bwd_bf16x8_y_kernel(const uint4 *__restrict__ dy, const uint2 *__restrict__ amax,
-                                                                   const uint4 *__restrict__ y, uint4 *__restrict__ dx, int N, int H,
-                                                                   int W, int C8, int Ho, int Wo, long long total8) {
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total8;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(idx % C8);
-        const unsigned pix = (unsigned)(idx / C8);
-        const int w = (int)(pix % (unsigned)W);
-        const unsigned t = pix / (unsigned)W;
-        const int h = (int)(t % (unsigned)H);
-        const int n = (int)(t / (unsigned)H);
-        float g[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = 0.0f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int th = h + 1 - kh;
-            if (th < 0 || (th & 1)) continue;
-            const int ho = th >> 1;
-            if (ho >= Ho) continue;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tw = w + 1 - kw;
-                if (tw < 0 || (tw & 1)) continue;
-                const int wo = tw >> 1;
-                if (wo >= Wo) continue;
-                const long long o8 = ((long long)(n * Ho + ho) * Wo + wo) * C8 + c8;
-                const uint2 am = amax[o8];
-                float d[8], yv[8];
-                bf8_to_f8(dy[o8], d);
-                bf8_to_f8(y[o8], yv);
-                const uint32_t tap = (uint32_t)(kh * 3 + kw);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (((am.x >> (8 * e)) & 0xFFu) == tap && yv[e] > 0.0f) g[e] += d[e];
-                    if (((am.y >> (8 * e)) & 0xFFu) == tap && yv[4 + e] > 0.0f) g[4 + e] += d[4 + e];
-                }
-            }
-        }
-        dx[idx] = make_uint4(f32_to_bf16_pair(g[0], g[1]), f32_to_bf16_pair(g[2], g[3]), f32_to_bf16_pair(g[4], g[5]), f32_to_bf16_pair(g[6], g[7]));
-    }
-}
-
 __global__ void subsample2_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, int H, int W, int C4,
                                       int Ho, int Wo, long long total) {
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -1522,18 +1475,5 @@ extern "C" int detr_hip_maxpool3x3s2_bwd_bf16(const uint16_t *dy, const uint8_t 
     hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint2 *)dy,
                        (const uint32_t *)argmax, (const uint2 *)x, (uint2 *)dx, N, H, W, C / 4, Ho, Wo, total);
     DETR_LAUNCH_CHECK("maxpool bwd bf16");
-    return 0;
-}
-
-extern "C" int detr_hip_maxpool3x3s2_bwd_y_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *y, uint16_t *dx, int32_t N,
-                                                int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream) {
-    DETR_REQUIRE(dy && argmax && y && dx && C % 8 == 0, "maxpool bwd (pooled mask) bf16: bad operands");
-    DETR_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)argmax % 8 == 0),
-                 "maxpool bwd (pooled mask) bf16: alignment");
-    DETR_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool bwd (pooled mask): bad output size");
-    const long long total8 = (long long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(maxpool_bwd_bf16x8_y_kernel, dim3(ew_grid(total8, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)dy,
-                       (const uint2 *)argmax, (const uint4 *)y, (uint4 *)dx, N, H, W, C / 8, Ho, Wo, total8);
-    DETR_LAUNCH_CHECK("maxpool bwd bf16 (pooled mask)");
     return 0;
 }

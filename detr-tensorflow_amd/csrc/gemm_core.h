@@ -51,7 +51,22 @@ struct EpiArgs {
     // 1: all-bf16 epilogue streams (C, and residual / mask when present) with rows that are 16-byte aligned and a multiple of 8
     // wide, no atomics -> epilogue_wide16 (8 columns per lane, every request of a strip in flight at once)
     int wide16 = 0;
+    // bit-packed ReLU masks (wide16 / streaming epilogues only): m16 == 2 -> `mask` points to bytes (bit (n & 7) of byte
+    // [row * ldmask + n / 8], ldmask in BYTES); mbits_out != null -> the epilogue also writes those bytes for its own output
+    unsigned char *mbits_out = nullptr;
+    long long ld_mbits_out = 0;
 };
+// bit j of the result = (bf16 element j of the four packed pairs > 0)
+__device__ __forceinline__ unsigned bf16x8_gt0_bits(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+    const unsigned w[4] = {w0, w1, w2, w3};
+    unsigned b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b |= ((short)(w[j] & 0xFFFFu) > 0 ? 1u : 0u) << (2 * j);
+        b |= ((short)(w[j] >> 16) > 0 ? 1u : 0u) << (2 * j + 1);
+    }
+    return b;
+}
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
 __device__ __forceinline__ float4 ld_bf16x4(const void *base, long long elem) {
@@ -383,7 +398,10 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
             rr[p] = make_uint4(0u, 0u, 0u, 0u);
             mm[p] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
             if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + prow[p] * e.ldr + col);
-            if (ok && msk16) mm[p] = *reinterpret_cast<const uint4 *>(msk16 + prow[p] * e.ldmask + col);
+            if (ok && msk16) {
+                if (e.m16 == 2) mm[p].x = reinterpret_cast<const unsigned char *>(e.mask)[prow[p] * e.ldmask + (col >> 3)];      // 8 mask bits
+                else mm[p] = *reinterpret_cast<const uint4 *>(msk16 + prow[p] * e.ldmask + col);
+            }
         }
         // the staging region is wave-private: only the first strip needs the workgroup (the main loop / a row-sum finish of the
         // other waves may still be reading the LDS it aliases); later strips and the write -> read turn-around are wave-local
@@ -404,7 +422,12 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
             const float4 a1 = *reinterpret_cast<const float4 *>(stage + rl * S::LD + c8 + 4);
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             const unsigned rw[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
-            const unsigned mw[4] = {mm[p].x, mm[p].y, mm[p].z, mm[p].w};
+            unsigned mw[4] = {mm[p].x, mm[p].y, mm[p].z, mm[p].w};
+            if (msk16 && e.m16 == 2) {                 // expand the byte into the bf16 pairs the arithmetic below reads (1.0 / 0.0)
+                const unsigned mb = mm[p].x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mw[j] = ((mb >> (2 * j)) & 1u ? 0x3f80u : 0u) | ((mb >> (2 * j + 1)) & 1u ? 0x3f800000u : 0u);
+            }
             bool keep[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) keep[j] = true;
@@ -425,6 +448,7 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
                 ow[j] = f32_to_bf16_pair(o0, o1);
             }
             *reinterpret_cast<uint4 *>(C16 + prow[p] * ldc + col) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if (e.mbits_out) e.mbits_out[prow[p] * e.ld_mbits_out + (col >> 3)] = (unsigned char)bf16x8_gt0_bits(ow[0], ow[1], ow[2], ow[3]);
         }
     }
 }

@@ -39,9 +39,12 @@ __device__ __forceinline__ void splitk_reduce_body(const float *__restrict__ ws,
     if (ts_bm > 0) {
         // tile-ordered slabs: unit i (a float4 = 4 consecutive ROWS of one column, gemm_core.h: slab_ts_unit) is summed over the
         // splits in the same order as a row-major element would be (k = grp, grp + G, ..., then the G groups in order), so the
-        // result is bit-identical to the row-major path; reads are lane-linear, the four stores of a wave cover 128-byte runs
+        // result is bit-identical to the row-major path.  Reads are lane-linear.  The four lanes of a quad hold a 4 x 4 block
+        // (4 rows x 4 consecutive columns): it is transposed through LDS so that every lane updates C with ONE 16-byte
+        // read-modify-write of a row (first version: four 4-byte ones per lane -- the reduce launches got 30 % slower).
+        __shared__ float tr[OUT][5];
         const int upt = (ts_bm * ts_bn) >> 2;
-        const long long total = part_stride >> 2;
+        const long long total = part_stride >> 2;           // a multiple of 1024: a quad is inside or outside as a whole
         for (long long base = (long long)bid * OUT; base < total; base += (long long)nbid * OUT) {
             const long long i = base + lo;
             const bool valid = i < total;
@@ -56,27 +59,35 @@ __device__ __forceinline__ void splitk_reduce_body(const float *__restrict__ ws,
             }
             red[grp][lo] = s;
             __syncthreads();
-            if (grp == 0 && valid) {
+            if (grp == 0) {
 #pragma unroll
                 for (int q = 1; q < G; ++q) {
                     const float4 t = red[q][lo];
                     s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
                 }
-                const int tile = (int)(i / upt), u = (int)(i - (long long)tile * upt);
-                int row0, col;
-                slab_ts_unit(u, ts_bm, ts_bn, row0, col);
-                row0 += (tile / ts_tn) * ts_bm;
-                col += (tile % ts_tn) * ts_bn;
-                if (col < cols) {
-                    const float sc = scale ? scale[col] : 1.0f;
-                    const float sv[4] = {s.x, s.y, s.z, s.w};
-                    float *dst = C + (long long)row0 * ldc + col;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (row0 + j < rows) dst[(long long)j * ldc] += alpha * sc * sv[j];
-                }
+                tr[lo][0] = s.x; tr[lo][1] = s.y; tr[lo][2] = s.z; tr[lo][3] = s.w;
             }
             __syncthreads();
+            if (grp == 0 && valid) {
+                const int qb = lo & ~3, t = lo & 3;             // lane t of the quad takes row t of the block
+                const long long iq = base + qb;
+                const int tile = (int)(iq / upt), u = (int)(iq - (long long)tile * upt);
+                int row0, col;
+                slab_ts_unit(u, ts_bm, ts_bn, row0, col);
+                const int row = row0 + (tile / ts_tn) * ts_bm + t;
+                col += (tile % ts_tn) * ts_bn;
+                if (row < rows && col < cols) {                 // (cols % 4 == 0, col % 4 == 0: the four columns exist together)
+                    const float4 v = make_float4(tr[qb][t], tr[qb + 1][t], tr[qb + 2][t], tr[qb + 3][t]);
+                    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (scale) sc = *reinterpret_cast<const float4 *>(scale + col);
+                    float4 *dst = reinterpret_cast<float4 *>(C + (long long)row * ldc + col);
+                    float4 o = *dst;
+                    o.x += alpha * sc.x * v.x; o.y += alpha * sc.y * v.y; o.z += alpha * sc.z * v.z; o.w += alpha * sc.w * v.w;
+                    *dst = o;
+                }
+            }
+            // (no third barrier: red[] is rewritten after barrier 2, behind every read of it; tr[] is rewritten after the NEXT
+            //  iteration's barrier 1, which the lanes reading it here have to reach first)
         }
     } else if (vec) {
         const int c4n = cols >> 2;
@@ -378,17 +389,23 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
         g.e.drop_seed = d->dropout_seed;
         g.e.drop_step = d->dropout_step;
     }
-    g.e.c16 = d->c_dtype == 1; g.e.r16 = d->r_dtype == 1; g.e.m16 = d->m_dtype == 1;
+    g.e.c16 = d->c_dtype == 1; g.e.r16 = d->r_dtype == 1;
+    g.e.m16 = (d->m_dtype == 1 || d->m_dtype == 2) ? d->m_dtype : 0;       // 2: bit-packed mask (one byte per 8 columns, ldmask in bytes)
+    g.e.mbits_out = d->maskbits_out; g.e.ld_mbits_out = d->ld_maskbits_out;
+    const bool bits_in = d->mask && d->m_dtype == 2, bits_out = d->maskbits_out != nullptr;
     g.e.vec = aligned16(d->C) && (d->ldc % 4 == 0) && (d->sC0 % 4 == 0) && (d->sC1 % 4 == 0) &&
               (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
               (!d->residual || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
-              (!d->mask || (aligned16(d->mask) && d->ldmask % 4 == 0));
+              (!d->mask || bits_in || (aligned16(d->mask) && d->ldmask % 4 == 0));
 
     // all-bf16 epilogue streams, 16-byte rows: the 8-columns-per-lane epilogue (gemm_core.h epilogue_wide16); DETR_HIP_EPI_WIDE=2: off
     g.e.wide16 = g.e.c16 && split == 1 && batch == 1 && (!d->residual || g.e.r16) && (!d->mask || g.e.m16) && d->N % 8 == 0 &&
                  d->ldc % 8 == 0 && aligned16(d->C) && (!d->residual || (d->ldr % 8 == 0 && aligned16(d->residual))) &&
-                 (!d->mask || (d->ldmask % 8 == 0 && aligned16(d->mask))) && (!d->scale || aligned16(d->scale)) &&
-                 (!d->bias || aligned16(d->bias)) && tune(T_EPI_WIDE) != 2;
+                 (!d->mask || bits_in || (d->ldmask % 8 == 0 && aligned16(d->mask))) && (!d->scale || aligned16(d->scale)) &&
+                 (!d->bias || aligned16(d->bias)) && (tune(T_EPI_WIDE) != 2 || bits_in || bits_out);
+    // bit-packed masks live in the all-bf16 epilogues (8 columns per lane = one byte) of the tile engine and of the streaming kernel
+    DETR_REQUIRE(!(bits_in || bits_out) || (bf16c && g.e.wide16 && (!bits_in || d->ldmask >= d->N / 8) && (!bits_out || d->ld_maskbits_out >= d->N / 8)),
+                 "gemm: bit-packed masks need bf16 C / residual, N %% 8 == 0, 16-byte aligned rows, no split-K / batch, and a row pitch >= N / 8 bytes");
 
     const bool ak = d->a_kcontig != 0, bk = d->b_kcontig != 0;
     DETR_REQUIRE(!(bf16c && d->a_dtype == 1 && !ak) || (d->lda % 8 == 0 && d->M % 8 == 0 && aligned16(d->A)),
@@ -462,9 +479,10 @@ static bool gemm_stream_eligible(const GemmPlan &p) {
     if (!((d->K == 64 || d->K == 128 || d->K == 256) && d->N % 64 == 0 && d->M >= ((d->K == 256 && d->N >= 1024) ? 4096 : 16384))) return false;
     if (d->scale || (ext && d->K != 256) || !(d->act == 0 || d->act == 1)) return false;
     if (d->residual && !(g.e.r16 && d->ldr % 8 == 0 && aligned16(d->residual))) return false;
-    if (d->mask && !(g.e.m16 && d->ldmask % 8 == 0 && aligned16(d->mask))) return false;
+    if (d->mask && g.e.m16 != 2 && !(g.e.m16 && d->ldmask % 8 == 0 && aligned16(d->mask))) return false;
     if (!(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C))) return false;
-    const long long span = (long long)(d->M - 1) * (d->ldr > d->ldmask ? d->ldr : d->ldmask) + d->N;
+    const long long ldm_eff = g.e.m16 == 2 ? 0 : d->ldmask;
+    const long long span = (long long)(d->M - 1) * (d->ldr > ldm_eff ? d->ldr : ldm_eff) + d->N;
     if (span * 2 > BUF_MAX_BYTES) return false;
     return tune(T_GEMM_STREAM) != 2;
 }
@@ -478,14 +496,16 @@ static void gemm_stream_launch(const GemmPlan &p, hipStream_t s) {
     a.C = reinterpret_cast<unsigned short *>(d->C); a.ldc = d->ldc;
     a.res = reinterpret_cast<const unsigned short *>(d->residual); a.ldr = d->ldr;
     a.mask = reinterpret_cast<const unsigned short *>(d->mask); a.ldm = d->ldmask;
+    a.mbits_out = d->maskbits_out; a.ld_mbits = d->ld_maskbits_out;
     a.bias = d->bias;
     a.act = d->act;
     a.alpha = d->alpha;
     a.drop_scale = p.g.e.drop_scale; a.drop_thresh = p.g.e.drop_thresh; a.drop_seed = p.g.e.drop_seed; a.drop_step = p.g.e.drop_step;
     a.n_tiles = a.row_tiles = a.q = 0;
-    if (d->K == 64) launch_gemm_stream<64>(a, p.bk, s);
-    else if (d->K == 128) launch_gemm_stream<128>(a, p.bk, s);
-    else launch_gemm_stream<256>(a, p.bk, s);
+    const bool mb = d->mask && d->m_dtype == 2;
+    if (d->K == 64) launch_gemm_stream<64>(a, p.bk, s, mb);
+    else if (d->K == 128) launch_gemm_stream<128>(a, p.bk, s, mb);
+    else launch_gemm_stream<256>(a, p.bk, s, mb);
 }
 
 static int gemm_launch(const GemmPlan &p, hipStream_t s) {

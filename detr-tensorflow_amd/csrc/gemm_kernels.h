@@ -286,6 +286,10 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     // flight into the second set.  The barrier orders LDS only (lds_barrier, common.h): __syncthreads() would drain
     // vmcnt and with it the requests that are supposed to stay in flight -- with it, the iteration time of a workgroup
     // was one HBM / L2 round trip however deep the register pipeline.
+    // (Round 4 measured FOUR register sets on the 64x64 tiles -- twice the bytes in flight: M800 N256 K2048 23 -> 19 us, every short-K
+    //  shape 5-8 % slower (longer prologue), M8400 N256 K2048 unchanged, step +0.08 ms: not kept.  The launches are not bound by
+    //  the request depth either)
+    constexpr int DEPTH = 2;
     typename LA::Reg ra0[NRA], ra1[NRA];
     typename LB::Reg rb0[NRB], rb1[NRB];
     la.load(kbeg + kt0 * BK, kend, ra0);
@@ -301,7 +305,7 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     la.load(kbeg + (kt0 + 2) * BK, kend, ra1);
     lb.load(kbeg + (kt0 + 2) * BK, kend, rb1);
     lds_barrier();
-    // one iteration: `rp` holds tile kt+1 (stored now, then refilled with tile kt+3), LDS[cur] holds tile kt
+    // one iteration: `rp` holds tile kt+1 (stored now, then refilled with tile kt+1+DEPTH), LDS[cur] holds tile kt
     auto iter = [&](const int kt, const int cur, typename LA::Reg (&rpa)[NRA], typename LB::Reg (&rpb)[NRB]) {
         if (do_rs && kt + 1 < kt1) rs_add(rpa);
         // (128x128 tiles with an fp32-storage operand keep the compiler's order: their 168-register budget has no room for the
@@ -317,10 +321,10 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
             lb.store(sm.B[cur ^ 1], rpb);
             if constexpr (P::NS > 2) P::read(sm.A[cur], sm.B[cur], 32, wm, wn, lane, f0);
             P::mma(f1, acc);
-            if constexpr (A16) la.load_tile(kbeg + (kt + 3) * BK, kend, rpa);
-            else la.load(kbeg + (kt + 3) * BK, kend, rpa);
-            if constexpr (B16) lb.load_tile(kbeg + (kt + 3) * BK, kend, rpb);
-            else lb.load(kbeg + (kt + 3) * BK, kend, rpb);
+            if constexpr (A16) la.load_tile(kbeg + (kt + 1 + DEPTH) * BK, kend, rpa);
+            else la.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpa);
+            if constexpr (B16) lb.load_tile(kbeg + (kt + 1 + DEPTH) * BK, kend, rpb);
+            else lb.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpb);
             if constexpr (P::NS > 2) {
                 P::read(sm.A[cur], sm.B[cur], 48, wm, wn, lane, f1);
                 P::mma(f0, acc);
@@ -347,8 +351,8 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
             for (int i = 0; i < NRB; ++i) ablate_keep(rpb[i]);
         }
         if constexpr ((DETR_ABLATE & 2) == 0) {
-            la.load(kbeg + (kt + 3) * BK, kend, rpa);
-            lb.load(kbeg + (kt + 3) * BK, kend, rpb);
+            la.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpa);
+            lb.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpb);
         }
         mma_ktile_bf16<BM, BN, WGM, WGN, !AK, !BKC, BK>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
 #ifdef DETR_IGLP

@@ -32,7 +32,8 @@ struct StreamArgs {
     const unsigned short *B; long long ldb;        // BKC: [N][ldb] (K contiguous); else [K][ldb] (N contiguous)
     unsigned short *C; long long ldc;              // [M][ldc] bf16
     const unsigned short *res; long long ldr;      // optional [M][ldr] bf16
-    const unsigned short *mask; long long ldm;     // optional [M][ldm] bf16, keeps C where mask > 0
+    const unsigned short *mask; long long ldm;     // optional [M][ldm] bf16, keeps C where mask > 0; MASK == 2: bytes of 8 mask bits, ldm in bytes
+    unsigned char *mbits_out; long long ld_mbits;  // optional: also write (C > 0) as one byte per 8 outputs (gemm_core.h EpiArgs)
     const float *bias;                             // optional [N] fp32
     int act;                                       // 0 none, 1 ReLU
     int n_tiles;                                   // N / 64
@@ -88,7 +89,8 @@ struct StreamOcc {
     static constexpr int VALUE = (3 * BYTES <= 160 * 1024) ? 3 : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
 };
 
-template <int K, bool BKC, bool RES, bool MASK, int SL = 1, bool EXT = false>
+// MASK: 0 none, 1 a bf16 tensor, 2 bit-packed (one byte per 8 columns)
+template <int K, bool BKC, bool RES, int MASK, int SL = 1, bool EXT = false>
 __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
     constexpr int WPS = 4 / SL;                    // row walkers (waves per slice) of a workgroup
     constexpr int KC = (K > 128) ? 128 : K;       // A rows are held in registers one K chunk (<= 128) at a time
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     BufSrc srcA, srcR, srcM;
     srcA.init_bytes(a.A, ((long long)(a.M - 1) * a.lda + K) * 2);
     if (RES) srcR.init_bytes(a.res, ((long long)(a.M - 1) * a.ldr + a.N) * 2);
-    if (MASK) srcM.init_bytes(a.mask, ((long long)(a.M - 1) * a.ldm + a.N) * 2);
+    if (MASK == 1) srcM.init_bytes(a.mask, ((long long)(a.M - 1) * a.ldm + a.N) * 2);
+    if (MASK == 2) srcM.init_bytes(a.mask, (long long)(a.M - 1) * a.ldm + a.N / 8);
     float *stage = &sm.stage[wave][0][0];
     const unsigned a_lane = (unsigned)(h * 16);    // byte offset of this lane's 8 k values inside a 16-k step
     const uint32_t dkey = (EXT && a.drop_scale != 0.0f) ? drop_key(a.drop_seed, a.drop_step) : 0u;
@@ -155,7 +158,9 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             const unsigned colb = (unsigned)((n0 + ecg * 8) * 2);
             const bool ep_live = (DETR_ABLATE & 32) == 0;               // ablation bit 5: no residual / mask requests
             if (RES) rres[it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
-            if (MASK) rmsk[it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            if (MASK == 1) rmsk[it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            if (MASK == 2)      // one byte = the 8 columns of this lane; the 8 lanes of a row read 8 consecutive bytes
+                rmsk[it].x = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(srcM.rsrc, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm) + (unsigned)((n0 >> 3) + ecg) : BUF_OOB, 0, 0);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -225,11 +230,16 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
                     for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
                 }
             }
-            if (MASK) {
+            if (MASK == 1) {
                 float m[8];
                 stream_unpack8(rmsk[it], m);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
+            }
+            if (MASK == 2) {
+                const unsigned mb = rmsk[it].x;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = ((mb >> i) & 1u) ? v[i] : 0.0f;
             }
             if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f)) {    // ablation bit 6: no output stores
                 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 #else
                 *dstp = ov;
 #endif
+                if (a.mbits_out) a.mbits_out[(long long)row * a.ld_mbits + ((n0 >> 3) + ecg)] = (unsigned char)bf16x8_gt0_bits(ov[0], ov[1], ov[2], ov[3]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 
 // Host side: eligibility is decided by the caller (gemm_f32.hip); here the slice grouping and the grid.
 template <int K, int SL, bool EXT = false>
-static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s) {
+static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s, bool mask_bits = false) {
     a.n_tiles = a.N / (64 * SL);
     a.row_tiles = (a.M + 31) / 32;
     const int wgs_per_cu = StreamOcc<K, SL>::VALUE;
@@ -297,29 +308,32 @@ static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s) {
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
 #define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT>), grid, dim3(256), 0, s, a)
-    if (bkc) {
-        if (r && m) DETR_STREAM_LAUNCH(true, true, true);
-        else if (r) DETR_STREAM_LAUNCH(true, true, false);
-        else if (m) DETR_STREAM_LAUNCH(true, false, true);
-        else DETR_STREAM_LAUNCH(true, false, false);
+    if (m && mask_bits) {       // bit-packed mask (the input gradients of the bottleneck blocks' first 1x1 convolution: BKC layout)
+        if (bkc) { if (r) DETR_STREAM_LAUNCH(true, true, 2); else DETR_STREAM_LAUNCH(true, false, 2); }
+        else { if (r) DETR_STREAM_LAUNCH(false, true, 2); else DETR_STREAM_LAUNCH(false, false, 2); }
+    } else if (bkc) {
+        if (r && m) DETR_STREAM_LAUNCH(true, true, 1);
+        else if (r) DETR_STREAM_LAUNCH(true, true, 0);
+        else if (m) DETR_STREAM_LAUNCH(true, false, 1);
+        else DETR_STREAM_LAUNCH(true, false, 0);
     } else {
-        if (r && m) DETR_STREAM_LAUNCH(false, true, true);
-        else if (r) DETR_STREAM_LAUNCH(false, true, false);
-        else if (m) DETR_STREAM_LAUNCH(false, false, true);
-        else DETR_STREAM_LAUNCH(false, false, false);
+        if (r && m) DETR_STREAM_LAUNCH(false, true, 1);
+        else if (r) DETR_STREAM_LAUNCH(false, true, 0);
+        else if (m) DETR_STREAM_LAUNCH(false, false, 1);
+        else DETR_STREAM_LAUNCH(false, false, 0);
     }
 #undef DETR_STREAM_LAUNCH
 }
 
 template <int K>
-static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
+static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s, bool mask_bits = false) {
     // slices per workgroup, by measurement (scripts/experiments/ablate_stream.py with DETR_HIP_STREAM_SL = 1 / 2 / 4, the tuning
     // hook below; SL 1 -> chosen): M534400 N256 K64 130 -> 123 us (+mask 180 -> 171), M133600 N512 K128 +res 95 -> 87 (SL 2),
     // +res +mask 116 -> 95 (SL 4), M133600 N512 K256 144 -> 126 (SL 2); M33600 N1024 K256 stays at SL 1 (52 vs 57 us)
     // (in the step, HIP events: K = 256 without a residual / mask epilogue is SLOWER with 2 slices -- 102 KB of LDS, one workgroup per
     //  CU: M133600 N512 0.091 -> 0.120 ms -- so K = 256 groups only the epilogue-heavy form)
     if (a.alpha != 1.0f || a.drop_scale != 0.0f) {      // the extended epilogue exists for K = 256, one slice per workgroup
-        if constexpr (K == 256) launch_gemm_stream_sl<256, 1, true>(a, bkc, s);
+        if constexpr (K == 256) launch_gemm_stream_sl<256, 1, true>(a, bkc, s, mask_bits);
         return;
     }
     int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : ((a.res && a.mask && a.N <= 512) ? 2 : 1));
@@ -327,11 +341,11 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s) {
     if (force == 1 || force == 2 || force == 4) sl = force;
     while (sl > 1 && (a.N % (64 * sl) != 0 || (int)sizeof(StreamSmem<K, 1>) + (sl - 1) * 64 * (K + 8) * 2 > 160 * 1024)) sl >>= 1;
     if (sl == 4) {
-        if constexpr (K <= 128) { launch_gemm_stream_sl<K, 4>(a, bkc, s); return; }
+        if constexpr (K <= 128) { launch_gemm_stream_sl<K, 4>(a, bkc, s, mask_bits); return; }
         sl = 2;
     }
-    if (sl == 2) launch_gemm_stream_sl<K, 2>(a, bkc, s);
-    else launch_gemm_stream_sl<K, 1>(a, bkc, s);
+    if (sl == 2) launch_gemm_stream_sl<K, 2>(a, bkc, s, mask_bits);
+    else launch_gemm_stream_sl<K, 1>(a, bkc, s, mask_bits);
 }
 
 }  // namespace detr

@@ -40,7 +40,8 @@ class GemmDesc(Structure):
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("compute", c_int32),
                 ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32),
                 ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32),
-                ("dropout_step", c_void_p), ("defer_out", POINTER(ReduceDesc))]
+                ("dropout_step", c_void_p), ("defer_out", POINTER(ReduceDesc)),
+                ("maskbits_out", c_void_p), ("ld_maskbits_out", c_int64)]          # ABI 5: bit-packed ReLU masks
 
 
 class AttnDesc(Structure):
@@ -119,8 +120,6 @@ _SIGNATURES = {
     "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p],
-    "detr_hip_maxpool3x3s2_bwd_y_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                         c_void_p],
     "detr_hip_cvt_bf16": [f32p, c_void_p, c_int64, c_void_p],
     "detr_hip_scale_cols_bf16": [f32p, f32p, c_void_p, c_int64, c_int32, c_void_p],
     "detr_hip_scale_cols_bf16_group": [c_void_p, c_int32, c_void_p],
@@ -449,13 +448,17 @@ def _f32(t, name="tensor"):
 def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
                residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0,
-               dropout_step=None, compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None):
+               dropout_step=None, compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None, maskbits_out=None):
     """Fills a detr_gemm_desc; returns (desc, profiler info).  ws_slice = (index, count): this call's share of WORKSPACE."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.A, d.lda, d.a_kcontig = A.data_ptr() + A.element_size() * a_off, lda, int(a_kcontig)
     is16 = lambda t: 1 if (t is not None and t.dtype == torch.bfloat16) else 0      # bf16 activation storage
     d.a_dtype, d.c_dtype, d.r_dtype, d.m_dtype = is16(A), is16(C), is16(residual), is16(mask)
+    if mask is not None and mask.dtype == torch.uint8:
+        d.m_dtype = 2                      # bit-packed ReLU mask: one byte per 8 columns, ldmask = row pitch in bytes
+    if maskbits_out is not None:           # also emit (C > 0) as bits (the ReLU mask of this output for a later backward GEMM)
+        d.maskbits_out, d.ld_maskbits_out = maskbits_out.data_ptr(), maskbits_out.stride(0)
     d.B, d.ldb, d.b_kcontig = B.data_ptr() + B.element_size() * b_off, ldb, int(b_kcontig)
     d.b_dtype = 1 if B.dtype == torch.bfloat16 else 0          # bf16 weight shadow (bf16 compute only)
     d.C, d.ldc = C.data_ptr() + C.element_size() * c_off, ldc
@@ -504,14 +507,15 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
     if (d.compute == 1 and d.a_dtype and d.b_dtype and d.c_dtype and a_kcontig and batch == 1 and split_k == 1 and rowsum_a is None
             and K in (64, 128, 256) and N % 64 == 0 and M >= (4096 if (K == 256 and N >= 1024) else 16384) and scale is None
             and (K == 256 or (alpha == 1.0 and dropout_p == 0.0))
-            and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or (d.m_dtype and ldmask % 8 == 0))
+            and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or d.m_dtype == 2 or (d.m_dtype and ldmask % 8 == 0))
             and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"):
         fam = "gemm_stream_bf16_kernel"          # one kernel body; its K / layout / epilogue instantiations are pooled
     sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} a16{d.a_dtype} b16{d.b_dtype} sk{split_k}"
            f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")
     nbytes = float(batch) * (A.element_size() * M * K + B.element_size() * K * N + C.element_size() * M * N
                              + (residual.element_size() * M * N if residual is not None else 0)
-                             + (mask.element_size() * M * N if mask is not None else 0))     # algorithmic bytes at the stored widths
+                             + ((M * N // 8 if mask.dtype == torch.uint8 else mask.element_size() * M * N) if mask is not None else 0)
+                             + (M * N // 8 if maskbits_out is not None else 0))     # algorithmic bytes at the stored widths
     return d, (fam, 2.0 * M * N * K * batch, sig, nbytes, rd)
 
 

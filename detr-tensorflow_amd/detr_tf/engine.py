@@ -38,6 +38,7 @@ ACT16 = os.environ.get("DETR_HIP_ACT16", "1") != "0"
 H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
 DEFER_REDUCE = os.environ.get("DETR_HIP_DEFER_REDUCE", "1") != "0"     # queue the weight gradients' split-K reductions (A/B switch)
 WGRAD_STREAM = os.environ.get("DETR_HIP_WGRAD_STREAM", "1") != "0"      # backbone weight gradients on a second HIP stream (A/B switch)
+MASK_BITS = os.environ.get("DETR_HIP_MASK_BITS", "1") != "0"            # ReLU masks of the block outputs as bits (A/B switch, round 4)
 
 
 def mix32(x):
@@ -111,6 +112,7 @@ class DetrEngine:
         self._seed_dev = torch.zeros(8, dtype=torch.int32, device=self.device)   # [0] = uint32 seed of the current training step
         self._cross = {}
         self._graph_replay = False       # True while a captured step is being recorded / replayed (training.GraphedTrainStep)
+        self.phase_events = None         # list of (name, torch.cuda.Event) while a caller times the phases of a step (bench.py --phase-events)
 
     # Derived weight copies (BN-folded kernels, the bf16 shadow, the gathered cross-attention weights) are stamped with the
     # weights version they were built from.  EVERY mutation of the parameters bumps the version -- the optimiser after an
@@ -134,6 +136,13 @@ class DetrEngine:
         hip.call("detr_hip_set_u32x8", self._seed_dev.data_ptr(), self._step_seed, 0, 0, 0, 0, 0, 0, 0)
         self._drop = (float(self.dropout_p), self._step_seed)
         return self._step_seed
+
+    def phase(self, name):
+        """Phase marker of the launch sequence: a timing event on the current stream when `phase_events` is a list (measurement only)."""
+        if self.phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_events.append((name, ev))
 
     # ---- buffers ------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
@@ -233,14 +242,15 @@ class DetrEngine:
                      w.numel() // co, co)
         return ws
 
-    def _conv1x1_fwd(self, x, M, cin, cout, conv_name, bn_name, out, residual=None, act=1):
+    def _conv1x1_fwd(self, x, M, cin, cout, conv_name, bn_name, out, residual=None, act=1, maskbits_out=None):
         """1x1 conv + frozen BN (+ residual) (+ ReLU) as one GEMM (resnet_backbone.py:119-121,128-135).
         B = scaled kernel [cin][cout] (N contiguous; in bf16 mode it is staged as a transpose-read LDS image, which
-        made the former transposed weight copy unnecessary)."""
+        made the former transposed weight copy unnecessary).  maskbits_out: also emit (out > 0) as one byte per 8 channels."""
         ws = self._scaled_kernel(conv_name, bn_name)
         shift = self.bn_shift[bn_name]
         ldr = cout if residual is not None else 0
-        hip.gemm(M, cout, cin, x, cin, 1, ws, cout, 0, out, cout, bias=shift, residual=residual, ldr=ldr, act=act)
+        hip.gemm(M, cout, cin, x, cin, 1, ws, cout, 0, out, cout, bias=shift, residual=residual, ldr=ldr, act=act,
+                 maskbits_out=maskbits_out)
 
     # ---- small helpers ----------------------------------------------------------------------------
     @staticmethod
@@ -504,6 +514,7 @@ class DetrEngine:
         self._shape = (B, H, W)
         self.images = images
         V = self.P.views
+        self.phase("fwd backbone")
         # ---------------- stem (resnet_backbone.py:11-26) ----------------
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         M1 = B * H1 * W1
@@ -555,13 +566,17 @@ class DetrEngine:
                 if b == 0:
                     self._side_join()
                 out = self.buf(f"{p}:out", (B, ho, wo, d2), adt)
-                self._conv1x1_fwd(y2, M_out, d1, d2, f"{n['conv3']}/kernel", n["bn3"], out, residual=idn)
+                # training, bf16 activation storage: the block output's ReLU mask as BITS (1 byte per 8 channels) next to the tensor --
+                # the backward only needs the sign, and the GEMMs that apply it are HBM streams (1/16 of the mask bytes)
+                obits = self.buf(f"{p}:out_bits", (M_out, d2 // 8), torch.uint8) if (training and MASK_BITS and adt == torch.bfloat16) else None
+                self._conv1x1_fwd(y2, M_out, d1, d2, f"{n['conv3']}/kernel", n["bn3"], out, residual=idn, maskbits_out=obits)
                 self._block_meta.append(dict(p=p, n=n, x=x, xs=xs, x1=x1, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, h1=h1, w1=w1,
-                                             M1=M1, s2=s2, cin=cin, d1=d1, d2=d2, stride=stride, first=(b == 0)))
+                                             M1=M1, s2=s2, cin=cin, d1=d1, d2=d2, stride=stride, first=(b == 0), out_bits=obits))
                 x, h, w, cin = out, ho, wo, d2
         feat, Hf, Wf = x, h, w
         L = Hf * Wf
         self._feat_meta = (feat, Hf, Wf, L)
+        self.phase("fwd encoder")
         # ---------------- input_proj + positional encoding (detr.py:172-175) ----------------
         src = self.buf("enc:src0", (B * L, D))
         hip.gemm(B * L, D, 2048, feat, 2048, 1, self._w("input_proj/kernel"), D, 0, src, D, bias=V["input_proj/bias"])
@@ -591,6 +606,7 @@ class DetrEngine:
         memory, mem_pos = x, qk
         if self.num_enc == 0:
             mem_pos = qk                                          # = src + pos
+        self.phase("fwd decoder")
         # ---------------- decoder (transformer.py:207-234, :104-133) ----------------
         Q, nd = self.Q, self.num_dec
         qpos = V["query_embed/kernel"]
@@ -643,6 +659,7 @@ class DetrEngine:
                 self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
             self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
             tgt = t3
+        self.phase("fwd heads")
         # ---------------- heads (detr.py:181-204 / :94-114) ----------------
         hip.COMPUTE_BF16 = 0          # the heads, like LayerNorm / softmax / the set loss, always run in exact fp32
         Lv = self.num_dec
@@ -665,6 +682,7 @@ class DetrEngine:
             dense(hs2, "pos_layer/dense_0", t_a, 1)
             dense(t_a, "pos_layer/dense_1", t_b, 1)
             dense(t_b, "pos_layer/dense_2", boxes, 2)
+        self.phase("set loss")
         return logits.view(Lv, B, Q, self.C), boxes.view(Lv, B, Q, 4)
 
     # ---- backward ---------------------------------------------------------------------------------
@@ -684,6 +702,7 @@ class DetrEngine:
         dl = d_logits.reshape(R, self.C)
         db = d_boxes.reshape(R, 4)
         boxes, t_a, t_b = self._bufs["head:boxes"], self._bufs["head:t1"], self._bufs["head:t2"]
+        self.phase("bwd heads")
         # ---------------- heads ----------------
         hip.COMPUTE_BF16 = 0
         dz3 = self.buf("scratch:dz3", (R, 4))
@@ -714,6 +733,7 @@ class DetrEngine:
             dense_bwd(dl, hs2, "cls_layer", d_hs, residual=d_hs)
         d_hs3 = d_hs.view(Lv, B * Q, D)
         hip.COMPUTE_BF16 = self.compute
+        self.phase("bwd decoder")
         # ---------------- decoder ----------------
         feat, Hf, Wf, L = self._feat_meta
         nd = self.num_dec
@@ -779,6 +799,7 @@ class DetrEngine:
         hip.multi_copy(ct["scatter"])
         d_mem = self.buf("scratch:d_mem", (B * L, D))
         hip.linear_dgrad(dKV, ct["Wkv"], d_mem)        # d(memory + pos) through K and d(memory) through V land on the same tensor
+        self.phase("bwd encoder")
         # ---------------- encoder ----------------
         d_x = d_mem
         for i in reversed(range(self.num_enc)):
@@ -796,6 +817,7 @@ class DetrEngine:
             d_x = d_xn
         if on_bucket:
             on_bucket(0)
+        self.phase("bwd backbone")
         # ---------------- input_proj ----------------
         self._wgrad(2048, D, B * L, feat, 2048, d_x, D, G["input_proj/kernel"], D)
         self._colsum(d_x, G["input_proj/bias"])
@@ -806,7 +828,11 @@ class DetrEngine:
             return
         adt = self._adt
         g = self.buf("scratch:g_feat", feat.shape, adt)
-        hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
+        fbits = self._block_meta[-1].get("out_bits") if self._block_meta else None
+        if fbits is not None:
+            hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=fbits, ldmask=fbits.stride(0))
+        else:
+            hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
         # ---------------- residual stages ----------------
         n_blocks = len(self._block_meta)
         tfb = self.tf_backbone
@@ -899,6 +925,7 @@ class DetrEngine:
             is_first_block = bi == 0
             gx = self.buf(f"scratch:gx:{cin}:{h}:{bi & 1}", (B, h, w, cin), adt)
             mask = None if is_first_block else x           # x = ReLU output of the previous block
+            xbits = None if is_first_block else self._block_meta[bi - 1].get("out_bits")      # ... or its sign bits
             if tfb and strided:
                 # both branches read the subsampled input: d_xs = g @ Wd^T + dz1 @ W1^T (ReLU-masked at the sampled pixels),
                 # scattered back into the zero-filled full-resolution gradient
@@ -910,8 +937,11 @@ class DetrEngine:
             else:
                 if idg_ready is not None:
                     main.wait_event(idg_ready)
-                hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
-                         ldmask=(cin if mask is not None else 0))
+                if xbits is not None:
+                    hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=xbits, ldmask=xbits.stride(0))
+                else:
+                    hip.gemm(M_in, cin, d1, dz1, d1, 1, ws1, d1, 1, gx, cin, residual=idg, ldr=cin, mask=mask,
+                             ldmask=(cin if mask is not None else 0))
             g = gx
             if on_bucket:
                 if p == block_names(3, 0, tfb)["tag"]:
@@ -924,11 +954,8 @@ class DetrEngine:
         H1, W1 = stem.shape[1], stem.shape[2]
         H2, W2 = pool.shape[1], pool.shape[2]
         d_stem = self.buf("scratch:d_stem", stem.shape, adt)
-        if adt == torch.bfloat16:      # the ReLU mask is read off the POOLED output (equal to x at every arg-max): no pass over `stem`
-            hip.call("detr_hip_maxpool3x3s2_bwd_y_bf16", g.data_ptr(), amax.data_ptr(), pool.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64,
-                     H2, W2)
-        else:
-            hip.call("detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(), amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
+        hip.call("detr_hip_maxpool3x3s2_bwd_bf16" if adt == torch.bfloat16 else "detr_hip_maxpool3x3s2_bwd_f32", g.data_ptr(),
+                 amax.data_ptr(), stem.data_ptr(), d_stem.data_ptr(), B, H1, W1, 64, H2, W2)
         M1 = B * H1 * W1
         hip.stem_conv(2, self.images, d_stem, G[f"{self._stem['conv']}/kernel"], B, self._shape[1], self._shape[2], H1, W1,
                       scale=self.bn_scale[self._stem["bn"]], split=max(1, min(512, M1 // 4096)))

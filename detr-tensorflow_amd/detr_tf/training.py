@@ -47,8 +47,10 @@ def run_val_step(model, images, t_bbox, t_class, config):
 def train_step(model, images, t_bbox, t_class, optimizers, config, epoch_step):
     """What `fit` does for one batch (training.py:46-54): gradients, then accumulate / apply per group."""
     m_outputs, total_loss, log, gradient_steps = run_train_step(model, images, t_bbox, t_class, optimizers, config)
+    model.engine.phase("optimizer")
     for name in gradient_steps:
         aggregate_grad_and_apply(name, optimizers, gradient_steps[name]["gradients"], epoch_step, config)
+    model.engine.phase("end")
     return m_outputs, total_loss, log
 
 

@@ -115,12 +115,18 @@ typedef struct {
     /* bf16 STORAGE of activation tensors (bf16 compute only; the engine's backbone tensors when DETR_HIP_ACT16=1): 1 = the
      * tensor is bf16 in memory (uint16, RNE; leading dimensions in elements), 0 = fp32.  The epilogue arithmetic stays
      * fp32 and the result is rounded once.  Not with split_k / batch (partial slabs and gradients of parameters stay fp32). */
-    int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask */
+    int32_t a_dtype, c_dtype, r_dtype, m_dtype;     /* A, C, residual, mask (m_dtype 2: bit-packed, see maskbits_out) */
     const uint32_t *dropout_step;                   /* see dropout_p */
     /* optional (HOST pointer): with deterministic split-K, do not launch the reduction but describe it here (splits = 0 when
      * no reduction is pending); the caller keeps `workspace` intact and reduces many slabs per launch with
      * detr_hip_splitk_reduce_many -- the weight gradients of a backward pass are only needed by the optimiser */
     detr_reduce_desc *defer_out;
+    /* ABI 5: bit-packed ReLU masks (bf16 activation storage only, N %% 8 == 0).  The backward of `relu` only needs the SIGN of the
+     * saved activation: a GEMM whose epilogue ends in the ReLU can emit, next to C, one byte per 8 outputs --
+     * bit (n & 7) of maskbits_out[m * ld_maskbits_out + n / 8] = (C[m][n] > 0) as stored -- and a later GEMM takes it instead of
+     * the activation tensor: `mask` pointing to those bytes with m_dtype = 2 and ldmask = their row pitch in BYTES (1/16 of the
+     * bytes of the bf16 tensor on an HBM-bound launch; resnet_backbone.py:132-135 backward). */
+    uint8_t *maskbits_out; int64_t ld_maskbits_out;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_t n, void *stream);
@@ -218,10 +224,6 @@ int detr_hip_maxpool3x3s2_fwd_bf16(const uint16_t *x, uint16_t *y, uint8_t *argm
                                    int32_t C, int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_maxpool3x3s2_bwd_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *x, uint16_t *dx, int32_t N,
                                    int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
-/* the same gradient from the POOLED output y instead of the pooling input x (C % 8 == 0, 16-byte aligned tensors): at a window's
- * arg-max x equals y bit for bit, so the ReLU mask (x > 0) of resnet_backbone.py:24-26 can be read at a quarter of the pixels */
-int detr_hip_maxpool3x3s2_bwd_y_bf16(const uint16_t *dy, const uint8_t *argmax, const uint16_t *y, uint16_t *dx, int32_t N,
-                                     int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_fwd_f32(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C,
                                 int32_t Ho, int32_t Wo, void *stream);
 int detr_hip_subsample2_bwd_f32(const float *dy, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,

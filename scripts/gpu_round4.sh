@@ -29,6 +29,30 @@ for w in "$@"; do
           python scripts/pmc_summary.py $OUT gemm_bf16c $OUT/traffic_bf16.json > $OUT/pmc_hbm_summary.txt 2>&1; head -30 $OUT/pmc_hbm_summary.txt; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
     sqA) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d /root/repo/$OUT/pmc_SQ -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" >> $OUT/summary.txt
           python scripts/pmc_sq_summary.py $OUT pmc_SQ > $OUT/pmc_sq_summary.txt 2>&1; head -40 $OUT/pmc_sq_summary.txt | cut -c1-120; rm -rf $OUT/pmc_SQ ;;
+    ab2) # same-box A/B: new library | lib/libdetr_hip_alt.so (whatever the alternative build of the moment is)
+         for rep in 1 2; do
+           for v in new alt; do
+             case $v in
+               new) envs="" ;;
+               alt) envs="DETR_HIP_LIB=/root/repo/detr-tensorflow_amd/lib/libdetr_hip_alt.so" ;;
+             esac
+             env $envs timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --launch eager --dump-shapes $OUT/shapes_$v.json > $OUT/ab_${v}_$rep.log 2>&1
+             echo "ab $v $rep rc=$?" >> $OUT/summary.txt
+             tail -1 $OUT/ab_${v}_$rep.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', $rep, d['ms_per_step'], d['value'], d['loss'])"
+           done
+         done ;;
+    abenv) # same-box A/B of an environment switch: AB_ENV="NAME=VALUE" (the B arm), default arm first
+         for rep in 1 2; do
+           for v in new env; do
+             case $v in
+               new) envs="" ;;
+               env) envs="$AB_ENV" ;;
+             esac
+             env $envs timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --launch eager --dump-shapes $OUT/shapes_$v.json > $OUT/ab_${v}_$rep.log 2>&1
+             echo "ab $v $rep rc=$?" >> $OUT/summary.txt
+             tail -1 $OUT/ab_${v}_$rep.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', $rep, d['ms_per_step'], d['value'], d['loss'])"
+           done
+         done ;;
     ab3) # same-box A/B/C: new library | compiler-scheduled K loop (lib/libdetr_hip_nopipe.so) | row-major split-K slabs
          for rep in 1 2; do
            for v in new nopipe rowmajor; do
@@ -42,6 +66,12 @@ for w in "$@"; do
              tail -1 $OUT/ab_${v}_$rep.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', $rep, d['ms_per_step'], d['value'], d['loss'])"
            done
          done ;;
+    timeline) (cd /tmp && export TMPDIR=/tmp DETR_HIP_WGRAD_STREAM=${TL_STREAMS:-1} && timeout 600 rocprofv3 --kernel-trace -d /root/repo/$OUT/proftl -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/proftl.log 2>&1); echo "timeline rc=$?" >> $OUT/summary.txt
+          python scripts/prof_timeline.py $OUT/proftl/prof_results.db 1 > $OUT/timeline.txt 2>&1; head -3 $OUT/timeline.txt; rm -rf $OUT/proftl ;;
+    timeline_graph) (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d /root/repo/$OUT/proftlg -o prof -- python /root/repo/bench.py --steps 3 --warmup 3 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch graph > /root/repo/$OUT/proftlg.log 2>&1); echo "timeline_graph rc=$?" >> $OUT/summary.txt
+          python scripts/prof_timeline.py $OUT/proftlg/prof_results.db 1 > $OUT/timeline_graph.txt 2>&1; head -3 $OUT/timeline_graph.txt; rm -rf $OUT/proftlg ;;
+    phases) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --no-kernel-events --launch ${PH_LAUNCH:-eager} --phase-events > $OUT/phases.log 2>&1; echo "phases rc=$?" >> $OUT/summary.txt
+          tail -1 $OUT/phases.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step']); print(json.dumps(d['phases_ms'], indent=1))" ;;
     tests_r4) timeout 1800 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --maxfail=12 -s > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; grep -E "^\[|passed|failed|FAILED|Error" $OUT/tests.log | cut -c1-400 | tail -60 ;;
     *) echo "unknown $w" ;;
   esac

@@ -5,5 +5,6 @@
 namespace detr {
 template __global__ void gemm_bf16c_k64_kernel<128, 128, 2, 2, false, false>(GemmArgs);   // split-K weight gradients (1 workgroup / CU)
 template __global__ void gemm_bf16c_k64_kernel<64, 64, 2, 2, true, true>(GemmArgs);
-template __global__ void gemm_bf16c_kernel<128, 128, 2, 2, true, true, true, true>(GemmArgs);   // big 1x1-conv forward / dgrad
+template __global__ void gemm_bf16c_kernel<128, 128, 2, 2, true, true, true, true>(GemmArgs);
+template __global__ void gemm_bf16c_kernel<64, 64, 2, 2, true, true, false, true>(GemmArgs);      // transformer linears (fp32 activations x bf16 weights)   // big 1x1-conv forward / dgrad
 }

@@ -1064,10 +1064,6 @@ def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stri
         xb, gb = b16(x), b16(gp)
         hip.call("detr_hip_maxpool3x3s2_bwd_bf16", gb.data_ptr(), a16.data_ptr(), xb.data_ptr(), d16.data_ptr(), N, H, W, C, H2, W2)
         assert torch.equal(d16, b16(d32))
-        # round 4: the same gradient with the ReLU mask read off the POOLED output (x == y at every arg-max), no pass over x
-        d16y = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
-        hip.call("detr_hip_maxpool3x3s2_bwd_y_bf16", gb.data_ptr(), a16.data_ptr(), p16.data_ptr(), d16y.data_ptr(), N, H, W, C, H2, W2)
-        assert torch.equal(d16y, d16) and float(d16.float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("rows", ["3", "4"])
@@ -1550,3 +1546,57 @@ def test_fused_attention_bf16_in_workgroup_split(hip, split, B, T, S, p):
     close(dq, q.grad, rtol=2.5e-2, what=f"bf16 attention dq (split {split})")
     close(dk, k.grad, rtol=2.5e-2, what=f"bf16 attention dk (split {split})")
     close(dv, v.grad, rtol=2.5e-2, what=f"bf16 attention dv (split {split})")
+
+
+def _pack_bits(t):
+    """[M, N] bool -> [M, N / 8] uint8, bit (n & 7) of byte n / 8 (the layout of detr_gemm_desc.maskbits_out)."""
+    M, N = t.shape
+    w = (2 ** torch.arange(8, dtype=torch.int32)).view(1, 1, 8)
+    return (t.view(M, N // 8, 8).to(torch.int32) * w).sum(-1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K,bk,use_res", [
+    (20000, 256, 64, 0, True),       # streaming kernel, 4 slices per workgroup (layer1 conv3 forward / conv1 input gradient)
+    (17000, 512, 128, 1, True),      # streaming kernel, K = 128, ragged last strip
+    (16500, 1024, 256, 1, True),     # streaming kernel, K = 256
+    (8400, 2048, 256, 1, False),     # streaming kernel: input gradient of input_proj (mask only)
+    (8400, 2048, 512, 1, True),      # tile engine (128x128, wide epilogue): layer4
+    (300, 128, 96, 0, True),         # tile engine 64x64, ragged rows
+])
+def test_gemm_bitpacked_relu_masks(hip, M, N, K, bk, use_res):
+    """Round 4: the ReLU masks of the bottleneck block outputs as BITS.  Producer: a GEMM with a ReLU epilogue also writes one byte
+    per 8 outputs, bit = (stored bf16 output > 0), and its C is unchanged by that.  Consumer: the same masked GEMM once with the
+    bf16 activation as `mask` and once with the bytes (m_dtype 2) -- bit-identical results on the streaming kernel and on the tile
+    engine (the wide all-bf16 epilogue)."""
+    torch.manual_seed(M + N + K)
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    A = b16(_bf(torch.randn(M, K)))
+    Bm = b16(_bf(torch.randn(N, K) / K ** 0.5 if bk else torch.randn(K, N) / K ** 0.5))
+    res = b16(_bf(torch.randn(M, N)))
+    bias = g(torch.randn(N))
+    ldb = K if bk else N
+    # ---- producer
+    C0 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    C1 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    bits = torch.full((M, N // 8), 0xAA, device=DEV, dtype=torch.uint8)
+    kw = dict(bias=bias, residual=res if use_res else None, ldr=N if use_res else 0, act=1, compute=1)
+    hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, C0, N, **kw)
+    hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, C1, N, maskbits_out=bits, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C1)
+    assert torch.equal(bits.cpu(), _pack_bits((C1.float() > 0).cpu()))
+    frac = float((C1.float() > 0).float().mean())
+    assert 0.2 < frac < 0.8
+    # ---- consumer: same call, bf16 mask vs its bits
+    D0 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    D1 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    kw = dict(residual=res if use_res else None, ldr=N if use_res else 0, compute=1)
+    hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, D0, N, mask=C1, ldmask=N, **kw)
+    hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, D1, N, mask=bits, ldmask=bits.stride(0), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(D0, D1) and float(D0.float().abs().max()) > 0
+    assert float((D0.float() == 0).float().mean()) > 0.15          # the mask did something
+    # fp32 C / split-K cannot carry bits: rejected loudly
+    Cf = torch.zeros(M, N, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, Cf, N, mask=bits, ldmask=bits.stride(0), compute=1)
