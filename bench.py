@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps (the last ones) whose launches carry HIP events")
     ap.add_argument("--dump-shapes", type=str, default=None, help="write the per-shape GEMM timing table (JSON) here")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
+    ap.add_argument("--grad-buckets", choices=("fp32", "bf16"), default="fp32",
+                    help="N > 1: dtype of the gradient buckets on the wire (bf16 = half the bytes over xGMI, fp32 master update; parallel.DataParallel)")
     ap.add_argument("--phase-events", action="store_true", help="after the timed region: 5 eager steps with HIP events at the phase "
                     "boundaries of the launch sequence (backbone / encoder / decoder / heads / set loss, forward and backward, optimiser)")
     args = ap.parse_args()
@@ -301,7 +303,7 @@ def main():
             for raw in m.engine.P.bn_raw.values():
                 dist.broadcast(raw, src=0)
             m.engine.fold_bn()
-            m.dp = parallel.DataParallel(m.engine.P.grad, m.engine.P.bucket_bounds(), engine=m.engine)
+            m.dp = parallel.DataParallel(m.engine.P.grad, m.engine.P.bucket_bounds(), engine=m.engine, bucket_dtype=args.grad_buckets)
         return m, o, training.GraphedTrainStep(m, o, cfg, launch=args.launch)
 
     rng = np.random.default_rng(1234 + rank)
@@ -543,6 +545,7 @@ def main():
             res["exposed_comm_ms"] = dp_timing["exposed_comm_ms"]
             res["ranks_seen"] = dp_timing["ranks_seen"]
             res["comm"] = dp_timing
+            res["grad_bucket_dtype"] = args.grad_buckets
         if not args.no_cpu_baseline and solo:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.height, args.width, threads=args.cpu_threads)

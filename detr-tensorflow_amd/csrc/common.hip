@@ -126,6 +126,7 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_conv3x3_desc, split)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, workspace)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, workspace_bytes));
         DETR_PUT(DETR_OFF(detr_conv3x3_desc, compute)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, w_dtype)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, x_dtype));
         DETR_PUT(DETR_OFF(detr_conv3x3_desc, y_dtype)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, r_dtype)); DETR_PUT(DETR_OFF(detr_conv3x3_desc, m_dtype));
+        DETR_PUT(DETR_OFF(detr_conv3x3_desc, maskbits_out));
         break;
     case 3:   // detr_stem_desc
         DETR_PUT((int32_t)sizeof(detr_stem_desc));

@@ -1279,9 +1279,11 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     e.act = d->act;
     e.atomic = 0;
     e.drop_scale = 0.0f; e.drop_thresh = 0; e.drop_seed = 0;
+    const bool bits_in = d->mask && d->m_dtype == 2, bits_out = mode == 0 && d->maskbits_out != nullptr;
     e.vec = (!d->scale || aligned16(d->scale)) && (!d->bias || aligned16(d->bias)) &&
-            (!d->residual || aligned16(d->residual)) && (!d->mask || aligned16(d->mask));   // channel counts are % 16
-    e.c16 = (mode != 2 && d->y_dtype == 1); e.r16 = d->r_dtype == 1; e.m16 = d->m_dtype == 1;
+            (!d->residual || aligned16(d->residual)) && (!d->mask || bits_in || aligned16(d->mask));   // channel counts are % 16
+    e.c16 = (mode != 2 && d->y_dtype == 1); e.r16 = d->r_dtype == 1;
+    e.m16 = (d->m_dtype == 1 || d->m_dtype == 2) ? d->m_dtype : 0;          // 2: bit-packed mask (see detr_gemm_desc.maskbits_out)
     if (mode == 2) {
         DETR_REQUIRE(!d->bias && !d->residual && !d->mask && d->act == 0, "conv3x3 wgrad: only scale/alpha epilogue");
         ConvWgradArgs a;
@@ -1326,9 +1328,12 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     }
     a.M = d->N * a.Hd * a.Wd;
     e.ldr = a.Cd;
-    e.ldmask = a.Cd;
+    e.ldmask = bits_in ? a.Cd / 8 : a.Cd;
+    e.mbits_out = bits_out ? d->maskbits_out : nullptr;
+    e.ld_mbits_out = a.Cd / 8;
     // all-bf16 epilogue streams (channel counts are % 16, rows 16-byte aligned): 8 columns per lane (gemm_core.h epilogue_wide16)
-    e.wide16 = e.c16 && e.vec && (!d->residual || e.r16) && (!d->mask || e.m16) && tune(T_EPI_WIDE) != 2;
+    e.wide16 = e.c16 && e.vec && (!d->residual || e.r16) && (!d->mask || e.m16) && (tune(T_EPI_WIDE) != 2 || bits_in || bits_out);
+    DETR_REQUIRE(!(bits_in || bits_out) || (d->compute == 1 && e.wide16), "conv3x3: bit-packed masks need bf16 x / y / residual tensors (compute = bf16)");
     a.e = e;
     a.w16 = (d->w_dtype == 1);
     a.x16 = (d->x_dtype == 1);

@@ -83,7 +83,10 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
         for (int it = 0; it < ITERS; ++it) {
             const int tw = it * RPI + rsub;
             mk[it] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-            if (mask && row_ok && tw < wn_ok) mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + PS * tw) * e.ldmask + col);
+            if (mask && row_ok && tw < wn_ok) {
+                if (e.m16 == 2) mk[it].x = reinterpret_cast<const unsigned char *>(e.mask)[(prow0 + PS * tw) * e.ldmask + (col >> 3)];   // 8 mask bits
+                else mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + PS * tw) * e.ldmask + col);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();                // the previous strip's reads are done
@@ -99,7 +102,12 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
             const float4 v0 = *reinterpret_cast<const float4 *>(stage + tw * LD + c8);
             const float4 v1 = *reinterpret_cast<const float4 *>(stage + tw * LD + c8 + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const unsigned mw[4] = {mk[it].x, mk[it].y, mk[it].z, mk[it].w};
+            unsigned mw[4] = {mk[it].x, mk[it].y, mk[it].z, mk[it].w};
+            if (mask && e.m16 == 2) {                  // bit-packed mask: expand the byte into 1.0 / 0.0 bf16 pairs
+                const unsigned mb = mk[it].x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mw[j] = ((mb >> (2 * j)) & 1u ? 0x3f80u : 0u) | ((mb >> (2 * j + 1)) & 1u ? 0x3f800000u : 0u);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 v[j] += bi[j];
@@ -107,9 +115,11 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
                 const float m = bf16_bits_to_f32((j & 1) ? (mw[j >> 1] >> 16) : (mw[j >> 1] & 0xFFFFu));
                 v[j] = (m > 0.0f) ? v[j] : 0.0f;
             }
-            if (row_ok && tw < wn_ok)
-                *reinterpret_cast<uint4 *>(dst + (prow0 + PS * tw) * a.Cd + col) =
-                    make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7]));
+            if (row_ok && tw < wn_ok) {
+                const uint4 ow = make_uint4(f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7]));
+                *reinterpret_cast<uint4 *>(dst + (prow0 + PS * tw) * a.Cd + col) = ow;
+                if (e.mbits_out) e.mbits_out[(prow0 + PS * tw) * e.ld_mbits_out + (col >> 3)] = (unsigned char)bf16x8_gt0_bits(ow.x, ow.y, ow.z, ow.w);
+            }
         }
     }
 }

@@ -82,7 +82,8 @@ class Conv3x3Desc(Structure):
                 ("scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("mask", c_void_p),
                 ("act", c_int32), ("split", c_int32),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("compute", c_int32), ("w_dtype", c_int32),
-                ("x_dtype", c_int32), ("y_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32)]
+                ("x_dtype", c_int32), ("y_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32),
+                ("maskbits_out", c_void_p)]                                   # ABI 5: bit-packed ReLU masks
 
 
 class InputDesc(Structure):
@@ -620,12 +621,15 @@ def linear_wgrad(*a, **kw):
 # conv
 # ------------------------------------------------------------------------------------------
 def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.0, scale=None, bias=None,
-            residual=None, mask=None, act=0, split=0, compute=None):
+            residual=None, mask=None, act=0, split=0, compute=None, maskbits_out=None):
     d = Conv3x3Desc()
     d.N, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co, d.stride, d.pad = N, Hi, Wi, Ci, Ho, Wo, Co, stride, pad
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     is16 = lambda t: 1 if (t is not None and t.dtype == torch.bfloat16) else 0      # bf16 weight shadow / activation storage
     d.w_dtype, d.x_dtype, d.y_dtype, d.r_dtype, d.m_dtype = is16(w), is16(x), is16(y), is16(residual), is16(mask)
+    if mask is not None and mask.dtype == torch.uint8:
+        d.m_dtype = 2                      # bit-packed ReLU mask, one byte per 8 channels of a pixel
+    d.maskbits_out = ptr(maskbits_out)     # mode 0: also emit (y > 0) as bits
     d.alpha = alpha
     d.scale, d.bias, d.residual, d.mask = ptr(scale), ptr(bias), ptr(residual), ptr(mask)
     d.act, d.split = act, split
@@ -643,7 +647,8 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
                      float(x.element_size() * (N * Hi * Wi * Ci if mode != 1 else N * Ho * Wo * Co)
                            + (w.element_size() * 9 * Ci * Co if mode != 2 else w.element_size() * N * Ho * Wo * Co)
                            + y.element_size() * (N * Ho * Wo * Co if mode == 0 else (N * Hi * Wi * Ci if mode == 1 else 9 * Ci * Co))
-                           + (mask.element_size() * rows * (Ci if mode == 1 else Co) if mask is not None else 0)
+                           + ((rows * (Ci if mode == 1 else Co) // 8 if mask.dtype == torch.uint8 else mask.element_size() * rows * (Ci if mode == 1 else Co))
+                              if mask is not None else 0) + (rows * Co // 8 if maskbits_out is not None else 0)
                            + (residual.element_size() * rows * (Ci if mode == 1 else Co) if residual is not None else 0)))
 
 

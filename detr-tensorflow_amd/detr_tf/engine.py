@@ -568,7 +568,13 @@ class DetrEngine:
                 out = self.buf(f"{p}:out", (B, ho, wo, d2), adt)
                 # training, bf16 activation storage: the block output's ReLU mask as BITS (1 byte per 8 channels) next to the tensor --
                 # the backward only needs the sign, and the GEMMs that apply it are HBM streams (1/16 of the mask bytes)
-                obits = self.buf(f"{p}:out_bits", (M_out, d2 // 8), torch.uint8) if (training and MASK_BITS and adt == torch.bfloat16) else None
+                # (only where the consumer is the STREAMING kernel -- the conv1 input gradient of a following block of layer1-3: there the
+                #  mask stream is a third of the bytes; in the tile engine's / the 3x3 kernels' epilogues the byte loads measured 2-9 %
+                #  SLOWER than the 16-byte mask loads, so y1 / y2 and the layer4 blocks keep their bf16 masks)
+                nxt_d1 = 64 * 2 ** (li if b + 1 < nb else li + 1)        # d1 of the next block
+                last = (li + 1 == len(self.blocks)) and (b + 1 == nb)
+                obits = self.buf(f"{p}:out_bits", (M_out, d2 // 8), torch.uint8) \
+                    if (training and MASK_BITS and adt == torch.bfloat16 and not last and nxt_d1 <= 256) else None
                 self._conv1x1_fwd(y2, M_out, d1, d2, f"{n['conv3']}/kernel", n["bn3"], out, residual=idn, maskbits_out=obits)
                 self._block_meta.append(dict(p=p, n=n, x=x, xs=xs, x1=x1, y1=y1, y2=y2, out=out, h=h, w=w, ho=ho, wo=wo, h1=h1, w1=w1,
                                              M1=M1, s2=s2, cin=cin, d1=d1, d2=d2, stride=stride, first=(b == 0), out_bits=obits))
@@ -828,11 +834,7 @@ class DetrEngine:
             return
         adt = self._adt
         g = self.buf("scratch:g_feat", feat.shape, adt)
-        fbits = self._block_meta[-1].get("out_bits") if self._block_meta else None
-        if fbits is not None:
-            hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=fbits, ldmask=fbits.stride(0))
-        else:
-            hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
+        hip.gemm(B * L, 2048, D, d_x, D, 1, self._w("input_proj/kernel"), D, 1, g, 2048, mask=feat, ldmask=2048)
         # ---------------- residual stages ----------------
         n_blocks = len(self._block_meta)
         tfb = self.tf_backbone

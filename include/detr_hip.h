@@ -165,6 +165,9 @@ typedef struct {
     /* bf16 storage of the activation tensors (see detr_gemm_desc.a_dtype): x = the tensor passed as `x`, y = the one passed as `y`
      * (mode 2: x = input activations, `w` = dy whose dtype is w_dtype, y = dw always fp32), r = residual, m = mask */
     int32_t x_dtype, y_dtype, r_dtype, m_dtype;
+    /* ABI 5: bit-packed ReLU masks as in detr_gemm_desc (bf16 tensors only): mode 0 with act = 1 also writes one byte per 8 output
+     * channels, bit = (y > 0), row pitch Co / 8 bytes per pixel; modes 0 / 1 take `mask` as such bytes when m_dtype = 2 */
+    uint8_t *maskbits_out;
 } detr_conv3x3_desc;
 int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, void *stream);
 

@@ -1600,3 +1600,33 @@ def test_gemm_bitpacked_relu_masks(hip, M, N, K, bk, use_res):
     Cf = torch.zeros(M, N, device=DEV)
     with pytest.raises(RuntimeError):
         hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, Cf, N, mask=bits, ldmask=bits.stride(0), compute=1)
+
+
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 19, 45, 64, 1), (1, 25, 70, 128, 1), (2, 24, 40, 128, 2), (1, 13, 42, 512, 1)])
+def test_conv3x3_bitpacked_relu_masks(hip, N, H, W, C, stride):
+    """The 3x3 convolution with bit-packed ReLU masks (round 4): the forward (+ BN shift, ReLU) also writes (y > 0) as one byte per 8
+    channels without changing y; the input gradient takes those bytes instead of the bf16 activation -- bit-identical dx.  Covers the
+    halo-staged kernel (8- and 4-row tiles), the stride-2 class form and the implicit-GEMM tile kernel (stride-2 forward)."""
+    torch.manual_seed(N + H + W + C + stride)
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = b16(_bf(torch.randn(N, H, W, C)))
+    w = b16(_bf(torch.randn(3, 3, C, C) / (3 * C ** 0.5)))
+    shift = g(torch.randn(C) * 0.1)
+    y0 = torch.zeros(N, Ho, Wo, C, device=DEV, dtype=torch.bfloat16)
+    y1 = torch.zeros_like(y0)
+    bits = torch.full((N * Ho * Wo, C // 8), 0x55, device=DEV, dtype=torch.uint8)
+    hip.conv3x3(0, x, w, y0, N, H, W, C, Ho, Wo, C, stride, bias=shift, act=1, compute=1)
+    hip.conv3x3(0, x, w, y1, N, H, W, C, Ho, Wo, C, stride, bias=shift, act=1, compute=1, maskbits_out=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(bits.cpu(), _pack_bits((y1.float() > 0).view(-1, C).cpu()))
+    # input gradient masked by the INPUT activation x (as conv2's dgrad is masked by y1 in the engine): bf16 tensor vs its bits
+    xbits = _pack_bits((x.float() > 0).view(-1, C).cpu()).to(DEV)
+    dy = b16(_bf(torch.randn(N, Ho, Wo, C)))
+    dx0 = torch.zeros(N, H, W, C, device=DEV, dtype=torch.bfloat16)
+    dx1 = torch.zeros_like(dx0)
+    hip.conv3x3(1, dy, w, dx0, N, H, W, C, Ho, Wo, C, stride, mask=x, compute=1)
+    hip.conv3x3(1, dy, w, dx1, N, H, W, C, Ho, Wo, C, stride, mask=xbits, compute=1)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and float(dx0.float().abs().max()) > 0

@@ -331,7 +331,7 @@ def test_bf16_training_curve_tracks_the_fp32_curve(hip):
     flipped assignment moves the loss by a few %), so "bf16 tracks fp32" is stated relative to how far fp32 strays from itself.
     All three curves must fall by more than 40 %; the bf16 curve must stay within 8 % of the fp32 curve at every step and, averaged
     over the second half, no further from it than 1.5 x the fp32-vs-fp32 distance (or 2 % of the loss, whichever is larger).
-    Measured (round 4): second-half mean |bf16 - fp32| = 0.9, see the printed curves."""
+    Measured (round 4, GPUTEST box): second-half mean |bf16 - fp32| = 0.34 against |fp32' - fp32| = 0.72 at a loss of ~30."""
     from detr_tf import training
     from detr_tf.networks.detr import get_detr_model
     from detr_tf.optimizers import setup_optimizers
