@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             const bf16x8 af = __builtin_bit_cast(bf16x8, f[kk]);
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[ws][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+                // BKC: [n][k] rows (+8 bf16 of padding); else the transpose-read image of gemm_bf16_core.h ([4 k][16 n] sub-blocks of
+                // the natural [k][n] orientation): lane (l31, h) receives the 8 consecutive k of column nh * 32 + l31 either way
+                bf16x8 bfr;
+                if constexpr (BKC) bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[ws][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+                else bfr = frag_tr<64>(reinterpret_cast<const unsigned short(*)[8]>(&sm.B[ws][0][0]), nh * 32, chunk * KC + kk * 16, lane);
                 if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(bfr); ablate_keep(af); }
                 else acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
             }
@@ -270,15 +274,14 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
             *reinterpret_cast<uint4 *>(&sm.B[n >> 6][n & 63][kc * 8]) = v;
         }
     } else {
+        // [k][n] weights keep their orientation: 16-byte chunk (k, 8 columns) -> sub-block (k / 4, n / 16) of the transpose-read image,
+        // ONE 16-byte LDS store (round 3 scattered it into [n][k] with eight 2-byte stores: ~8 us of a 39 us K = 256 launch)
         for (int c = tid; c < K * 8 * SL; c += 256) {
             const int k = c / (8 * SL), nc = c - k * (8 * SL);
             const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + g0 + nc * 8);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sm.B[nc >> 3][(nc & 7) * 8 + 2 * i][k] = (unsigned short)(w[i] & 0xFFFFu);
-                sm.B[nc >> 3][(nc & 7) * 8 + 2 * i + 1][k] = (unsigned short)(w[i] >> 16);
-            }
+            const int ncl = nc & 7;
+            unsigned short *img = &sm.B[nc >> 3][0][0];
+            *reinterpret_cast<uint4 *>(img + (((k >> 2) * 4 + (ncl >> 1)) * 64 + (k & 3) * 16 + (ncl & 1) * 8)) = v;
         }
     }
     __syncthreads();

@@ -72,6 +72,9 @@ for w in "$@"; do
           python scripts/prof_timeline.py $OUT/proftlg/prof_results.db 1 > $OUT/timeline_graph.txt 2>&1; head -3 $OUT/timeline_graph.txt; rm -rf $OUT/proftlg ;;
     phases) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-leg --no-configs --no-kernel-events --launch ${PH_LAUNCH:-eager} --phase-events > $OUT/phases.log 2>&1; echo "phases rc=$?" >> $OUT/summary.txt
           tail -1 $OUT/phases.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step']); print(json.dumps(d['phases_ms'], indent=1))" ;;
+    pmc32) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp DETR_HIP_WGRAD_STREAM=0 && timeout 900 rocprofv3 --pmc $c -d /root/repo/$OUT/pmc_$c -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision fp32 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/pmc32_$c.log 2>&1); echo "pmc32 $c rc=$?" >> $OUT/summary.txt; done
+          python scripts/pmc_summary.py $OUT gemm_f32 $OUT/traffic_fp32.json > $OUT/pmc_hbm_fp32_summary.txt 2>&1; head -30 $OUT/pmc_hbm_fp32_summary.txt | cut -c1-170; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
+    benchfull) timeout 1200 python bench.py --dump-shapes $OUT/shapes.json --phase-events > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/summary.txt; tail -1 $OUT/bench.log > $OUT/bench_line.json; tail -1 $OUT/bench.log | cut -c1-2500 ;;
     tests_r4) timeout 1800 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --maxfail=12 -s > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; grep -E "^\[|passed|failed|FAILED|Error" $OUT/tests.log | cut -c1-400 | tail -60 ;;
     *) echo "unknown $w" ;;
   esac
