@@ -366,6 +366,16 @@ __device__ __forceinline__ void sgb_mfma_block() {       // MF MFMAs, each follo
     }
 }
 
+// steps 2 .. NS-1 of a pipelined K tile: [reads of the next step] [MF MFMAs], the last step without reads
+template <int LEFT, int READS, int MF>
+__device__ __forceinline__ void sgb_tail() {
+    if constexpr (LEFT > 0) {
+        if constexpr (LEFT > 1) sgb_ds_read<READS>();
+        sgb_mfma_block<MF, 0, 0, 0>();
+        sgb_tail<LEFT - 1, READS, MF>();
+    }
+}
+
 // one BK-deep K tile: BK / 16 k-steps of v_mfma_f32_32x32x16_bf16 per 32x32 output tile.
 // operand map: lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31].
 template <int BM, int BN, int WGM, int WGN, bool ATR = false, bool BTR = false, int BK = BF_BK>

@@ -210,7 +210,7 @@ static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk, bool deep = false) {
+static int launch_cfg_bf16(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk, int deep = 0) {
     GemmArgs a = g;
     a.tiles_m = cdiv(g.M, BM);
     a.tiles_n = cdiv(g.N, BN);
@@ -249,7 +249,8 @@ using namespace detr;
 struct GemmPlan {
     GemmArgs g;
     int batch, split;
-    bool ak, bk, bf16c, partial, deep;
+    bool ak, bk, bf16c, partial;
+    int deep;                 // K-tile depth of the all-bf16 variants: 0 = 32, 1 = 64, 2 = 128 (64x64 tiles only)
     int tile;                 // 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64
     long long part;           // floats per split slab (row-major: M*N; tile-ordered: the padded tile grid)
     int ts_bm, ts_bn, ts_tn;  // tile-ordered slabs (0: row-major)
@@ -272,7 +273,10 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
         // round 3, cold-cache sweeps (scripts/micro_wgrad.py, micro_gemm.py --cold; profiles/r03_micro_*): the layer4 weight
         // gradients (M, N >= 512, K = 8400) gain 15-25 % on 128x128 tiles (512x2048: 64 -> 53 us, 1024x2048: 109 -> 80), and so do
         // the wide K = 512 GEMMs of layer3's first block (M33600 N1024: 100 -> 89 us, with residual + mask 163 -> 151)
-        const bool big_split = (d->N >= 128 && d->K >= 16384) || (d->M >= 512 && d->N >= 512 && d->K >= 4096);
+        // round 4 (scripts/experiments/tile_force.sh): the encoder's FFN weight-gradient pair (256 x 2048 and 2048 x 256 outputs, K = 8400)
+        // 54.7 us as one grouped launch of 64x64 tiles -> 45.3 us as two launches of 128x128 tiles
+        const bool big_split = (d->N >= 128 && d->K >= 16384) || (d->M >= 512 && d->N >= 512 && d->K >= 4096) ||
+                               (d->K >= 4096 && ((d->M >= 256 && d->N >= 2048) || (d->M >= 2048 && d->N >= 256)));
         const bool big_plain = (d->K >= 1024 && t128 >= 512) || (d->K >= 512 && d->N >= 512 && t128 >= 1024);
         const bool small = (split > 1) ? !big_split : !big_plain;
         if (force == 2) tile = 2;
@@ -459,8 +463,8 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
     {
         const int k64 = tune(T_GEMM_K64);
         const int per_split = cdiv(d->K, split);
-        p.deep = bf16c && g.a16 && g.b16 && (tile == 0 || tile == 1) && k64 != 2 &&
-                 (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)));
+        p.deep = (bf16c && g.a16 && g.b16 && (tile == 0 || tile == 1) && k64 != 2 &&
+                  (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)))) ? 1 : 0;
     }
     p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
     p.part = part; p.final_e = final_e; p.d = d;

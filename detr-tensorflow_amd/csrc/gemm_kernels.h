@@ -325,21 +325,22 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
             else la.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpa);
             if constexpr (B16) lb.load_tile(kbeg + (kt + 1 + DEPTH) * BK, kend, rpb);
             else lb.load(kbeg + (kt + 1 + DEPTH) * BK, kend, rpb);
-            if constexpr (P::NS > 2) {
-                P::read(sm.A[cur], sm.B[cur], 48, wm, wn, lane, f1);
-                P::mma(f0, acc);
-                P::mma(f1, acc);
+            // steps 2 .. NS-1: fragments of step s+1 are read before the MFMAs of step s (two sets, alternating)
+#pragma unroll
+            for (int st = 2; st < P::NS; ++st) {
+                if (st + 1 < P::NS) {
+                    if (st & 1) P::read(sm.A[cur], sm.B[cur], 16 * (st + 1), wm, wn, lane, f0);
+                    else P::read(sm.A[cur], sm.B[cur], 16 * (st + 1), wm, wn, lane, f1);
+                }
+                if (st & 1) P::mma(f1, acc);
+                else P::mma(f0, acc);
             }
             constexpr int NW = LA::NDSW + LB::NDSW, NG = LA::NVMEM + LB::NVMEM;
             sgb_ds_read<2 * P::READS>();
             sgb_mfma_block<P::MF, NW, 0, 0>();                 // step 0 + the next tile's LDS stores
             if constexpr (P::NS > 2) sgb_ds_read<P::READS>();
             sgb_mfma_block<P::MF, 0, NG, 3 * NG>();            // step 1 + the requests of the tile after next (3 VALU per offset)
-            if constexpr (P::NS > 2) {
-                sgb_ds_read<P::READS>();
-                sgb_mfma_block<P::MF, 0, 0, 0>();
-                sgb_mfma_block<P::MF, 0, 0, 0>();
-            }
+            sgb_tail<P::NS - 2, P::READS, P::MF>();
             lds_barrier();
             return;
         }
@@ -393,6 +394,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 2 : 4) void 
     gemm_work_item(g, tile, z);
     gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, true, true, 64>(g, tile, z);
 }
+// (Round 4 measured a 128-deep K tile for the 64x64-tile launches with K >= 1024 -- half the barrier-separated iterations, 70 KB of
+//  LDS, 2 workgroups per CU; bit-identical: M8400 N256 K2048 34.7 -> 40.2 us, M8400 N512 K2048 42.3 -> 50.3 us.  Not kept: these
+//  launches are bound by the bytes their tiles pull out of L2, not by the number of iterations -- DESIGN 7c.)
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MINW : 1) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
     int m, tile, z;

@@ -558,7 +558,8 @@ SPLIT_TARGET_64 = int(os.environ.get("DETR_HIP_SPLIT_TARGET64", "1024"))
 
 def pick_split_k(M, N, K, max_split=1024):
     """Reduction-heavy GEMMs (weight gradients): split K so that enough workgroups exist to fill 256 CUs."""
-    if COMPUTE_BF16 and ((N >= 128 and K >= 16384) or (M >= 512 and N >= 512 and K >= 4096)):   # 128x128 tiles (gemm_f32.hip), ~512 workgroups
+    if COMPUTE_BF16 and ((N >= 128 and K >= 16384) or (M >= 512 and N >= 512 and K >= 4096) or
+                         (K >= 4096 and ((M >= 256 and N >= 2048) or (M >= 2048 and N >= 256)))):   # 128x128 tiles (gemm_f32.hip: gemm_pick_tile)
         tiles = -(-M // 128) * -(-N // 128)
         ktiles = -(-K // 32)
         return int(max(1, min(max(1, SPLIT_TARGET_128 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
