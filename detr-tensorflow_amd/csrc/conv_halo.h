@@ -124,6 +124,18 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
     }
 }
 
+// Kernel tile of the input-gradient form ([n = ci][k = co], k contiguous, 32 k = four 16-byte chunks per row): UNPADDED 64-byte rows with
+// the chunk index XOR-swizzled by (row >> 2) & 3.  The padded 80-byte rows of the GEMM engine make the fragment reads conflict-free but
+// not the stores (the 8 lanes of a ds_write_b128 group cover two rows whose first slots share a bank: SQ_LDS_BANK_CONFLICT 0.12 of the CU
+// cycles in the dgrad launches against 0.04 forward); with the swizzle both are conflict-free (enumerated against the bank model of
+// MI355X_MICROARCH.md: ds_read_b128 groups of 16 lanes over 64 banks, ds_write_b128 groups of 8 lanes over 32).
+__device__ __forceinline__ int halo_bsw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }      // in shorts
+template <int BN>
+__device__ __forceinline__ void halo_store_b_swz(unsigned short *flat, const uint4 (&r)[BN / 64], int tid) {
+#pragma unroll
+    for (int i = 0; i < BN / 64; ++i) *reinterpret_cast<uint4 *>(flat + halo_bsw((tid >> 2) + 64 * i, tid & 3)) = r[i];
+}
+
 // ConvArgs as for conv3x3_bf16c_kernel (stride 1, pad 1, bf16 src / w / dst); Hp / Wp carry the tile counts along H / W.
 // S2C: the four pixel-parity classes (ph, pw) of the STRIDE-2 input gradient in one launch (ConvArgs.cls_*).  dx[2 h2 + ph, 2 w2 + pw] only receives the taps kh = ph + 1
 // (mod 2), kw = pw + 1 (mod 2), reading dy[h2 + dh, w2 + dw] with dh, dw in {0, 1}: a stride-1 "2 x 2" convolution over dy in class
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
             for (int ni = 0; ni < T::TN; ++ni) {
                 if constexpr ((DETR_ABLATE & 16) != 0) fb[ni] = __builtin_bit_cast(bf16x8, make_uint4(lane, ni, ks, 0x3f803f80u));
                 else if (!DGRAD) fb[ni] = frag_tr<BN>(Bs, wn * T::WTN + ni * 32, ks, lane);
-                else fb[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[wn * T::WTN + ni * 32 + l31][ks + kh8]);
+                else fb[ni] = *reinterpret_cast<const bf16x8 *>(&Bs[0][0] + halo_bsw(wn * T::WTN + ni * 32 + l31, (ks + kh8) >> 3));
             }
 #pragma unroll
             for (int mi = 0; mi < T::TM; ++mi)
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
     patch_load(0, rp);
     b_load(0, 0, rb0);
     patch_store(0, rp);
-    lb.store(sm.B[0], rb0);
+    if constexpr (DGRAD) halo_store_b_swz<BN>(&sm.B[0][0][0], rb0, tid); else lb.store(sm.B[0], rb0);
     patch_load(1, rp);
     b_load(0, 1, rb0);
     b_load(0, 2, rb1);
@@ -267,11 +279,11 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
             const int cur = (PAR + tp) & 1;
             // kernel tile of the next step: register set `cur ^ PAR ...` -- step parity decides the set, statically
             if (((PAR + tp) & 1) == 0) {
-                if constexpr ((DETR_ABLATE & 4) == 0) lb.store(sm.B[cur ^ 1], rb0);
+                if constexpr ((DETR_ABLATE & 4) == 0) { if constexpr (DGRAD) halo_store_b_swz<BN>(&sm.B[cur ^ 1][0][0], rb0, tid); else lb.store(sm.B[cur ^ 1], rb0); }
                 else for (int i = 0; i < NRB; ++i) ablate_keep(rb0[i]);
                 if constexpr ((DETR_ABLATE & 2) == 0) b_load(c + (tp + 3) / 9, (tp + 3) % 9, rb0);
             } else {
-                if constexpr ((DETR_ABLATE & 4) == 0) lb.store(sm.B[cur ^ 1], rb1);
+                if constexpr ((DETR_ABLATE & 4) == 0) { if constexpr (DGRAD) halo_store_b_swz<BN>(&sm.B[cur ^ 1][0][0], rb1, tid); else lb.store(sm.B[cur ^ 1], rb1); }
                 else for (int i = 0; i < NRB; ++i) ablate_keep(rb1[i]);
                 if constexpr ((DETR_ABLATE & 2) == 0) b_load(c + (tp + 3) / 9, (tp + 3) % 9, rb1);
             }
@@ -293,10 +305,12 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
         for (int tp = 0; tp < 4; ++tp) {
             const int cur = tp & 1;
             if ((tp & 1) == 0) {
-                lb.store(sm.B[cur ^ 1], rb0);
+                if constexpr (DGRAD) halo_store_b_swz<BN>(&sm.B[cur ^ 1][0][0], rb0, tid);        // (the class form is an input gradient)
+                else lb.store(sm.B[cur ^ 1], rb0);
                 b_load(c + (tp + 3) / 4, (tp + 3) % 4, rb0);
             } else {
-                lb.store(sm.B[cur ^ 1], rb1);
+                if constexpr (DGRAD) halo_store_b_swz<BN>(&sm.B[cur ^ 1][0][0], rb1, tid);
+                else lb.store(sm.B[cur ^ 1], rb1);
                 b_load(c + (tp + 3) / 4, (tp + 3) % 4, rb1);
             }
             if (tp == 0) {
