@@ -1630,3 +1630,56 @@ def test_conv3x3_bitpacked_relu_masks(hip, N, H, W, C, stride):
     hip.conv3x3(1, dy, w, dx1, N, H, W, C, Ho, Wo, C, stride, mask=xbits, compute=1)
     torch.cuda.synchronize()
     assert torch.equal(dx0, dx1) and float(dx0.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("compute", [0, 1])
+@pytest.mark.parametrize("M,N,K,split,rowsum", [(256, 1024, 4096, 8, False), (100, 92, 2048, 5, True), (200, 136, 33 * 64, 16, True), (64, 256, 8192, 12, False)])
+def test_tile_ordered_split_k_slabs_equal_row_major_slabs(hip, compute, M, N, K, split, rowsum):
+    """Round 4: split-K partials stored in MFMA register order (tile-ordered slabs, padded to whole tiles) and un-permuted by the reduce
+    launch must give the SAME BITS as row-major slabs (DETR_HIP_SLAB_TS=2) -- fp32 and bf16 compute, ragged outputs, the fused bias
+    gradient riding behind the slabs, 64x64 / 128x128 / 64x128 tiles -- and the 3x3 weight-gradient kernels likewise."""
+    hip.ensure_workspace(DEV)
+    torch.manual_seed(M + N + K + compute)
+    dt = torch.bfloat16 if (compute and M % 8 == 0 and N % 8 == 0) else torch.float32      # (bf16 storage needs 16-byte rows)
+    A = g(_bf(torch.randn(K, M)).float()).to(dt)     # weight-gradient layout: both operands reduction-major
+    Bm = g(_bf(torch.randn(K, N) / K ** 0.5).float()).to(dt)
+    scale = g(torch.rand(N) + 0.5)
+    outs = []
+    for mode in (None, 2):
+        hip.set_tuning("DETR_HIP_SLAB_TS", mode)
+        try:
+            C = torch.full((M, N), 0.25, device=DEV)
+            rs = torch.zeros(M, device=DEV) if rowsum else None
+            hip.gemm(M, N, K, A, M, 0, Bm, N, 0, C, N, alpha=0.5, scale=scale, split_k=split, compute=compute, rowsum_a=rs)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning("DETR_HIP_SLAB_TS", None)
+        outs.append((C.cpu(), None if rs is None else rs.cpu()))
+    (c_ts, r_ts), (c_rm, r_rm) = outs
+    assert torch.equal(c_ts, c_rm), float((c_ts - c_rm).abs().max())
+    if rowsum:
+        assert torch.equal(r_ts, r_rm)
+    want = 0.25 + 0.5 * scale.cpu().double() * (A.double().cpu().t() @ Bm.double().cpu())
+    assert float((c_ts.double() - want).abs().max()) < (2e-2 if compute else 1e-4) * float(want.abs().max())
+
+
+@pytest.mark.parametrize("C,stride", [(64, 1), (128, 1), (128, 2)])
+def test_conv3x3_wgrad_tile_ordered_slabs_equal_row_major(hip, C, stride):
+    hip.ensure_workspace(DEV)
+    torch.manual_seed(C + stride)
+    N, H, W = 2, 23, 40
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = g(torch.randn(N, H, W, C)).to(torch.bfloat16)
+    dy = g(torch.randn(N, Ho, Wo, C)).to(torch.bfloat16)
+    scale = g(torch.rand(C) + 0.5)
+    outs = []
+    for mode in (None, 2):
+        hip.set_tuning("DETR_HIP_SLAB_TS", mode)
+        try:
+            dw = torch.zeros(3, 3, C, C, device=DEV)
+            hip.conv3x3(2, x, dy, dw, N, H, W, C, Ho, Wo, C, stride, scale=scale, split=6, compute=1)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning("DETR_HIP_SLAB_TS", None)
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
