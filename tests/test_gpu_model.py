@@ -429,6 +429,9 @@ def test_finetune_heads_and_inference(hip):
     assert tuple(hs.shape) == (2, 1, 100, 256)
 
 
+C2_TOL = 2e-5      # measured (round 4): logits 1.3e-6, boxes 7.8e-7 of the tensor scale, loss identical to 7 digits
+
+
 @pytest.fixture(scope="module")
 def c2_ref():
     """The fp32 oracle at BASELINE config C2 / C3's shape (B=8, 800x1333, Q=100, 92 logits), computed once."""
@@ -458,9 +461,13 @@ def test_c2_full_size_forward_loss_parity(hip, c2_ref):
     total, log = get_losses(out, c2_ref["t_bbox"], c2_ref["t_class"], cfg)
     ref, ref_total = c2_ref["ref"], c2_ref["ref_total"]
     assert tuple(out["pred_logits"].shape) == (8, 100, 92)
-    assert _rel(out["pred_logits"], ref["pred_logits"]) < 1e-3
-    assert _rel(out["pred_boxes"], ref["pred_boxes"]) < 1e-3
-    assert abs(float(total) - ref_total) <= 1e-3 * abs(ref_total), (float(total), ref_total)
+    e_logits, e_boxes = _rel(out["pred_logits"], ref["pred_logits"]), _rel(out["pred_boxes"], ref["pred_boxes"])
+    e_loss = abs(float(total) - ref_total) / abs(ref_total)
+    print(f"[c2 parity] logits {e_logits:.2e} boxes {e_boxes:.2e} loss {e_loss:.2e}")
+    # exact-f32 MFMA against the oracle's CPU kernels: the only difference is the summation order.  SURVEY 4 allows 1e-4; the bound is
+    # 15x the measured level, 50x tighter than round 3's 1e-3
+    assert e_logits < C2_TOL and e_boxes < C2_TOL, (e_logits, e_boxes)
+    assert e_loss <= 1e-4, (float(total), ref_total)          # north_star: loss within 1e-3 relative
 
 
 def test_c3_bf16_full_shape_forward_loss_vs_fp32_oracle(hip, c2_ref):
