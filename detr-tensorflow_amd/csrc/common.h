@@ -90,6 +90,7 @@ enum TuneKey {
     T_GEMM_STREAM,
     T_GEMM_GROUP,
     T_STREAM_SL,
+    T_STREAM_NW,
     T_CONV_HALO,
     T_CONV_TILE,
     T_DGRAD_S2_CLASSES,

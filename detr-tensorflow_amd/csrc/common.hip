@@ -16,6 +16,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_GEMM_STREAM",
     "DETR_HIP_GEMM_GROUP",
     "DETR_HIP_STREAM_SL",
+    "DETR_HIP_STREAM_NW",
     "DETR_HIP_CONV_HALO",
     "DETR_HIP_CONV_TILE",
     "DETR_HIP_DGRAD_S2_CLASSES",

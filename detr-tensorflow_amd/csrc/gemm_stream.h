@@ -69,10 +69,15 @@ constexpr int STREAM_LD = 68;                      // floats per staged row (64 
 // instead of once per slice.  (Measured: the kernel's time is proportional to the number of slice-strips -- M534400 K64:
 // 33 us for N = 64 at 6.2 TB/s, 131 us for N = 256 -- i.e. the A rows re-read from L2 by the other slices cost as much as
 // HBM bytes; scripts/experiments/stream_stride_probe.py.)
-template <int K, int SL>
+// NW = column slices per WAVE (round 4, K = 256 only): a wave multiplies the A rows it holds with two resident slices (four MFMAs per
+// A fragment instead of two) -- the row-per-lane A requests (32 rows x 32 bytes per wave instruction, one line lookup per row) are what a
+// K = 256 launch with 16-32 column slices spends a third of its time on (profiles/r04_ab_results.txt #15) -- in workgroups of 8 waves
+// (2 x 34 KB of B + 8 strips of staging = 137 KB: one workgroup per CU, the same 8 waves per CU as two 4-wave workgroups before).
+template <int K, int SL, int NW = 1>
 struct StreamSmem {
-    unsigned short B[SL][64][K + 8];               // [slice][n][k], +8 bf16 of padding: 16-byte fragment reads spread over the banks
-    float stage[4][32][STREAM_LD];                 // one 32 x 64 fp32 strip per wave
+    static constexpr int WAVES = (NW > 1 && K * NW * SL >= 512) ? 8 : 4;      // 8 waves where four strips of staging would leave one 4-wave workgroup per CU
+    unsigned short B[SL * NW][64][K + 8];          // [slice][n][k], +8 bf16 of padding: 16-byte fragment reads spread over the banks
+    float stage[WAVES][32][STREAM_LD];             // one 32 x 64 fp32 strip per wave
 };
 
 __device__ __forceinline__ void stream_unpack8(uint4 r, float (&o)[8]) {
@@ -83,21 +88,22 @@ __device__ __forceinline__ void stream_unpack8(uint4 r, float (&o)[8]) {
 }
 
 // workgroups per CU that fit the 160 KB of LDS (at most 3: 12 waves / CU already keep > 100 KB of requests in flight)
-template <int K, int SL>
+template <int K, int SL, int NW = 1>
 struct StreamOcc {
-    static constexpr int BYTES = (int)sizeof(StreamSmem<K, SL>);
+    static constexpr int BYTES = (int)sizeof(StreamSmem<K, SL, NW>);
     static constexpr int VALUE = (3 * BYTES <= 160 * 1024) ? 3 : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
 };
 
 // MASK: 0 none, 1 a bf16 tensor, 2 bit-packed (one byte per 8 columns)
-template <int K, bool BKC, bool RES, int MASK, int SL = 1, bool EXT = false>
-__global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
-    constexpr int WPS = 4 / SL;                    // row walkers (waves per slice) of a workgroup
+template <int K, bool BKC, bool RES, int MASK, int SL = 1, bool EXT = false, int NW = 1>
+__global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, SL, NW>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
+    constexpr int WAVES = StreamSmem<K, SL, NW>::WAVES, THREADS = 64 * WAVES;
+    constexpr int WPS = WAVES / SL;                // row walkers (waves per slice group) of a workgroup
     constexpr int KC = (K > 128) ? 128 : K;       // A rows are held in registers one K chunk (<= 128) at a time
     constexpr int NC = K / KC;                     // chunks per strip: 1, or an even number
     constexpr int KK = KC / 16;                    // MFMA k-steps per chunk
     static_assert(K % KC == 0 && (NC == 1 || NC % 2 == 0), "gemm_stream: K must be 64, 128 or a multiple of 256");
-    __shared__ __attribute__((aligned(16))) StreamSmem<K, SL> sm;
+    __shared__ __attribute__((aligned(16))) StreamSmem<K, SL, NW> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup id -> (XCD, column slice, walker): ids are dealt round-robin over the 8 XCDs, so the n_tiles slices of
     // one walker p are consecutive multiples of 8 apart -- same XCD, dispatched together, same A rows
@@ -105,15 +111,17 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     const int xcd = id & 7, j = id >> 3;
     const int nt = j % a.n_tiles, p = (j / a.n_tiles) * 8 + xcd;      // n_tiles = slice GROUPS of SL slices
     const int ws = wave % SL, wr = wave / SL;      // this wave's slice inside the group, its row walker
-    const int n0 = (nt * SL + ws) * 64;
+    const int n0 = (nt * SL + ws) * NW * 64;       // first column of this wave's NW slices
     const int stride = a.q * 8 * WPS;              // wave slots per column slice
 
     // ---- per-lane constants ----------------------------------------------------------------------------------------------
     const int l31 = lane & 31, h = lane >> 5;
     const int erow = lane >> 3, ecg = lane & 7;    // epilogue item: 8 rows x 8 column groups of 8
-    float bias[8];
+    float bias[NW][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = a.bias ? a.bias[n0 + ecg * 8 + i] : 0.0f;
+    for (int sw = 0; sw < NW; ++sw)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bias[sw][i] = a.bias ? a.bias[n0 + sw * 64 + ecg * 8 + i] : 0.0f;
     BufSrc srcA, srcR, srcM;
     srcA.init_bytes(a.A, ((long long)(a.M - 1) * a.lda + K) * 2);
     if (RES) srcR.init_bytes(a.res, ((long long)(a.M - 1) * a.ldr + a.N) * 2);
@@ -131,19 +139,20 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
         for (int kk = 0; kk < KK; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
     };
     // D^T[n][m] += sum_k B^T[n][k] A^T[k][m] over one chunk: lane&31 = m, accumulator r -> n = (r&3) + 8*(r>>2) + 4*h (+32*nh)
-    auto mma = [&](const uint4 (&f)[KK], int chunk, f32x16 (&acc)[2]) {
+    auto mma = [&](const uint4 (&f)[KK], int chunk, f32x16 (&acc)[2 * NW]) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const bf16x8 af = __builtin_bit_cast(bf16x8, f[kk]);
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
+            for (int nq = 0; nq < 2 * NW; ++nq) {
+                const int nh = nq & 1, bs = ws * NW + (nq >> 1);
                 // BKC: [n][k] rows (+8 bf16 of padding); else the transpose-read image of gemm_bf16_core.h ([4 k][16 n] sub-blocks of
                 // the natural [k][n] orientation): lane (l31, h) receives the 8 consecutive k of column nh * 32 + l31 either way
                 bf16x8 bfr;
-                if constexpr (BKC) bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[ws][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
-                else bfr = frag_tr<64>(reinterpret_cast<const unsigned short(*)[8]>(&sm.B[ws][0][0]), nh * 32, chunk * KC + kk * 16, lane);
+                if constexpr (BKC) bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[bs][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+                else bfr = frag_tr<64>(reinterpret_cast<const unsigned short(*)[8]>(&sm.B[bs][0][0]), nh * 32, chunk * KC + kk * 16, lane);
                 if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(bfr); ablate_keep(af); }
-                else acc[nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nh], 0, 0, 0);
+                else acc[nq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nq], 0, 0, 0);
             }
         }
     };
@@ -155,22 +164,24 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     // a_first again.
     auto strip = [&](const int rt, uint4 (&a_first)[KK], uint4 (&a_other)[KK]) {
         const int r0 = rt * 32;
-        uint4 rres[4], rmsk[4];
+        uint4 rres[NW][4], rmsk[NW][4];
+#pragma unroll
+        for (int sw = 0; sw < NW; ++sw)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = r0 + it * 8 + erow;
-            const unsigned colb = (unsigned)((n0 + ecg * 8) * 2);
+            const unsigned colb = (unsigned)((n0 + sw * 64 + ecg * 8) * 2);
             const bool ep_live = (DETR_ABLATE & 32) == 0;               // ablation bit 5: no residual / mask requests
-            if (RES) rres[it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
-            if (MASK == 1) rmsk[it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            if (RES) rres[sw][it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
+            if (MASK == 1) rmsk[sw][it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
             if (MASK == 2)      // one byte = the 8 columns of this lane; the 8 lanes of a row read 8 consecutive bytes
-                rmsk[it].x = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(srcM.rsrc, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm) + (unsigned)((n0 >> 3) + ecg) : BUF_OOB, 0, 0);
+                rmsk[sw][it].x = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(srcM.rsrc, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm) + (unsigned)(((n0 + sw * 64) >> 3) + ecg) : BUF_OOB, 0, 0);
         }
-        f32x16 acc[2];
+        f32x16 acc[2 * NW];
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+        for (int nq = 0; nq < 2 * NW; ++nq)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nh][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[nq][r] = 0.0f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool last = (c + 1 == NC);
@@ -182,83 +193,86 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
                 mma(a_other, c, acc);
             }
         }
-        // ---- wave-private transposition: quads of 4 consecutive columns -> rows of 8 consecutive columns per lane
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+        for (int sw = 0; sw < NW; ++sw) {
+            // ---- wave-private transposition: quads of 4 consecutive columns -> rows of 8 consecutive columns per lane
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4 *>(stage + l31 * STREAM_LD + nh * 32 + 8 * g + 4 * h) =
-                    make_float4(acc[nh][4 * g], acc[nh][4 * g + 1], acc[nh][4 * g + 2], acc[nh][4 * g + 3]);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = it * 8 + erow;
-            const int row = r0 + rl;
-            const float4 v0 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8);
-            const float4 v1 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8 + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(stage + l31 * STREAM_LD + nh * 32 + 8 * g + 4 * h) =
+                        make_float4(acc[2 * sw + nh][4 * g], acc[2 * sw + nh][4 * g + 1], acc[2 * sw + nh][4 * g + 2], acc[2 * sw + nh][4 * g + 3]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += bias[i];
-            bool keep[8];
-            if constexpr (EXT) {
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 8 + erow;
+                const int row = r0 + rl;
+                const float4 v0 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8);
+                const float4 v1 = *reinterpret_cast<const float4 *>(stage + rl * STREAM_LD + ecg * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= a.alpha;
-                if (a.drop_scale != 0.0f) {        // one hash per element pair (common.h); this lane's 8 columns start at an even index
-                    const unsigned long long pair0 = ((unsigned long long)row * (unsigned long long)a.N + (unsigned)(n0 + ecg * 8)) >> 1;
+                for (int i = 0; i < 8; ++i) v[i] += bias[sw][i];
+                bool keep[8];
+                if constexpr (EXT) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t hh = drop_hash(dkey, pair0 + j);
-                        keep[2 * j] = (hh & 0xFFFFu) >= a.drop_thresh;
-                        keep[2 * j + 1] = (hh >> 16) >= a.drop_thresh;
+                    for (int i = 0; i < 8; ++i) v[i] *= a.alpha;
+                    if (a.drop_scale != 0.0f) {        // one hash per element pair (common.h); this lane's 8 columns start at an even index
+                        const unsigned long long pair0 = ((unsigned long long)row * (unsigned long long)a.N + (unsigned)(n0 + sw * 64 + ecg * 8)) >> 1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t hh = drop_hash(dkey, pair0 + j);
+                            keep[2 * j] = (hh & 0xFFFFu) >= a.drop_thresh;
+                            keep[2 * j + 1] = (hh >> 16) >= a.drop_thresh;
+                        }
+                        if (RES) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
+                        }
                     }
-                    if (RES) {
+                }
+                if (RES) {
+                    float r[8];
+                    stream_unpack8(rres[sw][it], r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += r[i];
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+                }
+                if constexpr (EXT) {
+                    if (!RES && a.drop_scale != 0.0f) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
                     }
                 }
-            }
-            if (RES) {
-                float r[8];
-                stream_unpack8(rres[it], r);
+                if (MASK == 1) {
+                    float m[8];
+                    stream_unpack8(rmsk[sw][it], m);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += r[i];
-            }
-            if (a.act == 1) {
+                    for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
+                }
+                if (MASK == 2) {
+                    const unsigned mb = rmsk[sw][it].x;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
-            }
-            if constexpr (EXT) {
-                if (!RES && a.drop_scale != 0.0f) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = keep[i] ? v[i] * a.drop_scale : 0.0f;
+                    for (int i = 0; i < 8; ++i) v[i] = ((mb >> i) & 1u) ? v[i] : 0.0f;
+                }
+                if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f)) {    // ablation bit 6: no output stores
+                    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+                    const u32x4v ov = {f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7])};
+                    u32x4v *dstp = reinterpret_cast<u32x4v *>(a.C + (long long)row * a.ldc + n0 + sw * 64 + ecg * 8);
+#if DETR_STREAM_NT & 2
+                    __builtin_nontemporal_store(ov, dstp);
+#else
+                    *dstp = ov;
+#endif
+                    if (a.mbits_out) a.mbits_out[(long long)row * a.ld_mbits + (((n0 + sw * 64) >> 3) + ecg)] = (unsigned char)bf16x8_gt0_bits(ov[0], ov[1], ov[2], ov[3]);
                 }
             }
-            if (MASK == 1) {
-                float m[8];
-                stream_unpack8(rmsk[it], m);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = (m[i] > 0.0f) ? v[i] : 0.0f;
-            }
-            if (MASK == 2) {
-                const unsigned mb = rmsk[it].x;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = ((mb >> i) & 1u) ? v[i] : 0.0f;
-            }
-            if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f)) {    // ablation bit 6: no output stores
-                typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-                const u32x4v ov = {f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7])};
-                u32x4v *dstp = reinterpret_cast<u32x4v *>(a.C + (long long)row * a.ldc + n0 + ecg * 8);
-#if DETR_STREAM_NT & 2
-                __builtin_nontemporal_store(ov, dstp);
-#else
-                *dstp = ov;
-#endif
-                if (a.mbits_out) a.mbits_out[(long long)row * a.ld_mbits + ((n0 >> 3) + ecg)] = (unsigned char)bf16x8_gt0_bits(ov[0], ov[1], ov[2], ov[3]);
-            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     };
 
     int rt = p * WPS + wr;
@@ -266,9 +280,9 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     load_a(rt, 0, a0);                             // first A rows: in flight while the B slice is staged
 
     // ---- prologue: B slice -> LDS as [n][k] (the only workgroup barrier of the kernel) ---------------------------
-    const int g0 = nt * SL * 64;                   // first column of the group
+    const int g0 = nt * SL * NW * 64;              // first column of the group
     if (BKC) {
-        for (int c = tid; c < SL * 64 * (K / 8); c += 256) {
+        for (int c = tid; c < SL * NW * 64 * (K / 8); c += THREADS) {
             const int n = c / (K / 8), kc = c - n * (K / 8);
             const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)(g0 + n) * a.ldb + kc * 8);
             *reinterpret_cast<uint4 *>(&sm.B[n >> 6][n & 63][kc * 8]) = v;
@@ -276,8 +290,8 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
     } else {
         // [k][n] weights keep their orientation: 16-byte chunk (k, 8 columns) -> sub-block (k / 4, n / 16) of the transpose-read image,
         // ONE 16-byte LDS store (round 3 scattered it into [n][k] with eight 2-byte stores: ~8 us of a 39 us K = 256 launch)
-        for (int c = tid; c < K * 8 * SL; c += 256) {
-            const int k = c / (8 * SL), nc = c - k * (8 * SL);
+        for (int c = tid; c < K * 8 * SL * NW; c += THREADS) {
+            const int k = c / (8 * SL * NW), nc = c - k * (8 * SL * NW);
             const uint4 v = *reinterpret_cast<const uint4 *>(a.B + (long long)k * a.ldb + g0 + nc * 8);
             const int ncl = nc & 7;
             unsigned short *img = &sm.B[nc >> 3][0][0];
@@ -298,19 +312,20 @@ __global__ __launch_bounds__(256, (StreamOcc<K, SL>::VALUE)) void gemm_stream_bf
 }
 
 // Host side: eligibility is decided by the caller (gemm_f32.hip); here the slice grouping and the grid.
-template <int K, int SL, bool EXT = false>
+template <int K, int SL, bool EXT = false, int NW = 1>
 static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s, bool mask_bits = false) {
-    a.n_tiles = a.N / (64 * SL);
+    constexpr int WAVES = StreamSmem<K, SL, NW>::WAVES;
+    a.n_tiles = a.N / (64 * SL * NW);
     a.row_tiles = (a.M + 31) / 32;
-    const int wgs_per_cu = StreamOcc<K, SL>::VALUE;
+    const int wgs_per_cu = StreamOcc<K, SL, NW>::VALUE;
     int q = (256 * wgs_per_cu) / (8 * a.n_tiles);
-    const int qmax = a.row_tiles / (8 * (4 / SL) * 2);          // at least two strips per wave
+    const int qmax = a.row_tiles / (8 * (WAVES / SL) * 2);      // at least two strips per wave
     if (q > qmax) q = qmax;
     if (q < 1) q = 1;
     a.q = q;
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
-#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT>), grid, dim3(256), 0, s, a)
+#define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT, NW>), grid, dim3(64 * WAVES), 0, s, a)
     if (m && mask_bits) {       // bit-packed mask (the input gradients of the bottleneck blocks' first 1x1 convolution: BKC layout)
         if (bkc) { if (r) DETR_STREAM_LAUNCH(true, true, 2); else DETR_STREAM_LAUNCH(true, false, 2); }
         else { if (r) DETR_STREAM_LAUNCH(false, true, 2); else DETR_STREAM_LAUNCH(false, false, 2); }
@@ -335,9 +350,23 @@ static void launch_gemm_stream(StreamArgs a, bool bkc, hipStream_t s, bool mask_
     // +res +mask 116 -> 95 (SL 4), M133600 N512 K256 144 -> 126 (SL 2); M33600 N1024 K256 stays at SL 1 (52 vs 57 us)
     // (in the step, HIP events: K = 256 without a residual / mask epilogue is SLOWER with 2 slices -- 102 KB of LDS, one workgroup per
     //  CU: M133600 N512 0.091 -> 0.120 ms -- so K = 256 groups only the epilogue-heavy form)
+    // DETR_HIP_STREAM_NW=1: one column slice per wave everywhere; otherwise two wherever that form exists (K = 256, N % 128 == 0):
+    // M33600 N1024 +res 63.8 -> 59.5 us, +res +mask 71.0 -> 64.3, M133600 N512 +res +mask 126 -> 107, M8400 N2048 28.3 -> 26.9, M534400 N128 122 -> 113
+    const int nw_mode = tune(T_STREAM_NW);
+    const bool nw2 = K == 256 && a.N % 128 == 0 && nw_mode != 1;
     if (a.alpha != 1.0f || a.drop_scale != 0.0f) {      // the extended epilogue exists for K = 256, one slice per workgroup
-        if constexpr (K == 256) launch_gemm_stream_sl<256, 1, true>(a, bkc, s, mask_bits);
+        if constexpr (K == 256) {
+            if (nw2) launch_gemm_stream_sl<256, 1, true, 2>(a, bkc, s, mask_bits);
+            else launch_gemm_stream_sl<256, 1, true>(a, bkc, s, mask_bits);
+        }
         return;
+    }
+    if constexpr (K == 256) {
+        if (nw2 && tune(T_STREAM_SL) == 0) { launch_gemm_stream_sl<256, 1, false, 2>(a, bkc, s, mask_bits); return; }
+    }
+    if constexpr (K == 128) {       // two slice pairs per 8-wave workgroup: M133600 N512 +res 80.8 -> 66.5 us, +res +mask 89.4 -> 85.9
+        // (one pair per 4-wave workgroup: 70.6 / 88.9; K = 64 loses with either form: 112 -> 117 us, it is bound by its output stores)
+        if (nw_mode != 1 && a.N % 256 == 0 && tune(T_STREAM_SL) == 0) { launch_gemm_stream_sl<128, 2, false, 2>(a, bkc, s, mask_bits); return; }
     }
     int sl = (K == 64) ? 4 : (K == 128 ? ((a.res && a.mask) ? 4 : 2) : ((a.res && a.mask && a.N <= 512) ? 2 : 1));
     const int force = tune(T_STREAM_SL);

@@ -32,7 +32,7 @@ bf = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
 out = []
 for (M, N, K, bk, res, mask, act) in [(534400, 256, 64, 0, 1, 0, 1), (534400, 256, 64, 1, 1, 1, 0), (534400, 64, 256, 1, 0, 1, 0),
                                       (133600, 512, 128, 0, 1, 0, 1), (133600, 512, 128, 1, 1, 1, 0),
-                                      (33600, 1024, 256, 0, 1, 0, 1), (33600, 1024, 256, 1, 1, 1, 0), (133600, 512, 256, 1, 1, 1, 0)]:
+                                      (33600, 1024, 256, 0, 1, 0, 1), (33600, 1024, 256, 1, 1, 1, 0), (133600, 512, 256, 1, 1, 1, 0), (8400, 2048, 256, 1, 0, 0, 1), (8400, 2048, 256, 0, 0, 1, 0)]:
     A, Bm, C = bf(M, K), (bf(N, K) if bk else bf(K, N)), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     R, Mk, bias = (bf(M, N) if res else None), (bf(M, N) if mask else None), torch.randn(N, device=dev)
     nbytes = 2 * (M * K + K * N + M * N * (1 + res + mask))

@@ -1309,13 +1309,19 @@ def test_scale_cols_bf16_group_matches_single_launches(hip):
     (16390, 128, 128, 1, False, True, 0),
     (16500, 64, 256, 0, False, False, 1),     # layer1 conv1 forward (two K chunks per strip)
     (33600, 1024, 256, 1, True, True, 0),     # layer3 conv1 input gradient
+    (16700, 1024, 256, 0, True, False, 1),    # layer3 conv3 forward ([k][n] weights, ragged last strip)
+    (16384, 128, 256, 1, False, True, 0),     # one 128-column group
 ])
-def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
+@pytest.mark.parametrize("slices_per_wave", ["1", "0"])      # DETR_HIP_STREAM_NW: one column slice per wave / the rule (two where the 8-wave form exists)
+def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act, slices_per_wave):
     """The streaming short-K kernel (csrc/gemm_stream.h; bf16 A / B / C / residual / mask, K in {64, 128}, M >= 16384) against
     fp64 on the same bf16 operands (one bf16 rounding of the result) and against the generic tile engine on the same call
     (DETR_HIP_GEMM_STREAM=2): the two may differ by the order of the fp32 products inside an MFMA, i.e. by one bf16 ulp on
     a small fraction of the outputs."""
     import os
+    if slices_per_wave == "0" and not ((K == 256 and N % 128 == 0) or (K == 128 and N % 256 == 0)):
+        pytest.skip("two slices per wave exist for K = 256 (N % 128 == 0) and K = 128 (N % 256 == 0)")
+    hip.set_tuning("DETR_HIP_STREAM_NW", slices_per_wave)
     torch.manual_seed(M + N + K + bk)
     A = _bf(torch.randn(M, K))
     Bm = _bf(torch.randn(N, K) / K ** 0.5 if bk else torch.randn(K, N) / K ** 0.5)
@@ -1340,6 +1346,7 @@ def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
         finally:
             hip.set_tuning("DETR_HIP_GEMM_STREAM", None)
         outs.append(C.float().cpu().double())
+    hip.set_tuning("DETR_HIP_STREAM_NW", None)
     stream, generic = outs
     scale = float(ref.abs().max())
     err = (stream - ref).abs()
@@ -1356,12 +1363,14 @@ def test_gemm_stream_bf16_short_k(hip, M, N, K, bk, use_res, use_mask, act):
     (8400, 2048, 0, False, 0, True, 1.0 / 0.9, 0.0),  # input gradient of linear2: alpha = 1/(1-p), ReLU / dropout mask
     (4100, 1024, 1, True, 0, False, 0.5, 0.25),       # ragged last strip, alpha and dropout together
 ])
-def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bias, act, use_mask, alpha, p):
+@pytest.mark.parametrize("slices_per_wave", ["1", "0"])
+def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bias, act, use_mask, alpha, p, slices_per_wave):
     """The K = 256 streaming kernel with the extended epilogue ((acc + bias) * alpha, keyed dropout after the activation) that
     takes the transformer's FFN GEMMs at M = B*L: same call on the generic tile engine (DETR_HIP_GEMM_STREAM=2).  The dropout
     masks are the SAME counter hash, so the zero patterns must coincide exactly; kept values may differ by one bf16 ulp
     (order of the fp32 products inside an MFMA)."""
     K = 256
+    hip.set_tuning("DETR_HIP_STREAM_NW", slices_per_wave)
     torch.manual_seed(M + N + bk)
     A = _bf(torch.randn(M, K))
     Bm = _bf(torch.randn(N, K) / K ** 0.5 if bk else torch.randn(K, N) / K ** 0.5)
@@ -1381,6 +1390,7 @@ def test_gemm_stream_extended_epilogue_equals_tile_engine(hip, M, N, bk, use_bia
         finally:
             hip.set_tuning("DETR_HIP_GEMM_STREAM", None)
         outs.append(C.float().cpu().double())
+    hip.set_tuning("DETR_HIP_STREAM_NW", None)
     stream, generic = outs
     ref = A @ (Bm.t() if bk else Bm) + (bias.double() if use_bias else 0.0)
     ref = ref * alpha
@@ -1563,11 +1573,15 @@ def _pack_bits(t):
     (8400, 2048, 512, 1, True),      # tile engine (128x128, wide epilogue): layer4
     (300, 128, 96, 0, True),         # tile engine 64x64, ragged rows
 ])
-def test_gemm_bitpacked_relu_masks(hip, M, N, K, bk, use_res):
+@pytest.mark.parametrize("slices_per_wave", ["1", "0"])      # DETR_HIP_STREAM_NW: both forms of the K = 128 / 256 streaming kernel
+def test_gemm_bitpacked_relu_masks(hip, M, N, K, bk, use_res, slices_per_wave):
     """Round 4: the ReLU masks of the bottleneck block outputs as BITS.  Producer: a GEMM with a ReLU epilogue also writes one byte
     per 8 outputs, bit = (stored bf16 output > 0), and its C is unchanged by that.  Consumer: the same masked GEMM once with the
     bf16 activation as `mask` and once with the bytes (m_dtype 2) -- bit-identical results on the streaming kernel and on the tile
     engine (the wide all-bf16 epilogue)."""
+    if slices_per_wave == "0" and K == 64:
+        pytest.skip("two slices per wave exist for K = 128 / 256")
+    hip.set_tuning("DETR_HIP_STREAM_NW", slices_per_wave)
     torch.manual_seed(M + N + K)
     b16 = lambda t: g(t.float()).to(torch.bfloat16)
     A = b16(_bf(torch.randn(M, K)))
@@ -1600,6 +1614,7 @@ def test_gemm_bitpacked_relu_masks(hip, M, N, K, bk, use_res):
     Cf = torch.zeros(M, N, device=DEV)
     with pytest.raises(RuntimeError):
         hip.gemm(M, N, K, A, K, 1, Bm, ldb, bk, Cf, N, mask=bits, ldmask=bits.stride(0), compute=1)
+    hip.set_tuning("DETR_HIP_STREAM_NW", None)
 
 
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 19, 45, 64, 1), (1, 25, 70, 128, 1), (2, 24, 40, 128, 2), (1, 13, 42, 512, 1)])
