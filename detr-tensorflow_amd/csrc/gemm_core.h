@@ -77,6 +77,13 @@ __device__ __forceinline__ float4 ld_bf16x4(const void *base, long long elem) {
 __device__ __forceinline__ float ld_bf16x1(const void *base, long long elem) {
     return bf16_bits_to_f32(reinterpret_cast<const unsigned short *>(base)[elem]);
 }
+// max(x, lo) as ONE v_max_f32: fmaxf() costs two under the IEEE mode of compute kernels (v_max x, x first, to quiet a signalling NaN
+// that these epilogues never see -- their inputs are sums of finite products)
+__device__ __forceinline__ float vmax_raw(float x, float lo) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+    return r;
+}
 __device__ __forceinline__ unsigned f32_to_bf16_pair(float a, float b) {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     bf2 r;
@@ -139,6 +146,12 @@ struct BufSrc {
     }
     __device__ __forceinline__ uint4 ld16_nt(unsigned voff) const {   // 16 raw bytes of a read-once stream: non-temporal (aux = 2)
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2));
+    }
+    __device__ __forceinline__ void st16(unsigned voff, u32x4 v) const {      // 16 raw bytes; an out-of-range offset (BUF_OOB) stores nothing
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+    }
+    __device__ __forceinline__ void st1(unsigned voff, unsigned char v) const {
+        __builtin_amdgcn_raw_buffer_store_b8(v, rsrc, voff, 0, 0);
     }
     __device__ __forceinline__ uint2 ld8(unsigned voff) const {       // 8 raw bytes (4 bf16)
         return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));

@@ -486,8 +486,12 @@ static bool gemm_stream_eligible(const GemmPlan &p) {
     if (d->mask && g.e.m16 != 2 && !(g.e.m16 && d->ldmask % 8 == 0 && aligned16(d->mask))) return false;
     if (!(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C))) return false;
     const long long ldm_eff = g.e.m16 == 2 ? 0 : d->ldmask;
-    const long long span = (long long)(d->M - 1) * (d->ldr > ldm_eff ? d->ldr : ldm_eff) + d->N;
+    long long pitch = d->ldr > ldm_eff ? d->ldr : ldm_eff;
+    if (d->ldc > pitch) pitch = d->ldc;             // C is stored through a buffer descriptor as well (32-bit byte offsets)
+    const long long span = (long long)(d->M - 1) * pitch + d->N;
     if (span * 2 > BUF_MAX_BYTES) return false;
+    // mask bits OUT: the kernel is instantiated for the form that produces them in the step (block outputs: [k][n] weights + residual)
+    if (d->maskbits_out && (p.bk || !d->residual || d->mask || ext)) return false;
     return tune(T_GEMM_STREAM) != 2;
 }
 

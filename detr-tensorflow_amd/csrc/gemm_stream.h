@@ -50,8 +50,7 @@ struct StreamArgs {
 // Cache policy of the epilogue streams.  The residual and the mask are read exactly once by this kernel and by nobody
 // after it, so they are requested non-temporal (bit 0): in the step that is -0.2 ms (20.07 -> 19.85 ms), e.g. M534400 N256
 // K64 +res+mask 166 -> 146 us, because they stop evicting the A rows the other slices of the workgroup are about to re-read.
-// The output stores stay temporal (bit 1 off): the next kernel reads C, and non-temporal stores measured +-0 here and
-// +0.02 ms on the consumers.
+// The output stores stay temporal: the next kernel reads C, and non-temporal stores measured +-0 here and +0.02 ms on the consumers.
 #ifndef DETR_STREAM_NT
 #define DETR_STREAM_NT 1
 #endif
@@ -62,6 +61,17 @@ __device__ __forceinline__ uint4 stream_ld_ep(const BufSrc &src, unsigned off) {
     return src.ld16(off);
 #endif
 }
+#ifndef DETR_STREAM_PIPE
+#define DETR_STREAM_PIPE 1                         // 0: the compiler's own order of fragment reads and MFMAs (A/B builds)
+#endif
+#ifndef DETR_STREAM_PROF
+#define DETR_STREAM_PROF 0                         // 1 (probe builds, scripts/experiments/stream_probe.py): s_memtime per strip section into maskbits_out
+#endif
+#if DETR_STREAM_PROF
+#define STREAM_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_last; prof_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STREAM_TICK(k) do { } while (0)
+#endif
 constexpr int STREAM_LD = 68;                      // floats per staged row (64 + 4): conflict-free b128 writes and reads
 
 // SL = column slices (64 columns each) a workgroup owns: its 4 waves are SL slice owners x 4 / SL row walkers, and the SL
@@ -95,7 +105,8 @@ struct StreamOcc {
 };
 
 // MASK: 0 none, 1 a bf16 tensor, 2 bit-packed (one byte per 8 columns)
-template <int K, bool BKC, bool RES, int MASK, int SL = 1, bool EXT = false, int NW = 1>
+// MBO: the epilogue also writes (C > 0) as bits (StreamArgs.mbits_out; instantiated for the forward form only: [k][n] weights + residual)
+template <int K, bool BKC, bool RES, int MASK, int SL = 1, bool EXT = false, int NW = 1, bool MBO = false>
 __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, SL, NW>::VALUE)) void gemm_stream_bf16_kernel(StreamArgs a) {
     constexpr int WAVES = StreamSmem<K, SL, NW>::WAVES, THREADS = 64 * WAVES;
     constexpr int WPS = WAVES / SL;                // row walkers (waves per slice group) of a workgroup
@@ -127,6 +138,11 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
     if (RES) srcR.init_bytes(a.res, ((long long)(a.M - 1) * a.ldr + a.N) * 2);
     if (MASK == 1) srcM.init_bytes(a.mask, ((long long)(a.M - 1) * a.ldm + a.N) * 2);
     if (MASK == 2) srcM.init_bytes(a.mask, (long long)(a.M - 1) * a.ldm + a.N / 8);
+    BufSrc dstC, dstB;
+    dstC.init_bytes(a.C, ((long long)(a.M - 1) * a.ldc + a.N) * 2);
+    if (MBO) dstB.init_bytes(a.mbits_out, (long long)(a.M - 1) * a.ld_mbits + a.N / 8);
+    const unsigned ldc2 = (unsigned)(a.ldc * 2), ldr2 = (unsigned)(a.ldr * 2), ldm2 = (unsigned)(a.ldm * 2), ldm1 = (unsigned)a.ldm, ldb1 = (unsigned)a.ld_mbits;
+    const float act_floor = a.act == 1 ? 0.0f : -__builtin_huge_valf();      // ReLU without a branch: max(v, 0) or max(v, -inf)
     float *stage = &sm.stage[wave][0][0];
     const unsigned a_lane = (unsigned)(h * 16);    // byte offset of this lane's 8 k values inside a 16-k step
     const uint32_t dkey = (EXT && a.drop_scale != 0.0f) ? drop_key(a.drop_seed, a.drop_step) : 0u;
@@ -139,24 +155,49 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
         for (int kk = 0; kk < KK; ++kk) f[kk] = srcA.ld16(base == BUF_OOB ? BUF_OOB : base + kk * 32);
     };
     // D^T[n][m] += sum_k B^T[n][k] A^T[k][m] over one chunk: lane&31 = m, accumulator r -> n = (r&3) + 8*(r>>2) + 4*h (+32*nh)
+    // B fragment nq of k-step kk.  BKC: [n][k] rows (+8 bf16 of padding); else the transpose-read image of gemm_bf16_core.h ([4 k][16 n]
+    // sub-blocks of the natural [k][n] orientation): lane (l31, h) receives the 8 consecutive k of column nh * 32 + l31 either way
+    auto read_b = [&](int chunk, int kk, int nq) -> bf16x8 {
+        const int nh = nq & 1, bs = ws * NW + (nq >> 1);
+        if constexpr (BKC) return *reinterpret_cast<const bf16x8 *>(&sm.B[bs][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
+        else return frag_tr<64>(reinterpret_cast<const unsigned short(*)[8]>(&sm.B[bs][0][0]), nh * 32, chunk * KC + kk * 16, lane);
+    };
+    // D^T[n][m] += sum_k B^T[n][k] A^T[k][m] over one chunk: lane&31 = m, accumulator r -> n = (r&3) + 8*(r>>2) + 4*h (+32*nh).
+    // The B fragments of k-step kk + 1 are read while the MFMAs of step kk run, one read per MFMA, pinned with sched_group_barrier
+    // (round 4: left alone, the compiler put every fragment read right in front of its MFMA -- `ds_read, s_waitcnt, v_mfma` 64 times
+    // per strip, an LDS round trip of latency per MFMA on waves that have one or two neighbours per SIMD to cover it)
     auto mma = [&](const uint4 (&f)[KK], int chunk, f32x16 (&acc)[2 * NW]) {
+        constexpr int NQ = 2 * NW, RPF = BKC ? 1 : 2;      // LDS reads per fragment
+        bf16x8 bq[2][NQ];
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) bq[0][nq] = read_b(chunk, 0, nq);
+#if DETR_STREAM_PIPE
+        if constexpr ((DETR_ABLATE & 1) == 0) sgb_ds_read<RPF * NQ>();
+#endif
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const bf16x8 af = __builtin_bit_cast(bf16x8, f[kk]);
 #pragma unroll
-            for (int nq = 0; nq < 2 * NW; ++nq) {
-                const int nh = nq & 1, bs = ws * NW + (nq >> 1);
-                // BKC: [n][k] rows (+8 bf16 of padding); else the transpose-read image of gemm_bf16_core.h ([4 k][16 n] sub-blocks of
-                // the natural [k][n] orientation): lane (l31, h) receives the 8 consecutive k of column nh * 32 + l31 either way
-                bf16x8 bfr;
-                if constexpr (BKC) bfr = *reinterpret_cast<const bf16x8 *>(&sm.B[bs][nh * 32 + l31][chunk * KC + kk * 16 + h * 8]);
-                else bfr = frag_tr<64>(reinterpret_cast<const unsigned short(*)[8]>(&sm.B[bs][0][0]), nh * 32, chunk * KC + kk * 16, lane);
-                if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(bfr); ablate_keep(af); }
-                else acc[nq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[nq], 0, 0, 0);
+            for (int nq = 0; nq < NQ; ++nq) {
+                if (kk + 1 < KK) bq[(kk + 1) & 1][nq] = read_b(chunk, kk + 1, nq);
+                if constexpr ((DETR_ABLATE & 1) != 0) { ablate_keep(bq[kk & 1][nq]); ablate_keep(af); }
+                else acc[nq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kk & 1][nq], af, acc[nq], 0, 0, 0);
             }
+#if DETR_STREAM_PIPE
+            if constexpr ((DETR_ABLATE & 1) == 0) {
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) {
+                    if (kk + 1 < KK) sgb_ds_read<RPF>();
+                    sgb_mfma();
+                }
+            }
+#endif
         }
     };
 
+#if DETR_STREAM_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+#endif
     // one strip: epilogue-operand requests, A prefetch, MFMAs, transposition, epilogue.  a_first holds chunk 0 of the
     // strip on entry.  NC == 1: the next strip's rows go to a_other and the two buffers swap roles from strip to strip
     // (the loop below is unrolled by two), so no register copy -- which would have to wait for the prefetch -- sits at
@@ -164,6 +205,7 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
     // a_first again.
     auto strip = [&](const int rt, uint4 (&a_first)[KK], uint4 (&a_other)[KK]) {
         const int r0 = rt * 32;
+        STREAM_TICK(7);                             // between strips (loop control)
         uint4 rres[NW][4], rmsk[NW][4];
 #pragma unroll
         for (int sw = 0; sw < NW; ++sw)
@@ -172,16 +214,18 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
             const int row = r0 + it * 8 + erow;
             const unsigned colb = (unsigned)((n0 + sw * 64 + ecg * 8) * 2);
             const bool ep_live = (DETR_ABLATE & 32) == 0;               // ablation bit 5: no residual / mask requests
-            if (RES) rres[sw][it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldr * 2) + colb : BUF_OOB);
-            if (MASK == 1) rmsk[sw][it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm * 2) + colb : BUF_OOB);
+            // (byte offsets fit 32 bits: the host dispatch only sends tensors below 4 GB here)
+            if (RES) rres[sw][it] = stream_ld_ep(srcR, (ep_live && row < a.M) ? (unsigned)row * ldr2 + colb : BUF_OOB);
+            if (MASK == 1) rmsk[sw][it] = stream_ld_ep(srcM, (ep_live && row < a.M) ? (unsigned)row * ldm2 + colb : BUF_OOB);
             if (MASK == 2)      // one byte = the 8 columns of this lane; the 8 lanes of a row read 8 consecutive bytes
-                rmsk[sw][it].x = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(srcM.rsrc, (ep_live && row < a.M) ? (unsigned)((long long)row * a.ldm) + (unsigned)(((n0 + sw * 64) >> 3) + ecg) : BUF_OOB, 0, 0);
+                rmsk[sw][it].x = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(srcM.rsrc, (ep_live && row < a.M) ? (unsigned)row * ldm1 + (unsigned)(((n0 + sw * 64) >> 3) + ecg) : BUF_OOB, 0, 0);
         }
         f32x16 acc[2 * NW];
 #pragma unroll
         for (int nq = 0; nq < 2 * NW; ++nq)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nq][r] = 0.0f;
+        STREAM_TICK(0);                             // epilogue-operand requests issued
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool last = (c + 1 == NC);
@@ -192,6 +236,7 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
                 load_a(last ? rt + stride : rt, last ? 0 : c + 1, a_first);
                 mma(a_other, c, acc);
             }
+            STREAM_TICK(1 + (c & 1));               // chunk c: A requests + MFMAs issued (incl. the wait for its A rows)
         }
 #pragma unroll
         for (int sw = 0; sw < NW; ++sw) {
@@ -204,6 +249,7 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
                         make_float4(acc[2 * sw + nh][4 * g], acc[2 * sw + nh][4 * g + 1], acc[2 * sw + nh][4 * g + 2], acc[2 * sw + nh][4 * g + 3]);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            STREAM_TICK(3);                         // accumulators staged (the first one waits for the MFMAs to finish)
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int rl = it * 8 + erow;
@@ -237,10 +283,8 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += r[i];
                 }
-                if (a.act == 1) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
-                }
+                for (int i = 0; i < 8; ++i) v[i] = vmax_raw(v[i], act_floor);
                 if constexpr (EXT) {
                     if (!RES && a.drop_scale != 0.0f) {
 #pragma unroll
@@ -258,20 +302,16 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = ((mb >> i) & 1u) ? v[i] : 0.0f;
                 }
-                if (row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f)) {    // ablation bit 6: no output stores
-                    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-                    const u32x4v ov = {f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7])};
-                    u32x4v *dstp = reinterpret_cast<u32x4v *>(a.C + (long long)row * a.ldc + n0 + sw * 64 + ecg * 8);
-#if DETR_STREAM_NT & 2
-                    __builtin_nontemporal_store(ov, dstp);
-#else
-                    *dstp = ov;
-#endif
-                    if (a.mbits_out) a.mbits_out[(long long)row * a.ld_mbits + (((n0 + sw * 64) >> 3) + ecg)] = (unsigned char)bf16x8_gt0_bits(ov[0], ov[1], ov[2], ov[3]);
-                }
+                // branch-free: a row past M (or the ablation build's "no output stores") gets an out-of-range offset and stores nothing
+                const bool st_live = row < a.M && ((DETR_ABLATE & 64) == 0 || v[0] == 12345.678f);
+                const u32x4 ov = {f32_to_bf16_pair(v[0], v[1]), f32_to_bf16_pair(v[2], v[3]), f32_to_bf16_pair(v[4], v[5]), f32_to_bf16_pair(v[6], v[7])};
+                dstC.st16(st_live ? (unsigned)row * ldc2 + (unsigned)((n0 + sw * 64 + ecg * 8) * 2) : BUF_OOB, ov);
+                if constexpr (MBO && !DETR_STREAM_PROF)
+                    dstB.st1(st_live ? (unsigned)row * ldb1 + (unsigned)(((n0 + sw * 64) >> 3) + ecg) : BUF_OOB, (unsigned char)bf16x8_gt0_bits(ov[0], ov[1], ov[2], ov[3]));
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            STREAM_TICK(4);                         // epilogue items: LDS reads, residual / mask waits, stores issued
         }
     };
 
@@ -300,6 +340,10 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
     }
     __syncthreads();
 
+#if DETR_STREAM_PROF
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+    prof_last = prof_t0;
+#endif
     while (rt < a.row_tiles) {
         strip(rt, a0, a1);
         rt += stride;
@@ -309,6 +353,14 @@ __global__ __launch_bounds__(64 * (StreamSmem<K, SL, NW>::WAVES), (StreamOcc<K, 
             rt += stride;
         }
     }
+#if DETR_STREAM_PROF
+    if (lane == 0 && a.mbits_out) {                // [workgroup][wave][8]: sections 0-4, 5 = prologue end, 6 = loop total, 7 = between strips
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.mbits_out) + ((size_t)blockIdx.x * WAVES + wave) * 8;
+        prof_acc[6] = __builtin_readcyclecounter() - prof_t0;
+        prof_acc[5] = prof_t0;
+        for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
+    }
+#endif
 }
 
 // Host side: eligibility is decided by the caller (gemm_f32.hip); here the slice grouping and the grid.
@@ -326,7 +378,9 @@ static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s, bool ma
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
 #define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT, NW>), grid, dim3(64 * WAVES), 0, s, a)
-    if (m && mask_bits) {       // bit-packed mask (the input gradients of the bottleneck blocks' first 1x1 convolution: BKC layout)
+    if (a.mbits_out) {          // mask bits out: the forward form only (gemm_stream_eligible: [k][n] weights + residual, no mask in)
+        if constexpr (!EXT) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, false, true, 0, SL, false, NW, true>), grid, dim3(64 * WAVES), 0, s, a);
+    } else if (m && mask_bits) {       // bit-packed mask (the input gradients of the bottleneck blocks' first 1x1 convolution: BKC layout)
         if (bkc) { if (r) DETR_STREAM_LAUNCH(true, true, 2); else DETR_STREAM_LAUNCH(true, false, 2); }
         else { if (r) DETR_STREAM_LAUNCH(false, true, 2); else DETR_STREAM_LAUNCH(false, false, 2); }
     } else if (bkc) {
