@@ -378,7 +378,8 @@ static void launch_gemm_stream_sl(StreamArgs a, bool bkc, hipStream_t s, bool ma
     const dim3 grid((unsigned)(8 * a.n_tiles * q));
     const bool r = a.res != nullptr, m = a.mask != nullptr;
 #define DETR_STREAM_LAUNCH(BK_, R_, M_) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, BK_, R_, M_, SL, EXT, NW>), grid, dim3(64 * WAVES), 0, s, a)
-    if (a.mbits_out) {          // mask bits out: the forward form only (gemm_stream_eligible: [k][n] weights + residual, no mask in)
+    if (a.mbits_out) {          // mask bits out: the forward form only -- gemm_stream_eligible() sends nothing else here ([k][n] weights + residual,
+                                // no mask in, no extended epilogue; any other request with bits out runs on the tile engine)
         if constexpr (!EXT) hipLaunchKernelGGL((gemm_stream_bf16_kernel<K, false, true, 0, SL, false, NW, true>), grid, dim3(64 * WAVES), 0, s, a);
     } else if (m && mask_bits) {       // bit-packed mask (the input gradients of the bottleneck blocks' first 1x1 convolution: BKC layout)
         if (bkc) { if (r) DETR_STREAM_LAUNCH(true, true, 2); else DETR_STREAM_LAUNCH(true, false, 2); }

@@ -16,7 +16,8 @@ dev = "cuda"
 hip.ensure_workspace(dev)
 bf = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
 NAMES = ["requests", "chunk0", "chunk1", "staged", "items", "t0", "loop", "between"]
-for (M, N, K, bk, res, act) in [(33600, 1024, 256, 0, 1, 1), (8400, 2048, 256, 1, 0, 1), (133600, 512, 128, 0, 1, 1), (534400, 256, 64, 0, 1, 1)]:
+# (the probe rides on the mask-bits-out form of the kernel: [k][n] weights + residual, see gemm_stream_eligible)
+for (M, N, K, bk, res, act) in [(33600, 1024, 256, 0, 1, 1), (8400, 2048, 256, 0, 1, 1), (133600, 512, 128, 0, 1, 1), (534400, 256, 64, 0, 1, 1)]:
     A, Bm, C = bf(M, K), (bf(N, K) if bk else bf(K, N)), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     R, bias = (bf(M, N) if res else None), torch.randn(N, device=dev)
     prof = torch.zeros(M, N // 8, device=dev, dtype=torch.uint8)
