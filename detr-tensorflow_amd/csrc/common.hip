@@ -149,7 +149,7 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_layernorm_desc, workspace_bytes)); DETR_PUT(DETR_OFF(detr_layernorm_desc, dx_add));
         DETR_PUT(DETR_OFF(detr_layernorm_desc, dx_drop)); DETR_PUT(DETR_OFF(detr_layernorm_desc, dropout_p)); DETR_PUT(DETR_OFF(detr_layernorm_desc, dropout_site));
         DETR_PUT(DETR_OFF(detr_layernorm_desc, dropout_step)); DETR_PUT(DETR_OFF(detr_layernorm_desc, dx_drop16));
-        DETR_PUT(DETR_OFF(detr_layernorm_desc, defer_blocks_out));
+        DETR_PUT(DETR_OFF(detr_layernorm_desc, defer_blocks_out)); DETR_PUT(DETR_OFF(detr_layernorm_desc, dy_add));
         break;
     case 5:   // detr_attn_desc
         DETR_PUT((int32_t)sizeof(detr_attn_desc));

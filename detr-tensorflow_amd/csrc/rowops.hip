@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             const float *__restrict__ dx_add, float *__restrict__ dx_drop,
                                                             float drop_scale, uint32_t drop_thresh, uint32_t drop_site,
                                                             const uint32_t *__restrict__ drop_step,
-                                                            unsigned short *__restrict__ dx_drop16) {
+                                                            unsigned short *__restrict__ dx_drop16,
+                                                            const float *__restrict__ dy_add) {
     __shared__ float red[2][4][64 * LN_MAXV * 4 / 4];  // [gamma|beta][wave][C] ; C <= 1024 -> see below
     // (partial sums are kept per lane in registers and reduced through LDS at the end)
     const int lane = threadIdx.x & 63;
@@ -113,7 +114,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         for (int i = 0; i < LN_MAXV; ++i) {
             const int j = lane + 64 * i;
             if (j < nv) {
-                const float4 xv = xr[j], dv = dr[j];
+                const float4 xv = xr[j];
+                float4 dv = dr[j];
+                if (dy_add) {    // two gradient branches meet at this LayerNorm's output
+                    const float4 e = reinterpret_cast<const float4 *>(dy_add + (long long)row * C)[j];
+                    dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w;
+                }
                 const float4 gm = reinterpret_cast<const float4 *>(gamma)[j];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
@@ -350,7 +356,7 @@ extern "C" int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream
     float *partial = (d->workspace && d->workspace_bytes >= (long long)grid * 2 * C * 4) ? d->workspace : nullptr;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->gamma, d->mean, d->rstd,
                        d->dx, d->dgamma, d->dbeta, rows, C, partial, d->dx_add, d->dx_drop, drop_scale, drop_thresh16(d->dropout_p),
-                       d->dropout_site, d->dropout_step, d->dx_drop16);
+                       d->dropout_site, d->dropout_step, d->dx_drop16, d->dy_add);
     DETR_LAUNCH_CHECK("layernorm bwd");
     if (d->defer_blocks_out) {
         DETR_REQUIRE(partial != nullptr, "layernorm bwd: defer_blocks_out needs a workspace of %d * 2 * C floats", grid);

@@ -62,7 +62,7 @@ class LayerNormDesc(Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("dx_add", c_void_p),
                 ("dx_drop", c_void_p), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p),
-                ("dx_drop16", c_void_p), ("defer_blocks_out", POINTER(c_int32))]
+                ("dx_drop16", c_void_p), ("defer_blocks_out", POINTER(c_int32)), ("dy_add", c_void_p)]
 
 
 class StemDesc(Structure):
@@ -734,13 +734,14 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None, y16=
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, dx_add=None, dx_drop=None, dropout_p=0.0, dropout_site=0,
-                  dropout_step=None, dx_drop16=None, defer=True):
+                  dropout_step=None, dx_drop16=None, defer=True, dy_add=None):
     """defer=False: finish the gamma / beta reduction at once even while reductions are being queued (a LayerNorm whose
     parameters receive several backward passes per step -- two queued reductions into one output would force a flush)."""
     d = LayerNormDesc()
     d.rows, d.C = x.shape[0], x.shape[1]
     d.dy, d.x, d.gamma, d.mean, d.rstd = dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     d.dx, d.dgamma, d.dbeta = dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+    d.dy_add = ptr(dy_add)
     ln_need = _ws_query("detr_hip_workspace_bytes_layernorm", ("ln", d.rows, d.C), byref(d))
     if WORKSPACE is not None:                                       # deterministic gamma / beta reduction
         need_workspace(ln_need)

@@ -318,10 +318,10 @@ class DetrEngine:
         """Suffix that makes a scratch tensor private to one site while the second stream is in use."""
         return f":{site}" if getattr(self, "_side_on", False) else ""
 
-    def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None, want16=False):
-        """Backward of _ln_fwd w.r.t. x (+ dx_add).  drop_site: also return dropout_bwd(dx) -- the gradient through the
-        Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the same launch.
-        want16: that second output as bf16 (it only feeds GEMM operands of the bf16-compute FFN backward)."""
+    def _ln_bwd(self, dy, x, pfx, dx, tag, dx_add=None, drop_site=None, want16=False, dy_add=None):
+        """Backward of _ln_fwd w.r.t. x (+ dx_add); the incoming gradient is dy (+ dy_add).  drop_site: also return dropout_bwd(dx)
+        -- the gradient through the Dropout in front of the residual add that feeds this LayerNorm -- as a second output of the
+        same launch.  want16: that second output as bf16 (it only feeds GEMM operands of the bf16-compute FFN backward)."""
         dp, _ = self._drop
         dx_drop = dx_drop16 = None
         if drop_site is not None:
@@ -332,7 +332,7 @@ class DetrEngine:
         hip.layernorm_bwd(dy, x, self.P.views[f"{pfx}/gamma"], self._bufs[f"{tag}:mean"], self._bufs[f"{tag}:rstd"], dx,
                           self.P.gviews[f"{pfx}/gamma"], self.P.gviews[f"{pfx}/beta"], dx_add=dx_add, dx_drop=dx_drop,
                           dropout_p=dp, dropout_site=(drop_site or 0), dropout_step=self._seed_dev, dx_drop16=dx_drop16,
-                          defer=(pfx != "transformer/decoder/norm"))       # the shared decoder norm: one backward per level
+                          dy_add=dy_add)
         if dx_drop16 is not None:
             return dx_drop16
         return dx if dx_drop is None else dx_drop
@@ -619,6 +619,7 @@ class DetrEngine:
         tgt = self.buf("dec:tgt0", (B * Q, D))
         hip.zero_(tgt)                                           # transformer.py:45
         hs = self.buf("dec:hs", (nd, B * Q, D))
+        t3all = self.buf("dec:t3all", (nd, B * Q, D))           # the layer outputs, contiguous: ONE final-norm launch over all levels
         dp, _ = self._drop
         # K / V projections of `memory` for ALL decoder layers at once: memory is layer-invariant (:221-223)
         ct = self._cross_tables()
@@ -657,14 +658,15 @@ class DetrEngine:
             self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2", y16=t2h)
             f = self.buf(f"{tag}:f", (B * Q, D))
             self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4, x16=t2h)
-            t3 = self.buf(f"{tag}:t3", (B * Q, D))
+            t3 = self._bufs[f"{tag}:t3"] = t3all[i]
             if i + 1 < nd:
                 qin = self.buf(f"dec{i + 1}:qin", (B * Q, D))
                 self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3", add=qpos, y2=qin)
             else:
                 self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
-            self._ln_fwd(t3, "transformer/decoder/norm", hs[i], f"{tag}:lnf")      # :121-125
             tgt = t3
+        # the shared decoder norm of every level (:121-125) in one launch (round 4: it was one 800-row launch per layer, forward and backward)
+        self._ln_fwd(t3all.view(nd * B * Q, D), "transformer/decoder/norm", hs.view(nd * B * Q, D), "dec:lnf")
         self.phase("fwd heads")
         # ---------------- heads (detr.py:181-204 / :94-114) ----------------
         hip.COMPUTE_BF16 = 0          # the heads, like LayerNorm / softmax / the set loss, always run in exact fp32
@@ -754,6 +756,9 @@ class DetrEngine:
         acc_qpos = self.buf("scratch:acc_qpos", (BQ, D))             # sum over layers / sites of d(tgt + query_pos): query_pos gradient
         hip.zero_(acc_qpos)
         d_next = None                       # gradient flowing into t3 of layer i from layer i+1
+        # the shared decoder norm, all levels at once: d_t3n[i] = gradient of level i's head input w.r.t. t3 of layer i
+        d_t3n = self.buf("scratch:d_t3n", (nd, BQ, D))
+        self._ln_bwd(d_hs3.view(nd * BQ, D), self._bufs["dec:t3all"].view(nd * BQ, D), "transformer/decoder/norm", d_t3n.view(nd * BQ, D), "dec:lnf")
         for i in reversed(range(nd)):
             pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
             cp = f"{pfx}/multihead_attn"
@@ -762,10 +767,9 @@ class DetrEngine:
             qin, q2 = self._bufs[f"{tag}:qin"], self._bufs[f"{tag}:q2"]
             tgt = self._bufs[f"dec{i - 1}:t3"] if i > 0 else self._bufs["dec:tgt0"]
             ds = 16 * (32 + i)
-            d_t3 = self.buf("scratch:d_t3", (BQ, D))
-            self._ln_bwd(d_hs3[i], t3, "transformer/decoder/norm", d_t3, f"{tag}:lnf", dx_add=d_next)
             d_f = self.buf(f"scratch:d_f{self._sx(tag)}", (BQ, D))
-            d_y = self._ln_bwd(d_t3, f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5, want16=self.ffn16)
+            # d_t3 = d_t3n[i] + d_next: the two branches are summed by the norm3 backward itself
+            d_y = self._ln_bwd(d_t3n[i], f, f"{pfx}/norm3", d_f, f"{tag}:ln3", drop_site=ds + 5, want16=self.ffn16, dy_add=d_next)
             d_t2 = self.buf("scratch:d_t2", (BQ, D))
             self._ffn_bwd(tag, pfx, d_y, d_f, t2, d_t2, x16=self._bufs.get(f"{tag}:t2h") if self.ffn16 else None)
             d_a2 = self.buf(f"scratch:d_a2{self._sx(tag)}", (BQ, D))

@@ -264,6 +264,7 @@ typedef struct {
      * partial blocks -- the caller owns `workspace` ([blocks][2*C]: gamma partials, then beta partials, per block) and
      * reduces it later through detr_hip_splitk_reduce_many (two entries: rows 1, cols C, splits = blocks, part_stride 2*C) */
     int32_t *defer_blocks_out;
+    const float *dy_add;            /* bwd, optional: the incoming gradient is dy + dy_add (two branches meeting at this LayerNorm's output) */
 } detr_layernorm_desc;
 int detr_hip_layernorm_fwd(const detr_layernorm_desc *d, void *stream);
 int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);

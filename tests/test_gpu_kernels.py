@@ -523,6 +523,14 @@ def test_layernorm_fwd_bwd(hip, rows, C):
     close(res[0][0], gam.grad, rtol=5e-5, what="layernorm dgamma (workspace)")
     close(res[0][1], bet.grad, rtol=5e-5, what="layernorm dbeta (workspace)")
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # dy_add (round 4): two gradient branches summed inside the launch == the launch on their sum
+    part = g(torch.randn(rows, C))
+    rest = dyd - part
+    dx2, dg3, db3 = torch.zeros(rows, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    hip.layernorm_bwd(rest, xd, gd, mean, rstd, dx2, dg3, db3, dy_add=part)
+    close(dx2, x.grad, rtol=4e-5, what="layernorm dx (dy + dy_add)")
+    close(dg3, gam.grad, rtol=1e-4, what="layernorm dgamma (dy + dy_add)")
+    close(db3, bet.grad, rtol=1e-4, what="layernorm dbeta (dy + dy_add)")
     # queued finish (detr_layernorm_desc.defer_blocks_out + detr_hip_splitk_reduce_many): same partials, same summation order
     hip.begin_deferred_reduces(DEV)
     try:
