@@ -23,7 +23,7 @@ for w in "$@"; do
     micro_wgrad) timeout 900 python scripts/micro_wgrad.py $OUT/micro_wgrad.json > $OUT/micro_wgrad.log 2>&1; echo "micro_wgrad rc=$?" >> $OUT/summary.txt; grep -v amdgpu $OUT/micro_wgrad.log | cut -c1-400 ;;
     micro_attn) timeout 600 python scripts/micro_attn.py > $OUT/micro_attn.log 2>&1; echo "micro_attn rc=$?" >> $OUT/summary.txt; tail -12 $OUT/micro_attn.log ;;
     prof16) (cd /tmp && export TMPDIR=/tmp DETR_HIP_WGRAD_STREAM=0 && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof16 -o prof -- python /root/repo/bench.py --steps 3 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/prof16.log 2>&1); echo "prof16 rc=$?" >> $OUT/summary.txt
-          python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 > $OUT/prof16_summary.txt 2>&1; head -70 $OUT/prof16_summary.txt
+          python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 > $OUT/prof16_summary.txt 2>&1; python scripts/prof_summary.py $OUT/prof16/prof_results.db 3 400 > $OUT/prof16_all.txt 2>&1; head -70 $OUT/prof16_summary.txt
           python scripts/launch_count.py $OUT/prof16/prof_results.db 10 > $OUT/launch_count.txt 2>&1; cat $OUT/launch_count.txt; rm -rf $OUT/prof16 ;;
     pmc16) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp DETR_HIP_WGRAD_STREAM=0 && timeout 600 rocprofv3 --pmc $c -d /root/repo/$OUT/pmc_$c -o pmc -- python /root/repo/bench.py --steps 2 --warmup 2 --precision bf16 --no-fp32-leg --no-configs --no-cpu-baseline --no-kernel-events --launch eager > /root/repo/$OUT/pmc_$c.log 2>&1); echo "pmc $c rc=$?" >> $OUT/summary.txt; done
           python scripts/pmc_summary.py $OUT gemm_bf16c $OUT/traffic_bf16.json > $OUT/pmc_hbm_summary.txt 2>&1; head -30 $OUT/pmc_hbm_summary.txt; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
