@@ -115,6 +115,10 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_gemm_desc, a_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, c_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, r_dtype));
         DETR_PUT(DETR_OFF(detr_gemm_desc, m_dtype)); DETR_PUT(DETR_OFF(detr_gemm_desc, dropout_step)); DETR_PUT(DETR_OFF(detr_gemm_desc, defer_out));
         DETR_PUT(DETR_OFF(detr_gemm_desc, maskbits_out)); DETR_PUT(DETR_OFF(detr_gemm_desc, ld_maskbits_out));
+        DETR_PUT(DETR_OFF(detr_gemm_desc, ln_gamma)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_beta)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_y));
+        DETR_PUT(DETR_OFF(detr_gemm_desc, ln_mean)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_rstd)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_add));
+        DETR_PUT(DETR_OFF(detr_gemm_desc, ln_add_rows)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_y2)); DETR_PUT(DETR_OFF(detr_gemm_desc, ln_y16));
+        DETR_PUT(DETR_OFF(detr_gemm_desc, ln_eps));
         break;
     case 2:   // detr_conv3x3_desc
         DETR_PUT((int32_t)sizeof(detr_conv3x3_desc));

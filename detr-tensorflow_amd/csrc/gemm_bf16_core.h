@@ -150,8 +150,9 @@ template <int BMN, int BK = BF_BK>
 struct LoaderKh {
     static constexpr int CPR = BK / 8;
     static constexpr int RPP = 256 / CPR;             // rows per pass of the 256 threads
-    static constexpr int NV = BMN / RPP;
-    static_assert(BMN % RPP == 0, "tile rows must be a multiple of the rows one pass covers");
+    static constexpr int NV = (BMN + RPP - 1) / RPP;
+    static constexpr bool PART = BMN % RPP != 0;      // a tile with fewer rows than one pass (32 rows x 32 k): the upper threads idle
+    static_assert(!PART || NV == 1, "tile rows: a multiple of the rows one pass covers, or fewer than one pass");
     typedef uint4 Reg;
     static constexpr int NREG = NV;
     static constexpr int NDSW = NV, NVMEM = NV;
@@ -165,8 +166,9 @@ struct LoaderKh {
         k8 = (tid % CPR) * 8;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int g = mn0 + tid / CPR + RPP * i;
-            off[i] = g < MN ? (unsigned)((long long)g * ld * 2) : BUF_OOB;
+            const int lr = tid / CPR + RPP * i;
+            const int g = mn0 + lr;
+            off[i] = (g < MN && (!PART || lr < BMN)) ? (unsigned)((long long)g * ld * 2) : BUF_OOB;
         }
     }
     __device__ __forceinline__ void load(int k0, int K, uint4 (&r)[NV], unsigned base = 0) const {
@@ -177,7 +179,8 @@ struct LoaderKh {
     template <int LD>
     __device__ __forceinline__ void store(unsigned short (*S)[LD], const uint4 (&r)[NV]) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<uint4 *>(&S[tid / CPR + RPP * i][k8]) = r[i];
+        for (int i = 0; i < NV; ++i)
+            if (!PART || tid / CPR + RPP * i < BMN) *reinterpret_cast<uint4 *>(&S[tid / CPR + RPP * i][k8]) = r[i];
     }
     // ---- per-tile descriptor form (round 4): the K advance lives in the DESCRIPTOR (base += 2 k0, num_records -= 2 k0: scalar
     // instructions), the per-lane offsets voff[] = off[] + 2 k8 are loop constants, and a tile at or past `kend` gets an empty

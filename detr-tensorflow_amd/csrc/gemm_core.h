@@ -502,6 +502,88 @@ __host__ __device__ __forceinline__ void slab_ts_unit(int u, int BM, int BN, int
     col = (w & 1) * (BN >> 1) + ni * 32 + (lane & 31);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-complete epilogue with the LayerNorm fused (round 4; detr_gemm_desc.ln_fwd): the workgroup's tile spans ALL N = 256 columns
+// (32 rows x 256, four waves side by side), so the rows of   C = drop((acc + bias) * alpha) + residual   are complete inside the
+// workgroup and the LayerNormalization that follows every attention / FFN block of the transformer (transformer.py:151-152,
+// 169-170,177, 215-233) runs on them while they are still on chip: the tile is staged row-major in LDS, one wave per row, a lane
+// owns 4 consecutive columns -- the arithmetic, its order and the wave reductions are those of rowops.hip layernorm_fwd_kernel
+// (C = 256: one float4 per lane), so y / mean / rstd equal the two-launch path bit for bit.  C (the LayerNorm INPUT, which the
+// backward needs) is still written.  Saves the 800- / 8400-row LayerNorm launch behind the GEMM.
+// ---------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float *gamma = nullptr, *beta = nullptr;
+    float *y = nullptr, *mean = nullptr, *rstd = nullptr;
+    const float *add = nullptr;
+    int add_rows = 0;
+    float *y2 = nullptr;
+    unsigned short *y16 = nullptr;
+    float eps = 0.0f;
+};
+constexpr int LN_TILE_M = 32, LN_TILE_N = 256, LN_STAGE_LD = LN_TILE_N + 4;
+__device__ __forceinline__ void epilogue_ln(const f32x16 (&acc)[1][2], float *stage, float *C, long long ldc, int M, int m0, int wn,
+                                            int lane, int wave, const EpiArgs &e, const LnArgs &ln) {
+    const int l31 = lane & 31, rh = (lane >> 5) * 4;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rh) * LN_STAGE_LD + wn * 64 + ni * 32 + l31] = acc[0][ni][r];
+    __syncthreads();
+    const int c4 = lane * 4;
+    const uint32_t dkey = e.drop_scale != 0.0f ? drop_key(e.drop_seed, e.drop_step) : 0u;
+    float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.bias) bi = *reinterpret_cast<const float4 *>(e.bias + c4);
+    const float4 gm = *reinterpret_cast<const float4 *>(ln.gamma + c4), bt = *reinterpret_cast<const float4 *>(ln.beta + c4);
+#pragma unroll
+    for (int rr = 0; rr < LN_TILE_M / 4; ++rr) {
+        const int lr = wave + 4 * rr, row = m0 + lr;
+        if (row >= M) continue;                                         // wave-uniform
+        const float4 a = *reinterpret_cast<const float4 *>(stage + lr * LN_STAGE_LD + c4);
+        float v[4] = {a.x, a.y, a.z, a.w};
+        const float b4[4] = {bi.x, bi.y, bi.z, bi.w};
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.residual) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(e.residual + (long long)row * e.ldr + c4);
+            res[0] = r4.x; res[1] = r4.y; res[2] = r4.z; res[3] = r4.w;
+        }
+        bool keep[4] = {true, true, true, true};
+        if (e.drop_scale != 0.0f) {                                     // element index row * N + col, one hash per pair (common.h)
+            const unsigned long long idx = (unsigned long long)row * LN_TILE_N + (unsigned)c4;
+            const uint32_t h0 = drop_hash(dkey, idx >> 1), h1 = drop_hash(dkey, (idx >> 1) + 1);
+            keep[0] = (h0 & 0xFFFFu) >= e.drop_thresh; keep[1] = (h0 >> 16) >= e.drop_thresh;
+            keep[2] = (h1 & 0xFFFFu) >= e.drop_thresh; keep[3] = (h1 >> 16) >= e.drop_thresh;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = epi_one(v[j], 1.0f, b4[j], e, res[j], 1.0f, keep[j]);
+        *reinterpret_cast<float4 *>(C + (long long)row * ldc + c4) = make_float4(v[0], v[1], v[2], v[3]);
+        // ---- layernorm_fwd_kernel, C = 256
+        const float mu = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)LN_TILE_N;
+        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+        const float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / (float)LN_TILE_N;
+        const float rs = rsqrtf(var + ln.eps);
+        float4 o;
+        o.x = (v[0] - mu) * rs * gm.x + bt.x;
+        o.y = (v[1] - mu) * rs * gm.y + bt.y;
+        o.z = (v[2] - mu) * rs * gm.z + bt.z;
+        o.w = (v[3] - mu) * rs * gm.w + bt.w;
+        *reinterpret_cast<float4 *>(ln.y + (long long)row * LN_TILE_N + c4) = o;
+        if (ln.y16) {
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            bf2 p0, p1;
+            p0[0] = (__bf16)o.x; p0[1] = (__bf16)o.y; p1[0] = (__bf16)o.z; p1[1] = (__bf16)o.w;
+            *reinterpret_cast<uint2 *>(ln.y16 + (long long)row * LN_TILE_N + c4) = make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
+        }
+        if (ln.y2) {
+            const float4 p = *reinterpret_cast<const float4 *>(ln.add + (long long)(row % ln.add_rows) * LN_TILE_N + c4);
+            *reinterpret_cast<float4 *>(ln.y2 + (long long)row * LN_TILE_N + c4) = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+        }
+        if (lane == 0) {
+            ln.mean[row] = mu;
+            ln.rstd[row] = rs;
+        }
+    }
+}
+
 // ALLOW_WIDE = false: callers whose output can never take the all-bf16 form (weight gradients: fp32, accumulated) keep the
 // 4-column code alone -- the second form would only cost them registers and code
 template <int BM, int BN, int WGM, int WGN, bool ALLOW_WIDE = true>

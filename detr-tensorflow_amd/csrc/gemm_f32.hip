@@ -516,11 +516,39 @@ static void gemm_stream_launch(const GemmPlan &p, hipStream_t s) {
     else launch_gemm_stream<256>(a, p.bk, s, mb);
 }
 
+// GEMM with the LayerNorm of its output rows fused (detr_gemm_desc.ln_y; gemm_core.h: epilogue_ln): row-complete 32 x 256 tiles
+static int gemm_ln_launch(const GemmPlan &p, hipStream_t s) {
+    const detr_gemm_desc *d = p.d;
+    const GemmArgs &g0 = p.g;
+    DETR_REQUIRE(p.bf16c && d->N == LN_TILE_N && d->ldc == LN_TILE_N && p.ak && p.bk && g0.b16 && p.batch == 1 && p.split == 1,
+                 "gemm + LayerNorm: needs compute = 1, N = ldc = 256, k-contiguous A and bf16 k-contiguous B, no batch / split_k");
+    DETR_REQUIRE(d->act == 0 && !d->scale && !d->mask && !g0.e.c16 && !g0.e.r16 && !d->rowsum_a && !d->maskbits_out && d->K % 8 == 0,
+                 "gemm + LayerNorm: epilogue is bias, alpha, dropout and an fp32 residual only (K %% 8 == 0)");
+    DETR_REQUIRE(d->ln_gamma && d->ln_beta && d->ln_mean && d->ln_rstd && (!d->ln_y2 || (d->ln_add && d->ln_add_rows > 0)),
+                 "gemm + LayerNorm: gamma, beta, mean, rstd are required (and add / add_rows with y2)");
+    DETR_REQUIRE((!d->residual || (d->ldr % 4 == 0 && aligned16(d->residual))) && aligned16(d->C) && aligned16(d->ln_y) &&
+                 (!d->bias || aligned16(d->bias)) && aligned16(d->ln_gamma) && aligned16(d->ln_beta) &&
+                 (!d->ln_y2 || (aligned16(d->ln_y2) && aligned16(d->ln_add))) && (!d->ln_y16 || aligned16(d->ln_y16)),
+                 "gemm + LayerNorm: rows must be 16-byte aligned");
+    GemmArgs a = g0;
+    a.tiles_m = cdiv(d->M, LN_TILE_M);
+    a.tiles_n = 1;
+    a.ln.gamma = d->ln_gamma; a.ln.beta = d->ln_beta; a.ln.y = d->ln_y; a.ln.mean = d->ln_mean; a.ln.rstd = d->ln_rstd;
+    a.ln.add = d->ln_add; a.ln.add_rows = d->ln_add_rows; a.ln.y2 = d->ln_y2; a.ln.y16 = d->ln_y16; a.ln.eps = d->ln_eps;
+    const dim3 grid((unsigned)a.tiles_m), block(GEMM_THREADS);
+    if (g0.a16) hipLaunchKernelGGL(gemm_bf16c_ln_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(gemm_bf16c_ln_kernel<false>, grid, block, 0, s, a);
+    DETR_LAUNCH_CHECK("gemm + LayerNorm");
+    if (d->defer_out) d->defer_out->splits = 0;
+    return 0;
+}
+
 static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const GemmArgs &g = p.g;
     const detr_gemm_desc *d = p.d;
     const int batch = p.batch;
     const bool ak = p.ak, bk = p.bk;
+    if (d->ln_y) return gemm_ln_launch(p, s);
     if (gemm_stream_eligible(p)) {
         gemm_stream_launch(p, s);
         DETR_LAUNCH_CHECK("gemm (stream)");

@@ -27,6 +27,7 @@ struct GemmArgs {
     int a16;                     // A operand is bf16 in memory (bf16 activation storage)
     int split_xcd;               // split-K: remap the whole (split, tile) space over the XCDs (0 = per-split tile remap only, A/B hook)
     int slab_ts;                 // split-K partials as tile-ordered slabs (gemm_core.h: store_slab_ts); part_stride counts padded tiles
+    LnArgs ln;                   // gemm_bf16c_ln_kernel only: the LayerNorm fused behind the row-complete tile (gemm_core.h: epilogue_ln)
 };
 
 // Row sums of A collected from the loader registers (fp32, before any rounding): every thread owns the float4 of
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_group_kernel(GemmGroupA
 // each with twice the MFMA work behind one LDS round trip.  The split ranges stay in units of 32 (the host's slab arithmetic,
 // gemm_effective_split, does not depend on the variant); a range that is not a multiple of 64 ends in a half-empty tile whose
 // missing half is never requested (out-of-range offsets -> zeros).
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16, int BK = BF_BK>
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16, int BK = BF_BK, bool LN = false>
 __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id, const int zidx) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     static_assert(BK == BF_BK || (A16 && B16), "the 64-deep K tile exists for bf16 operands only");
@@ -372,6 +373,12 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     }
     __syncthreads();
     if (do_rs) rowsum_finish<BM, NRS>(rs, reinterpret_cast<float *>(smem_raw), g, m0, split, tid, (!AK && A16) ? 2 : 1);
+    if constexpr (LN) {              // row-complete 32 x 256 tile: C, then the LayerNorm of its rows (epilogue_ln)
+        static_assert(BM == LN_TILE_M && BN == LN_TILE_N && WGM == 1 && WGN == 4, "the fused LayerNorm needs the row-complete tile");
+        static_assert(LN_TILE_M * LN_STAGE_LD * 4 <= BfSmemBytes<BM, BN, WGN, BK>::VALUE, "staged tile must fit the operand LDS");
+        epilogue_ln(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, m0, wn, lane, wave, g.e, g.ln);
+        return;
+    }
     if constexpr (WGM == 2 && WGN == 2) {
         if (g.slab_ts) {             // split-K partial: the accumulator registers as they are, 16-byte lane-linear stores
             store_slab_ts<BM, BN, WGM, WGN>(acc, C + (long long)id * (BM * BN), wave, lane);
@@ -393,6 +400,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 2 : 4) void 
     int tile, z;
     gemm_work_item(g, tile, z);
     gemm_bf16c_body<BM, BN, WGM, WGN, AK, BKC, true, true, 64>(g, tile, z);
+}
+// GEMM + LayerNorm of the transformer blocks (N = 256): row-complete 32 x 256 tiles, [n][k] bf16 weights, A fp32 or bf16
+template <bool A16>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16c_ln_kernel(GemmArgs g) {
+    int tile, z;
+    gemm_work_item(g, tile, z);
+    gemm_bf16c_body<LN_TILE_M, LN_TILE_N, 1, 4, true, true, A16, true, BF_BK, true>(g, tile, z);
 }
 // (Round 4 measured a 128-deep K tile for the 64x64-tile launches with K >= 1024 -- half the barrier-separated iterations, 70 KB of
 //  LDS, 2 workgroups per CU; bit-identical: M8400 N256 K2048 34.7 -> 40.2 us, M8400 N512 K2048 42.3 -> 50.3 us.  Not kept: these

@@ -41,7 +41,9 @@ class GemmDesc(Structure):
                 ("rowsum_a", c_void_p), ("rowsum_alpha", c_float), ("b_dtype", c_int32),
                 ("a_dtype", c_int32), ("c_dtype", c_int32), ("r_dtype", c_int32), ("m_dtype", c_int32),
                 ("dropout_step", c_void_p), ("defer_out", POINTER(ReduceDesc)),
-                ("maskbits_out", c_void_p), ("ld_maskbits_out", c_int64)]          # ABI 5: bit-packed ReLU masks
+                ("maskbits_out", c_void_p), ("ld_maskbits_out", c_int64),          # ABI 5: bit-packed ReLU masks
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
+                ("ln_add", c_void_p), ("ln_add_rows", c_int32), ("ln_y2", c_void_p), ("ln_y16", c_void_p), ("ln_eps", c_float)]
 
 
 class AttnDesc(Structure):
@@ -449,10 +451,17 @@ def _f32(t, name="tensor"):
 def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1.0, scale=None, bias=None,
                residual=None, ldr=0, mask=None, ldmask=0, act=0, split_k=1, batch=1, batch_inner=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), a_off=0, b_off=0, c_off=0, workspace=None, dropout_p=0.0, dropout_seed=0,
-               dropout_step=None, compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None, maskbits_out=None):
-    """Fills a detr_gemm_desc; returns (desc, profiler info).  ws_slice = (index, count): this call's share of WORKSPACE."""
+               dropout_step=None, compute=None, rowsum_a=None, rowsum_alpha=1.0, ws_slice=None, maskbits_out=None, ln=None):
+    """Fills a detr_gemm_desc; returns (desc, profiler info).  ws_slice = (index, count): this call's share of WORKSPACE.
+    ln: dict(gamma, beta, y, mean, rstd, eps[, add, y2][, y16]) -- the LayerNorm of the output rows from the same launch."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_y = ln["gamma"].data_ptr(), ln["beta"].data_ptr(), ln["y"].data_ptr()
+        d.ln_mean, d.ln_rstd, d.ln_eps = ln["mean"].data_ptr(), ln["rstd"].data_ptr(), float(ln["eps"])
+        if ln.get("y2") is not None:
+            d.ln_add, d.ln_add_rows, d.ln_y2 = ln["add"].data_ptr(), ln["add"].shape[0], ln["y2"].data_ptr()
+        d.ln_y16 = ptr(ln.get("y16"))
     d.A, d.lda, d.a_kcontig = A.data_ptr() + A.element_size() * a_off, lda, int(a_kcontig)
     is16 = lambda t: 1 if (t is not None and t.dtype == torch.bfloat16) else 0      # bf16 activation storage
     d.a_dtype, d.c_dtype, d.r_dtype, d.m_dtype = is16(A), is16(C), is16(residual), is16(mask)
@@ -572,14 +581,14 @@ def pick_split_k(M, N, K, max_split=1024):
 
 
 def linear_fwd_call(x2d, w_out_in, bias, out2d, *, alpha=1.0, residual=None, act=0, dropout_p=0.0, dropout_seed=0,
-                    dropout_step=None):
+                    dropout_step=None, ln=None):
     """(args, kwargs) of the gemm() that computes out = act((x @ W^T + b) * alpha + residual); W is (out, in) like
     custom_layers.Linear.  The *_call forms exist so that independent Linear products can be issued with gemm_group()."""
     M, K = x2d.shape
     N = w_out_in.shape[0]
     return ((M, N, K, x2d, x2d.stride(0), 1, w_out_in, w_out_in.stride(0), 1, out2d, out2d.stride(0)),
             dict(alpha=alpha, bias=bias, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), act=act,
-                 dropout_p=dropout_p, dropout_seed=dropout_seed, dropout_step=dropout_step))
+                 dropout_p=dropout_p, dropout_seed=dropout_seed, dropout_step=dropout_step, **({"ln": ln} if ln is not None else {})))
 
 
 def linear_dgrad_call(dy2d, w_out_in, dx2d, *, alpha=1.0, residual=None, mask=None):

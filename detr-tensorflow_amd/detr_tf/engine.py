@@ -39,6 +39,11 @@ H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
 DEFER_REDUCE = os.environ.get("DETR_HIP_DEFER_REDUCE", "1") != "0"     # queue the weight gradients' split-K reductions (A/B switch)
 WGRAD_STREAM = os.environ.get("DETR_HIP_WGRAD_STREAM", "1") != "0"      # backbone weight gradients on a second HIP stream (A/B switch)
 MASK_BITS = os.environ.get("DETR_HIP_MASK_BITS", "1") != "0"            # ReLU masks of the block outputs as bits (A/B switch, round 4)
+# bf16 compute mode: the LayerNorm behind an attention out-projection (2, default) / also behind the FFN's second Linear (1) runs in
+# that GEMM's launch (detr_gemm_desc.ln_*, row-complete 32 x 256 tiles; same bits as the two launches); 0 = off.  Measured, same box:
+# 16.53 / 16.56 ms (2) vs 16.53 / 16.61 (0) vs 16.85 / 16.96 (1): the K = 256 launches absorb their LayerNorm at equal time (18 launches
+# fewer per step), the K = 2048 ones lose 0.35 ms -- a 32-row tile walks 64 K tiles behind one barrier each
+LN_FUSE = int(os.environ.get("DETR_HIP_LN_FUSE", "2"))
 
 
 def mix32(x):
@@ -275,6 +280,14 @@ class DetrEngine:
         hip.layernorm_fwd(x, self.P.views[f"{pfx}/gamma"], self.P.views[f"{pfx}/beta"], y, mean, rstd, LN_EPS, add=add, y2=y2,
                           y16=y16)
 
+    def _ln_spec(self, rows, pfx, y, tag, add=None, y2=None, y16=None, ffn=False):
+        """The same LayerNorm as an epilogue of the GEMM that produces its input (hip.linear_fwd(..., ln=spec)); None when this
+        pass runs them as two launches (fp32 compute mode, DETR_HIP_LN_FUSE)."""
+        if self.compute != 1 or LN_FUSE == 0 or (ffn and LN_FUSE == 2) or (ffn and not self.ffn16):
+            return None
+        return dict(gamma=self.P.views[f"{pfx}/gamma"], beta=self.P.views[f"{pfx}/beta"], y=y, mean=self.buf(f"{tag}:mean", (rows,)),
+                    rstd=self.buf(f"{tag}:rstd", (rows,)), eps=LN_EPS, add=add, y2=y2, y16=y16)
+
     # ---- second launch stream ----------------------------------------------------------------------------------------------
     # Work that does not feed the critical chain is issued on a second HIP stream behind an event of the main stream that
     # follows its producer (a graph edge when the pass is captured) and is joined where its result is read:
@@ -346,7 +359,7 @@ class DetrEngine:
     # with N = 512 against rows 0..511 of in_proj_kernel.  The query scaling head_dim**-0.5 (:307) is folded into the
     # attention kernels (detr_attn_desc.scale).  In the backward the packed dQKV buffer turns the three data gradients
     # and the three residual-style adds into ONE GEMM with K = 768:  d_x = dQKV @ in_proj_kernel + d_residual.
-    def _self_attn_fwd(self, tag, pfx, qk_in, v_in, B, T, out, site):
+    def _self_attn_fwd(self, tag, pfx, qk_in, v_in, B, T, out, site, ln=None):
         W, bias = self._w(f"{pfx}/in_proj_kernel"), self.P.views[f"{pfx}/in_proj_bias"]
         QKV = self.buf(f"{tag}:QKV", (B * T, 3 * D))
         hip.gemm_group([hip.linear_fwd_call(qk_in, W[0:2 * D], bias[0:2 * D], QKV[:, 0:2 * D]),        # :294-300
@@ -357,7 +370,7 @@ class DetrEngine:
         hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, lse, B, HEADS, T, T, scale=float(HD) ** -0.5,
                       dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)                    # :307-345
         hip.linear_fwd(O, self._w(f"{pfx}/out_proj_kernel"), self.P.views[f"{pfx}/out_proj_bias"], out, residual=v_in,
-                       dropout_p=dp, dropout_seed=site + 1, dropout_step=self._seed_dev)               # :346-347 + :169
+                       dropout_p=dp, dropout_seed=site + 1, dropout_step=self._seed_dev, ln=ln)        # :346-347 + :169 (+ the LayerNorm behind it)
 
     def _self_attn_bwd(self, tag, pfx, d_out, d_res, qk_in, v_in, B, T, d_x, site, acc_qk=None):
         """d_out: gradient of the out-projection output (dropout backward already applied), d_res: gradient of the
@@ -398,14 +411,14 @@ class DetrEngine:
     def ffn16(self):
         return self.compute == 1 and H16
 
-    def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0, x16=None):
+    def _ffn_fwd(self, tag, pfx, x, out_pre_ln, seed=0, x16=None, ln=None):
         V = self.P.views
         dp, _ = self._drop
         h = self.buf(f"{tag}:h", (x.shape[0], FF), torch.bfloat16 if self.ffn16 else torch.float32)
         hip.linear_fwd(x16 if x16 is not None else x, self._w(f"{pfx}/linear1/kernel"), V[f"{pfx}/linear1/bias"], h, act=1,
                        dropout_p=dp, dropout_seed=seed, dropout_step=self._seed_dev)    # :172-174
         hip.linear_fwd(h, self._w(f"{pfx}/linear2/kernel"), V[f"{pfx}/linear2/bias"], out_pre_ln, residual=x, dropout_p=dp,
-                       dropout_seed=seed + 1, dropout_step=self._seed_dev)             # :175-176
+                       dropout_seed=seed + 1, dropout_step=self._seed_dev, ln=ln)      # :175-176 (+ the LayerNorm behind it)
 
     def _ffn_bwd(self, tag, pfx, d_y, d_f, x, dx, x16=None):
         """d_f: grad of (drop(linear2(drop(relu(linear1(x))))) + x); d_y = dropout_bwd(d_f) (from the LayerNorm backward
@@ -598,16 +611,20 @@ class DetrEngine:
         for i in range(self.num_enc):
             pfx, tag = f"transformer/encoder/layer_{i}", f"enc{i}"
             a = self.buf(f"{tag}:a", (B * L, D))
-            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, x, B, L, a, site=16 * i)
             x1 = self.buf(f"{tag}:x1", (B * L, D))
             x1h = self.buf(f"{tag}:x1h", (B * L, D), torch.bfloat16) if self.ffn16 else None
-            self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1", y16=x1h)
+            ln1 = self._ln_spec(B * L, f"{pfx}/norm1", x1, f"{tag}:ln1", y16=x1h)
+            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qk, x, B, L, a, site=16 * i, ln=ln1)
+            if ln1 is None:
+                self._ln_fwd(a, f"{pfx}/norm1", x1, f"{tag}:ln1", y16=x1h)
             f = self.buf(f"{tag}:f", (B * L, D))
-            self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2, x16=x1h)
             x2 = self.buf(f"{tag}:x2", (B * L, D))
             # x2 + pos = the q / k input of the next layer, or `memory + pos` of the decoder (:219), in the same launch
             qk = self.buf(f"enc{i + 1}:qk" if i + 1 < self.num_enc else "dec:mem_pos", (B * L, D))
-            self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2", add=pos, y2=qk)
+            ln2 = self._ln_spec(B * L, f"{pfx}/norm2", x2, f"{tag}:ln2", add=pos, y2=qk, ffn=True)
+            self._ffn_fwd(tag, pfx, x1, f, seed=16 * i + 2, x16=x1h, ln=ln2)
+            if ln2 is None:
+                self._ln_fwd(f, f"{pfx}/norm2", x2, f"{tag}:ln2", add=pos, y2=qk)
             x = x2
         memory, mem_pos = x, qk
         if self.num_enc == 0:
@@ -635,10 +652,12 @@ class DetrEngine:
             pfx, tag = f"transformer/decoder/layer_{i}", f"dec{i}"
             ds = 16 * (32 + i)
             a1 = self.buf(f"{tag}:a1", (B * Q, D))
-            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, tgt, B, Q, a1, site=ds)
             t1 = self.buf(f"{tag}:t1", (B * Q, D))
             q2 = self.buf(f"{tag}:q2", (B * Q, D))
-            self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1", add=qpos, y2=q2)          # q2 = t1 + query_pos (:219)
+            ln1 = self._ln_spec(B * Q, f"{pfx}/norm1", t1, f"{tag}:ln1", add=qpos, y2=q2)
+            self._self_attn_fwd(f"{tag}:sa", f"{pfx}/self_attn", qin, tgt, B, Q, a1, site=ds, ln=ln1)
+            if ln1 is None:
+                self._ln_fwd(a1, f"{pfx}/norm1", t1, f"{tag}:ln1", add=qpos, y2=q2)      # q2 = t1 + query_pos (:219)
             # cross attention: Q from this layer, K / V column blocks of the shared projection buffer
             cp = f"{pfx}/multihead_attn"
             Wc, bc = self._w(f"{cp}/in_proj_kernel"), V[f"{cp}/in_proj_bias"]
@@ -651,19 +670,20 @@ class DetrEngine:
             hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, lse, B, HEADS, Q, L,
                           scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev)
             a2 = self.buf(f"{tag}:a2", (B * Q, D))
-            hip.linear_fwd(Oc, self._w(f"{cp}/out_proj_kernel"), V[f"{cp}/out_proj_bias"], a2, residual=t1, dropout_p=dp,
-                           dropout_seed=ds + 3, dropout_step=self._seed_dev)              # :226
             t2 = self.buf(f"{tag}:t2", (B * Q, D))
             t2h = self.buf(f"{tag}:t2h", (B * Q, D), torch.bfloat16) if self.ffn16 else None
-            self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2", y16=t2h)
+            ln2 = self._ln_spec(B * Q, f"{pfx}/norm2", t2, f"{tag}:ln2", y16=t2h)
+            hip.linear_fwd(Oc, self._w(f"{cp}/out_proj_kernel"), V[f"{cp}/out_proj_bias"], a2, residual=t1, dropout_p=dp,
+                           dropout_seed=ds + 3, dropout_step=self._seed_dev, ln=ln2)      # :226 (+ norm2)
+            if ln2 is None:
+                self._ln_fwd(a2, f"{pfx}/norm2", t2, f"{tag}:ln2", y16=t2h)
             f = self.buf(f"{tag}:f", (B * Q, D))
-            self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4, x16=t2h)
             t3 = self._bufs[f"{tag}:t3"] = t3all[i]
-            if i + 1 < nd:
-                qin = self.buf(f"dec{i + 1}:qin", (B * Q, D))
-                self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3", add=qpos, y2=qin)
-            else:
-                self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3")
+            qin = self.buf(f"dec{i + 1}:qin", (B * Q, D)) if i + 1 < nd else None        # next layer's tgt + query_pos
+            ln3 = self._ln_spec(B * Q, f"{pfx}/norm3", t3, f"{tag}:ln3", add=qpos if qin is not None else None, y2=qin, ffn=True)
+            self._ffn_fwd(tag, pfx, t2, f, seed=ds + 4, x16=t2h, ln=ln3)
+            if ln3 is None:
+                self._ln_fwd(f, f"{pfx}/norm3", t3, f"{tag}:ln3", add=qpos if qin is not None else None, y2=qin)
             tgt = t3
         # the shared decoder norm of every level (:121-125) in one launch (round 4: it was one 800-row launch per layer, forward and backward)
         self._ln_fwd(t3all.view(nd * B * Q, D), "transformer/decoder/norm", hs.view(nd * B * Q, D), "dec:lnf")

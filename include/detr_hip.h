@@ -127,6 +127,14 @@ typedef struct {
      * the activation tensor: `mask` pointing to those bytes with m_dtype = 2 and ldmask = their row pitch in BYTES (1/16 of the
      * bytes of the bf16 tensor on an HBM-bound launch; resnet_backbone.py:132-135 backward). */
     uint8_t *maskbits_out; int64_t ld_maskbits_out;
+    /* Optional fused LayerNormalization of the output rows (ln_y != NULL; transformer.py:151-152 behind every attention / FFN block,
+     * :169-170,177,215-233): C = drop((A B^T + bias) * alpha) + residual is written as usual (the backward reads the LayerNorm INPUT)
+     * and, from the same launch,  ln_y = LayerNorm(C; ln_gamma, ln_beta, ln_eps), ln_mean / ln_rstd [M], optionally
+     * ln_y2[r] = ln_y[r] + ln_add[r % ln_add_rows] and the bf16 twin ln_y16 -- the outputs of detr_hip_layernorm_fwd, bit for bit.
+     * Needs: compute = 1, N = 256 = ldc (contiguous fp32 C / ln_y / ln_y2 / residual rows), a_kcontig = b_kcontig = 1, b_dtype = 1,
+     * K % 8 == 0, batch = split_k = 1, act = 0, no scale / mask; anything else is rejected. */
+    const float *ln_gamma, *ln_beta; float *ln_y, *ln_mean, *ln_rstd; const float *ln_add; int32_t ln_add_rows; float *ln_y2;
+    uint16_t *ln_y16; float ln_eps;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
 int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_t n, void *stream);

@@ -878,6 +878,59 @@ def test_fused_attention_dropout(hip, B, T, S, compute):
     assert bool((dqb[:, D:] == 5.0).all()) and bool((dkvb[:, :2 * D] == 5.0).all()) and bool((dkvb[:, 3 * D:4 * D] == 5.0).all())
 
 
+@pytest.mark.parametrize("M,K,a16,p,use_res,use_add,use_y16", [
+    (800, 256, False, 0.1, True, True, False),       # decoder out-projection + norm1 (+ query_pos twin)
+    (8400, 256, False, 0.1, True, False, True),      # encoder out-projection + norm1 (+ bf16 twin)
+    (8400, 2048, True, 0.1, True, True, False),      # encoder FFN linear2 + norm2 (bf16 hidden activation)
+    (37, 2048, True, 0.0, False, False, True),       # ragged tile, no dropout / residual
+    (800, 512, False, 0.25, True, True, True),
+])
+def test_gemm_with_fused_layernorm_equals_the_two_launches(hip, M, K, a16, p, use_res, use_add, use_y16):
+    """detr_gemm_desc.ln_* (round 4): out = drop((x W^T + b)) + residual and LayerNorm(out) from ONE launch of the row-complete
+    32 x 256 tile kernel against the GEMM on the tile engine followed by detr_hip_layernorm_fwd: same C (the LayerNorm input the
+    backward needs), same y / y2 / bf16 twin / mean / rstd.  The K loop feeds every accumulator the same k in the same order and
+    the fused epilogue is the LayerNorm kernel's arithmetic, so everything must be IDENTICAL bits."""
+    torch.manual_seed(M + K)
+    N = 256
+    x = g(torch.randn(M, K))
+    if a16:
+        x = x.to(torch.bfloat16)
+    W = g(torch.randn(N, K) / K ** 0.5).to(torch.bfloat16)
+    bias, res = g(torch.randn(N)), g(torch.randn(M, N))
+    gam, bet = g(torch.rand(N) + 0.5), g(torch.randn(N))
+    add = g(torch.randn(100 if M % 100 == 0 else M, N))
+    step = torch.tensor([0x2468ACE, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+    kw = dict(residual=res if use_res else None, dropout_p=p, dropout_seed=9, dropout_step=step)
+    outs = []
+    for fused in (False, True):
+        C = torch.full((M, N), 3.0, device=DEV)
+        y, y2 = torch.full((M, N), 5.0, device=DEV), torch.full((M, N), 6.0, device=DEV)
+        y16 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+        hip.COMPUTE_BF16 = 1
+        try:
+            if fused:
+                hip.linear_fwd(x, W, bias, C, ln=dict(gamma=gam, beta=bet, y=y, mean=mean, rstd=rstd, eps=1e-5, add=add if use_add else None,
+                                                      y2=y2 if use_add else None, y16=y16 if use_y16 else None), **kw)
+            else:
+                hip.linear_fwd(x, W, bias, C, **kw)
+                hip.layernorm_fwd(C, gam, bet, y, mean, rstd, 1e-5, add=add if use_add else None, y2=y2 if use_add else None,
+                                  y16=y16 if use_y16 else None)
+        finally:
+            hip.COMPUTE_BF16 = 0
+        torch.cuda.synchronize()
+        outs.append((C, y, y2, y16, mean, rstd))
+    for a, b, what in zip(outs[0], outs[1], ("C", "y", "y2", "y16", "mean", "rstd")):
+        assert torch.equal(a, b), what
+    C, y = outs[1][0], outs[1][1]
+    ref = F.layer_norm(C.double().cpu(), (N,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    close(y, ref, rtol=2e-5, what="fused layernorm vs fp64 on the same C")
+    if p > 0.0:
+        lin = (x.float() @ W.float().t() + bias).cpu()
+        dropped = ((C.cpu() - (res.cpu() if use_res else 0.0)).abs() < 1e-12) & (lin.abs() > 1e-3)
+        assert abs(float(dropped.float().mean()) - p) < 0.02
+
+
 @pytest.mark.parametrize("rows,C,period", [(8400, 256, 1050), (800, 256, 100), (37, 64, 37)])
 def test_layernorm_fused_outputs(hip, rows, C, period):
     """Fused side outputs of the LayerNorm launches: forward y2 = y + add[r % period] (the `+ pos` operand of the next
