@@ -611,8 +611,10 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
     while (done < n) {
         const int m = (n - done) < GEMM_MAX_GROUP ? (n - done) : GEMM_MAX_GROUP;
         GemmPlan p[GEMM_MAX_GROUP];
-        for (int i = 0; i < m; ++i)
+        for (int i = 0; i < m; ++i) {
+            DETR_REQUIRE(!descs[done + i].ln_y, "gemm group: the fused LayerNorm (ln_y) exists for single launches only");
             if (gemm_prepare(descs + done + i, p[i])) return -1;
+        }
         // one launch needs ONE kernel variant: 64x64 tiles, same layouts / storage types, no batch; members may differ in shape
         bool same = m > 1 && tune(T_GEMM_GROUP) != 2;
         for (int i = 0; i < m && same; ++i)

@@ -929,6 +929,18 @@ def test_gemm_with_fused_layernorm_equals_the_two_launches(hip, M, K, a16, p, us
         lin = (x.float() @ W.float().t() + bias).cpu()
         dropped = ((C.cpu() - (res.cpu() if use_res else 0.0)).abs() < 1e-12) & (lin.abs() > 1e-3)
         assert abs(float(dropped.float().mean()) - p) < 0.02
+    # what the fused form does not cover is rejected loudly: fp32 compute, N != 256, a grouped launch
+    spec = dict(gamma=gam, beta=bet, y=outs[1][1], mean=outs[1][4], rstd=outs[1][5], eps=1e-5)
+    with pytest.raises(RuntimeError):
+        hip.linear_fwd(x.float(), W.float(), bias, outs[1][0], ln=spec)                       # compute = 0
+    hip.COMPUTE_BF16 = 1
+    try:
+        with pytest.raises(RuntimeError):
+            hip.linear_fwd(x, W[:128], bias[:128], torch.zeros(M, 128, device=DEV), ln=spec)  # N = 128
+        with pytest.raises(RuntimeError):
+            hip.gemm_group([hip.linear_fwd_call(x, W, bias, outs[1][0], ln=spec), hip.linear_fwd_call(x, W, bias, outs[0][0])])
+    finally:
+        hip.COMPUTE_BF16 = 0
 
 
 @pytest.mark.parametrize("rows,C,period", [(8400, 256, 1050), (800, 256, 100), (37, 64, 37)])
