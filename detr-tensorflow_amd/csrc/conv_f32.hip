@@ -1175,8 +1175,10 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     a.part_stride = 0;
     a.slab_ts = 0;
     // whole tiles (channel counts are multiples of the tile): the tile-ordered slab has exactly the row-major slab's size
+    // (the tile-ordered reduce does 16-byte read-modify-writes of dw and 16-byte slab loads: `partial` already holds aligned16(ws);
+    //  a gradient buffer that is only 4-byte aligned keeps the row-major slabs and the scalar reduce -- the rule of gemm_slab_ts)
     const bool ts = partial && WGM == 2 && WGN == 2 && a.Ci % BM == 0 && a.Co % BN == 0 && (!final_e.scale || aligned16(final_e.scale)) &&
-                    tune(T_SLAB_TS) != 2;
+                    aligned16(dw_final) && tune(T_SLAB_TS) != 2;
     if (partial) {
         a.dw = ws;
         a.part_stride = part;
@@ -1212,7 +1214,7 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
     const EpiArgs final_e = a.e;
     a.part_stride = 0;
     a.slab_ts = 0;
-    const bool ts = partial && (!final_e.scale || aligned16(final_e.scale)) && tune(T_SLAB_TS) != 2;
+    const bool ts = partial && (!final_e.scale || aligned16(final_e.scale)) && aligned16(dw_final) && tune(T_SLAB_TS) != 2;
     if (partial) {
         a.dw = ws;
         a.part_stride = part;

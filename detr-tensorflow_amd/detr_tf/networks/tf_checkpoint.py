@@ -322,10 +322,14 @@ def read_bundle(prefix, verify_tensors=1 << 20):
     return out
 
 
-def load_tf_checkpoint(prefix):
+def load_tf_checkpoint(prefix, duplicates=None):
     """{variable name: array}.  Object-based checkpoints are renamed through their object graph (attribute VARIABLE_VALUE ->
     the variable's full_name without the ':0' suffix); optimizer slots and bookkeeping entries (save counter) keep their
-    checkpoint keys.  Name-based checkpoints are returned unchanged."""
+    checkpoint keys.  Name-based checkpoints are returned unchanged.
+    Eager Keras variable names are not unique (several optimizers may each own `Adam/iter:0`): the first entry of a name
+    keeps it, later ones stay under their checkpoint key, and `duplicates` (a list, optional) receives (name, key) of each
+    -- the caller decides whether a duplicated name matters (networks.weights.load_tf_checkpoint_params raises when it is
+    one of the parameters it was asked for)."""
     bundle = read_bundle(prefix)
     graph = bundle.pop(OBJECT_GRAPH_KEY, None)
     if graph is None:
@@ -335,8 +339,10 @@ def load_tf_checkpoint(prefix):
     for name, full, key in parse_object_graph(graph):
         if name == "VARIABLE_VALUE" and key in bundle and full:
             var = full[:-2] if full.endswith(":0") else full
-            if var in out:      # non-unique eager names would silently drop a tensor
-                raise ValueError(f"{prefix}: two checkpoint entries carry the variable name {var!r} ({key} and another one)")
+            if var in out:
+                if duplicates is not None:
+                    duplicates.append((var, key))
+                continue
             out[var] = bundle[key]
             renamed.add(key)
     for k, v in bundle.items():

@@ -252,7 +252,16 @@ def load_tf_checkpoint_params(prefix, wanted):
     """Parameters of a TensorFlow checkpoint `<prefix>.index` / `.data-*` (the reference's `weights="detr"` files,
     weights.py:5-11,33) under this package's names; no TensorFlow needed (networks/tf_checkpoint.py)."""
     from .tf_checkpoint import load_tf_checkpoint
-    return map_tf_variables(load_tf_checkpoint(prefix), wanted)
+    dups = []
+    variables = load_tf_checkpoint(prefix, duplicates=dups)
+    # a variable name that occurs twice is only a problem when it is one of the wanted parameters (optimizer / bookkeeping
+    # variables of a user checkpoint may repeat freely)
+    by_len = sorted(wanted, key=len, reverse=True)
+    for var, key in dups:
+        hit = next((k for k in by_len if var == k or var.endswith("/" + k)), None)
+        if hit is not None:
+            raise ValueError(f"{prefix}: two checkpoint entries carry the variable name {var!r} (parameter {hit}; second entry {key})")
+    return map_tf_variables(variables, wanted)
 
 
 def main(argv=None):

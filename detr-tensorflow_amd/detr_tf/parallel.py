@@ -155,8 +155,16 @@ class DataParallel:
         timing = self.timing is not None and self.cuda and bool(self.works)
         w0 = self._ev(torch.cuda.current_stream()) if timing else None
         host_side = dist.is_initialized() and dist.get_backend(self.group) != "nccl"
+        # With async_op=True the RCCL process group runs a collective on its OWN internal stream; Work.wait() orders the
+        # stream that is current at the call behind it.  The waits are therefore issued with the COMMUNICATION stream current:
+        # the bf16 copy-back below is enqueued there and must not start before its bucket is reduced, and the
+        # compute stream then waits for the communication stream once, which covers collectives and copies alike.
         for k, w in enumerate(self.works):
-            w.wait()
+            if self.cuda:
+                with torch.cuda.stream(self.comm_stream):
+                    w.wait()
+            else:
+                w.wait()
             if timing and host_side and k < len(self.timing["cur"]):
                 self.timing["cur"][k][3] = self._ev(self.comm_stream)
         self.works = []

@@ -129,6 +129,7 @@ class GraphedTrainStep:
         self.probe = None                                              # {"graph_ms", "eager_ms"} once "auto" has decided (once per stepper)
         self._probe_t = {}
         self._probe_dirty = False
+        self._probe_skipped = False
         self.total_calls = 0                                           # never reset: the probe schedule of "auto" runs on it
 
     def _signature(self, images, t_bbox, t_class):
@@ -260,6 +261,11 @@ class GraphedTrainStep:
         self.calls += 1
         eager_only = (self.launch == "eager" or _gradient_aggregate(cfg) > 1 or bool(getattr(cfg, "check_matching", False)))
         if eager_only:
+            # an eager-only call that lands inside the probe schedule of an "auto" stepper spoils the window it falls into:
+            # the window's first step may never set its start time, its last step would time a partial window
+            if self.launch == "auto" and self.probe is None:
+                self._probe_dirty = True
+                self._probe_skipped = True
             return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         warm = self.calls <= self.eager_steps       # first sighting of a shape: eager (allocates the static memory plan)
         if self.launch != "auto" or self.probe is not None:
@@ -285,12 +291,13 @@ class GraphedTrainStep:
         if first:
             torch.cuda.synchronize()
             self._probe_dirty = warm or (phase == "graph" and self.step_graph is None)     # a (re-)recording inside the window
+            self._probe_skipped = False
             self._probe_t[phase] = time.perf_counter()
         out = self._replay(images, t_bbox, t_class) if (phase == "graph" and not warm) else \
             train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         if last:
             torch.cuda.synchronize()
-            if not self._probe_dirty:
+            if not self._probe_dirty and not getattr(self, "_probe_skipped", False) and phase in self._probe_t:
                 self._probe_t[phase + "_s"] = time.perf_counter() - self._probe_t[phase]
             if phase == "eager":
                 self._decide()

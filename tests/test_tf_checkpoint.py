@@ -238,3 +238,27 @@ def test_model_loads_a_tf_checkpoint_prefix(hip, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path / "weights")
     with pytest.raises(FileNotFoundError, match="detr.ckpt.index"):
         get_detr_model(TrainingConfig(), include_top=True, num_encoder_layers=1, num_decoder_layers=1, weights="detr")
+
+
+def test_duplicate_variable_names_only_matter_for_wanted_parameters(tmp_path):
+    """Eager Keras names are not unique (two optimizers both own `Adam/iter:0`): such a checkpoint loads -- first entry under the
+    name, later ones under their checkpoint keys -- and only a duplicated name that is one of the WANTED parameters is an error
+    (ADVICE r4)."""
+    from detr_tf.networks.weights import load_tf_checkpoint_params
+    k = lambda i: f"obj-{i}/v{T.VARIABLE_SUFFIX}"
+    arrays = {k(0): np.full((8, 4), 1.0, np.float32), k(1): np.array(3, np.int64), k(2): np.array(9, np.int64)}
+    graph = [("VARIABLE_VALUE", "detr/class_embed/kernel:0", k(0)), ("VARIABLE_VALUE", "Adam/iter:0", k(1)),
+             ("VARIABLE_VALUE", "Adam/iter:0", k(2))]
+    prefix = str(tmp_path / "dup.ckpt")
+    write_bundle(prefix, arrays, graph)
+    dups = []
+    got = T.load_tf_checkpoint(prefix, duplicates=dups)
+    assert int(got["Adam/iter"]) == 3 and int(got[k(2)]) == 9 and dups == [("Adam/iter", k(2))]
+    params, unused = load_tf_checkpoint_params(prefix, {"class_embed/kernel": (8, 4)})
+    assert set(params) == {"class_embed/kernel"} and "Adam/iter" in unused
+    arrays[k(3)] = np.full((8, 4), 2.0, np.float32)
+    graph.append(("VARIABLE_VALUE", "detr/class_embed/kernel:0", k(3)))
+    prefix2 = str(tmp_path / "dup2.ckpt")
+    write_bundle(prefix2, arrays, graph)
+    with pytest.raises(ValueError, match="two checkpoint entries"):
+        load_tf_checkpoint_params(prefix2, {"class_embed/kernel": (8, 4)})
