@@ -103,6 +103,10 @@ enum TuneKey {
     T_GEMM_K64,
     T_EPI_WIDE,
     T_SLAB_TS,           // 2: split-K slabs stay row-major (A/B of the tile-ordered form, round 4)
+    T_GEMM_RING,         // 2: the 8-wave LDS-DMA ring kernel (gemm_ring.h, round 5) is off; 1: taken wherever eligible (tests)
+    T_RING_NS,           // ring stages forced (2 / 3); 0 = as many as fit
+    T_RING_BN,           // column panel forced (128 / 256); 0 = cost model
+    T_RING_WGS,          // workgroup target forced; 0 = cost model
     T_COUNT
 };
 int tune(TuneKey k);

@@ -29,6 +29,10 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_GEMM_K64",
     "DETR_HIP_EPI_WIDE",
     "DETR_HIP_SLAB_TS",
+    "DETR_HIP_GEMM_RING",
+    "DETR_HIP_RING_NS",
+    "DETR_HIP_RING_BN",
+    "DETR_HIP_RING_WGS",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {

@@ -296,7 +296,7 @@ struct TileCfg {
     static constexpr int WTN = BN / WGN;
     static constexpr int TM = WTM / 32;
     static constexpr int TN = WTN / 32;
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 waves per workgroup (8: the ring kernel, gemm_ring.h)");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 };
 

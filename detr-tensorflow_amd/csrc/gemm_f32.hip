@@ -6,6 +6,7 @@
 #include "gemm_stream.h"
 
 #include "gemm_kernels.h"
+#include "gemm_ring.h"
 
 namespace detr {
 
@@ -546,6 +547,21 @@ static int gemm_ln_launch(const GemmPlan &p, hipStream_t s) {
     return 0;
 }
 
+// The ring kernel (gemm_ring.h) takes the tall unsplit GEMMs whose operands are both bf16 in memory with a K-contiguous A: the
+// K >= 512 1x1 convolutions of layer2-layer4 (forward and input gradient) and the encoder's FFN at M = B*L.  DETR_HIP_GEMM_RING=2
+// disables it, =1 takes every eligible shape (tests: small M as well).
+static bool gemm_ring_eligible(const GemmPlan &p, RingPlan &rp) {
+    const detr_gemm_desc *d = p.d;
+    const GemmArgs &g = p.g;
+    const int mode = tune(T_GEMM_RING);
+    if (mode == 2) return false;
+    if (!(p.bf16c && g.a16 && g.b16 && p.ak && p.batch == 1 && p.split == 1 && !g.rowsum && !d->ln_y)) return false;
+    if (!(d->K % RING_BK == 0 && d->K >= 2 * RING_BK && d->N >= 128 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) &&
+          aligned16(d->B))) return false;
+    if (mode != 1 && !(d->M >= 4096 && d->K >= 512)) return false;
+    return gemm_ring_plan(d->M, d->N, d->K, rp);
+}
+
 static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const GemmArgs &g = p.g;
     const detr_gemm_desc *d = p.d;
@@ -556,6 +572,15 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         gemm_stream_launch(p, s);
         DETR_LAUNCH_CHECK("gemm (stream)");
         return 0;
+    }
+    {
+        RingPlan rp;
+        if (gemm_ring_eligible(p, rp)) {
+            if (gemm_ring_launch(g, bk, rp, s)) return -1;
+            DETR_LAUNCH_CHECK("gemm (ring)");
+            if (d->defer_out) d->defer_out->splits = 0;
+            return 0;
+        }
     }
     if (p.bf16c) {
         if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
@@ -621,6 +646,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
             same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
                    p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&
                    !gemm_stream_eligible(p[i]);
+        if (same) { RingPlan rp; for (int i = 0; i < m && same; ++i) same = !gemm_ring_eligible(p[i], rp); }
         if (!same) {
             for (int i = 0; i < m; ++i)
                 if (gemm_launch(p[i], s)) return -1;

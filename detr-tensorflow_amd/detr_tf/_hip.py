@@ -118,6 +118,7 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_gemm_group_f32": [POINTER(GemmDesc), c_int32, c_void_p],
+    "detr_hip_gemm_ring_plan": [c_int32, c_int32, c_int32, POINTER(c_int32)],
     "detr_hip_splitk_reduce_many": [POINTER(ReduceDesc), c_int32, c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
     "detr_hip_maxpool3x3s2_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
@@ -169,7 +170,7 @@ _SIGNATURES_I64 = {
     "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
-ABI_VERSION = 5
+ABI_VERSION = 6
 # order of detr_hip_struct_layout's `which`
 LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 5
+#define DETR_HIP_ABI_VERSION 6
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -476,6 +476,14 @@ int64_t detr_hip_workspace_bytes_gemm(const detr_gemm_desc *d);
 int64_t detr_hip_workspace_bytes_conv3x3(const detr_conv3x3_desc *d, int32_t mode);
 int64_t detr_hip_workspace_bytes_stem(const detr_stem_desc *d, int32_t mode);
 int64_t detr_hip_workspace_bytes_layernorm(const detr_layernorm_desc *d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tile plan of the 8-wave LDS-DMA "ring" GEMM (csrc/gemm_ring.h, round 5) that detr_hip_gemm_f32 takes for the tall unsplit
+ * bf16 GEMMs (the K >= 512 1x1 convolutions of resnet_backbone.py:119-135 -- forward and input gradient -- and the FFN of
+ * transformer.py:172-177): out[0..7] = {32-row blocks per wave, 32-column blocks per wave, ring stages, row pitch of the tile
+ * grid, tiles along M, tiles along N, workgroups, LDS bytes}.  Returns 1 when the shape has a plan, 0 when it has none.  Pure
+ * host arithmetic (tests, tuning scripts); `out` may be null. */
+int detr_hip_gemm_ring_plan(int32_t M, int32_t N, int32_t K, int32_t *out);
 
 #ifdef __cplusplus
 }

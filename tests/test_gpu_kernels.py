@@ -1771,3 +1771,133 @@ def test_conv3x3_wgrad_tile_ordered_slabs_equal_row_major(hip, C, stride):
             hip.set_tuning("DETR_HIP_SLAB_TS", None)
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+
+
+RING_CASES = [
+    # M, N, K, b_kcontig, epilogue, C / residual fp32?
+    (600, 256, 128, 1, "res_mask", False),
+    (600, 256, 128, 0, "bias_relu", False),
+    (1333, 128, 256, 1, "mask", False),
+    (1333, 128, 256, 0, "plain", False),
+    (2100, 512, 192, 0, "bias_res_relu", False),
+    (2100, 384, 192, 1, "scale_bias_res_mask_relu", False),
+    (840, 256, 2048, 1, "bias_res", True),
+    (840, 256, 2048, 0, "drop_res", True),
+    (4200, 1024, 512, 1, "res_mask", False),
+    (33, 256, 64 * 3, 1, "bias_relu", False),
+    (8, 136, 128, 0, "bias", False),
+]
+
+
+@pytest.mark.parametrize("variant", ["auto", "ns2", "bn128", "wgs64", "wgs512"])
+@pytest.mark.parametrize("M,N,K,bk,epi,f32", RING_CASES)
+def test_gemm_ring_is_bit_identical_to_the_tile_engine(hip, variant, M, N, K, bk, epi, f32):
+    """The 8-wave LDS-DMA ring kernel (csrc/gemm_ring.h, round 5) against the 4-wave tile engine (DETR_HIP_GEMM_RING=2): same MFMA
+    instruction, every accumulator sees its k-steps in ascending order, same epilogue function -> IDENTICAL bits.  Covers both B
+    layouts ([n][k]: XOR-swizzled K-contiguous image; [k][n]: transpose-read image), ragged M (last tile / last 32-row block / a row
+    wave without rows), N that is not a multiple of the column panel, 2- and 3-stage rings, both column panels, forced workgroup
+    counts (row pitches from 8 to 256), every epilogue item incl. fp32 C / residual and the keyed dropout.  The tile engine itself
+    is pinned against fp64 here as well."""
+    torch.manual_seed(M + N + K + bk)
+    b16 = torch.bfloat16
+    A = g(torch.randn(M, K)).to(b16)
+    Bm = (g(torch.randn(N, K) / K ** 0.5) if bk else g(torch.randn(K, N) / K ** 0.5)).to(b16)
+    bias, scale = g(torch.randn(N)), g(torch.rand(N) + 0.5)
+    rdt = torch.float32 if f32 else b16
+    res, msk = g(torch.randn(M, N)).to(rdt), g(torch.randn(M, N)).to(b16)
+    step = torch.tensor([0x13579bd, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+    kw = dict(compute=1)
+    if "bias" in epi:
+        kw.update(bias=bias)
+    if "scale" in epi:
+        kw.update(scale=scale, alpha=0.75)
+    if "relu" in epi:
+        kw.update(act=1)
+    if "res" in epi:
+        kw.update(residual=res, ldr=N)
+    if "mask" in epi:
+        kw.update(mask=msk, ldmask=N)
+    if "drop" in epi:
+        kw.update(dropout_p=0.1, dropout_seed=11, dropout_step=step)
+    forced = {"auto": {}, "ns2": {"DETR_HIP_RING_NS": "2"}, "bn128": {"DETR_HIP_RING_BN": "128"}, "wgs64": {"DETR_HIP_RING_WGS": "64"},
+              "wgs512": {"DETR_HIP_RING_WGS": "512"}}[variant]
+    plan = (ctypes.c_int32 * 8)()
+    outs = []
+    for ring in ("1", "2"):
+        env = {"DETR_HIP_GEMM_RING": ring, "DETR_HIP_GEMM_STREAM": "2"}
+        env.update(forced)
+        for k, v in env.items():
+            hip.set_tuning(k, v)
+        try:
+            has_plan = hip.load().detr_hip_gemm_ring_plan(M, N, K, plan)
+            C = torch.full((M, N), 7.0, device=DEV, dtype=rdt)
+            hip.gemm(M, N, K, A, K, 1, Bm, Bm.stride(0), bk, C, N, **kw)
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                hip.set_tuning(k, None)
+        outs.append(C.float().cpu())
+    ring_out, tile_out = outs
+    if not has_plan:
+        pytest.skip(f"no ring plan for this shape under {variant}")
+    want = A.double().cpu() @ (Bm.double().cpu().t() if bk else Bm.double().cpu())
+    if "scale" in epi:
+        want = want * scale.double().cpu()
+    if "bias" in epi:
+        want = want + bias.double().cpu()
+    if "scale" in epi:
+        want = want * 0.75
+    if "drop" not in epi:
+        if "res" in epi:
+            want = want + res.double().cpu()
+        if "relu" in epi:
+            want = torch.relu(want)
+        if "mask" in epi:
+            want = torch.where(msk.double().cpu() > 0, want, torch.zeros_like(want))
+        tol = (2.0 ** -16 if f32 else 2.0 ** -7) * float(want.abs().max())
+        assert float((tile_out.double() - want).abs().max()) < tol
+    assert float(tile_out.abs().max()) > 0
+    assert torch.equal(ring_out, tile_out), (list(plan), float((ring_out - tile_out).abs().max()),
+                                             int((ring_out != tile_out).sum()), ring_out.numel())
+
+
+def test_gemm_ring_takes_the_step_shapes_and_repeats_exactly(hip):
+    """At the step's own sizes (M = 33600 / 8400 rows) the default dispatch takes the ring kernel (plan exists, result equals the tile
+    engine's bit for bit) and twenty back-to-back launches return the same bits every time -- the screen for a staged buffer read
+    before its DMA has landed (guide: 'place reads by the vmcnt / barrier count, never by clean runs'; a race shows up as rare
+    wrong tiles that come and go)."""
+    b16 = torch.bfloat16
+    for M, N, K, bk, kwx in [(33600, 256, 1024, 1, "mask"), (33600, 256, 1024, 0, "bias_relu"), (8400, 256, 2048, 1, "res32"),
+                             (8400, 2048, 512, 0, "bias_res_relu"), (33600, 1024, 512, 1, "res_mask")]:
+        torch.manual_seed(M + N + K)
+        A = g(torch.randn(M, K)).to(b16)
+        Bm = (g(torch.randn(N, K) / K ** 0.5) if bk else g(torch.randn(K, N) / K ** 0.5)).to(b16)
+        f32 = kwx == "res32"
+        rdt = torch.float32 if f32 else b16
+        kw = dict(compute=1)
+        if "bias" in kwx:
+            kw.update(bias=g(torch.randn(N)))
+        if "relu" in kwx:
+            kw.update(act=1)
+        if "res" in kwx:
+            kw.update(residual=g(torch.randn(M, N)).to(rdt), ldr=N)
+        if "mask" in kwx:
+            kw.update(mask=g(torch.randn(M, N)).to(b16), ldmask=N)
+        plan = (ctypes.c_int32 * 8)()
+        assert hip.load().detr_hip_gemm_ring_plan(M, N, K, plan) == 1
+        outs = []
+        for ring in (None, "2"):
+            hip.set_tuning("DETR_HIP_GEMM_RING", ring)
+            try:
+                C = torch.full((M, N), 7.0, device=DEV, dtype=rdt)
+                hip.gemm(M, N, K, A, K, 1, Bm, Bm.stride(0), bk, C, N, **kw)
+                torch.cuda.synchronize()
+                outs.append(C.clone())
+                if ring is None:
+                    for _ in range(20):
+                        C.fill_(3.0)
+                        hip.gemm(M, N, K, A, K, 1, Bm, Bm.stride(0), bk, C, N, **kw)
+                        assert torch.equal(C, outs[0])
+            finally:
+                hip.set_tuning("DETR_HIP_GEMM_RING", None)
+        assert torch.equal(outs[0], outs[1]), (M, N, K, bk, list(plan), int((outs[0] != outs[1]).sum()))
