@@ -107,6 +107,8 @@ enum TuneKey {
     T_RING_NS,           // ring stages forced (2 / 3); 0 = as many as fit
     T_RING_BN,           // column panel forced (128 / 256); 0 = cost model
     T_RING_WGS,          // workgroup target forced; 0 = cost model
+    T_RING_ROWS,         // row pitch forced (sweeps)
+    T_RING_ABLATE,       // timing experiments: RingArgs.ablate bits (results wrong when set)
     T_COUNT
 };
 int tune(TuneKey k);

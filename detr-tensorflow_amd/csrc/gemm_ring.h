@@ -17,8 +17,8 @@
 //   * the DMA writes lane-linearly, so the LDS image is chosen by the SOURCE address each lane requests (guide rule 21):
 //     K-contiguous rows are 128 B = eight 16-byte chunks, chunk c of row r sits at slot 8 r + (c ^ ((r >> 1) & 7)); the 16 lanes of
 //     every ds_read_b128 service group (rows distinct mod 16, one chunk index) then hit 16 distinct 16-byte slots of the 256-byte
-//     bank row: conflict-free without padding (which a lane-linear DMA could not produce).  [k][n] operands keep the
-//     transpose-read image of gemm_bf16_core.h ([4 k][16 n] sub-blocks, ds_read_b64_tr_b16).
+//     bank row: conflict-free without padding (which a lane-linear DMA could not produce).  [k][n] operands: a transpose-read
+//     image in row-major pieces (RingDmaMN below; fragments by ds_read_b64_tr_b16).
 // Pipeline of one tile (every wave issues its share of both operands' pieces; requests are unconditional -- past the last K
 // stage the descriptor is empty: no traffic, zeros into a stage nobody reads -- so the counted waits are exact on every path):
 //     prologue   issue stages 0 .. NS-2
@@ -44,6 +44,8 @@ struct RingArgs {
     int a_rows8;         // rows of the A stage image: tile_rows rounded up to a DMA piece (8 rows)
     int stage_bytes;     // a_rows8 * 128 + BN * 128
     int dump_off;        // byte offset of the 1 KB dump area behind the ring (pieces past the A image land there)
+    int ablate;          // timing experiments only (DETR_HIP_RING_ABLATE; results are WRONG with any bit set): 1 no fragment reads / MFMAs,
+                         // 2 no A requests, 4 no B requests, 8 no epilogue, 16 no K loop at all
 };
 
 // host side (gemm_ring.hip)
@@ -62,13 +64,38 @@ __device__ __forceinline__ void ring_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from buffer (`rs`, per-lane byte offset voff) to LDS bytes [lds_addr, lds_addr + 1024).
+// Inline assembly on purpose: hipcc's waitcnt pass knows that a `buffer_load ... lds` it emitted itself is a pending LDS write,
+// and in front of every ds_read_b64_tr_b16 (the [k][n] fragments) it therefore waits for vmcnt(0) -- measured: the [k][n] shapes ran
+// 6-17 us slower than the [n][k] ones, the ring drained at every k-step.  Which requests a read depends on is decided HERE,
+// by the counted waits of the pipeline (ring_wait_vmcnt in front of the barrier that publishes a stage); requests the compiler
+// does not know about can only make ITS OWN vmcnt waits (epilogue loads) wait longer, never shorter (the counter is in-order).
+// M0 carries the LDS address (what the compiler emits for the builtin: s_add_i32 m0, <addr>, 0); one wait state between the M0
+// write and the request (gfx9 hazard table: S_MOV M0 -> buffer ... lds).
+__device__ __forceinline__ void ring_dma_piece(u32x4 rs, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4 ring_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 r;
+    r[0] = (unsigned)b;
+    r[1] = (unsigned)(b >> 32) & 0xFFFFu;          // stride 0: raw buffer
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ unsigned ring_lds_addr(char *p) {      // LDS byte address of a pointer into the workgroup's shared array
+    return (unsigned)(unsigned long long)(lds_void_t *)p;
+}
+
 // K-contiguous operand [rows][k]: piece P = rows 8P .. 8P+7 of the stage image, lane (r = lane / 8, slot position lane % 8)
 template <int NP>
 struct RingDmaK {
     const unsigned short *base;
     long long text;            // bytes from `base` to the end of the operand
     unsigned voff[NP];         // loop-invariant per-lane offsets (BUF_OOB: row outside)
-    int lds_off[NP];           // wave-uniform byte offset of piece i inside the stage image, < 0: dump area
+    int lds_off[NP];           // wave-uniform byte offset of piece i inside the stage image
+    int in_img[NP];            // -1: the piece lies inside the stage image, 0: past it (its zeros go to the dump area)
     // rows [row0, row_end) of the operand belong to this tile; img_rows8: rows the stage image holds
     __device__ __forceinline__ void init(const void *p, long long ld, int row0, int row_end, int rows_total, int K, int img_rows8,
                                          int lane, int wave) {
@@ -81,25 +108,41 @@ struct RingDmaK {
             const int c = (lane & 7) ^ ((r >> 1) & 7);                     // source chunk that belongs at this lane's slot
             const int g = row0 + r;
             voff[i] = (g < row_end) ? (unsigned)((long long)g * ld * 2) + 16u * (unsigned)c : BUF_OOB;
-            lds_off[i] = (8 * P < img_rows8) ? P * 1024 : -1;
+            lds_off[i] = P * 1024;
+            in_img[i] = (8 * P < img_rows8) ? -1 : 0;
         }
     }
-    __device__ __forceinline__ void issue(int k0, int K, char *img, char *dump) const {
-        long long left = (k0 < K) ? text - 2ll * k0 : 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(base + k0), 0, (int)(unsigned)left, 0x00020000);
+    // descriptor of K stage k0: base advanced by k0, an EMPTY range past the last stage (no traffic); scalar instructions only
+    __device__ __forceinline__ u32x4 stage_rsrc(int k0, int K) const {
+        const unsigned left = (k0 < K) ? (unsigned)(text - 2ll * k0) : 0u;
+        return ring_rsrc(base + k0, left);
+    }
+    // piece I (a compile-time constant after inlining).  lds0: LDS byte address of the workgroup's array; img / dump: byte offsets into
+    // it.  Branch-free on purpose (mask arithmetic instead of ?: -- pointer- and flag-typed selects compiled to scalar branches,
+    // which cut the stage into several basic blocks).
+    __device__ __forceinline__ void issue_one(const int I, u32x4 rs, unsigned lds0, int img, int dump) const {
+        const int off = dump + (in_img[I] & (img + lds_off[I] - dump));      // wave-uniform
+        ring_dma_piece(rs, lds0 + (unsigned)off, voff[I]);
+    }
+    __device__ __forceinline__ void issue(int k0, int K, unsigned lds0, int img, int dump) const {
+        const u32x4 rs = stage_rsrc(k0, K);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            char *dst = lds_off[i] >= 0 ? img + lds_off[i] : dump;         // wave-uniform
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)dst, 16, voff[i], 0, 0, 0);
-        }
+        for (int i = 0; i < NP; ++i) issue_one(i, rs, lds0, img, dump);
     }
 };
 
-// MN-contiguous operand [k][mn], transpose-read image: sub-block (kb, ib) = 4 k x 16 mn at ((kb * NB + ib) * 128) bytes; piece P =
-// sub-blocks 8P .. 8P+7; lane: sub-block 8P + lane / 8, k row (lane >> 1) & 3, 8-column half lane & 1
+// MN-contiguous operand [k][mn] (a [k][n] weight): transpose-read image in ROW-MAJOR pieces.  A piece = 4 k rows x 128 columns =
+// four 256-byte row segments, lane = 16 kr + pc requests 16-byte chunk pc ^ (4 kr) of row 4 kb + kr: sixteen consecutive lanes read
+// ONE contiguous 256-byte segment (two whole cache lines).  (First form, measured: the sub-block-major image of gemm_bf16_core.h,
+// where consecutive lane PAIRS jump to the next k row -- 32-byte fragments of four different lines per eight lanes -- ran the
+// [k][n] shapes 7-16 us slower than the [n][k] ones.)  ds_read_b64_tr_b16 takes a per-lane address, so the 4 x 16 sub-block a
+// transpose read assembles does not have to be contiguous: its row kr lives at kr * 256 + ((2 ib + half) ^ (4 kr)) * 16 inside the
+// piece, and the XOR spreads the four rows of a sub-block -- which all start at the same bank in a plain row-major piece -- over
+// the 256-byte bank row: the 32 lanes of a service group (2 sub-blocks x 4 rows x 4 eight-byte quarters) cover all 64 banks once.
+// piece P = kb * NH + nh (kb: k group of 4, nh: 128-column half), wave w issues pieces w + 8 i.
 template <int BMN>
 struct RingDmaMN {
-    static constexpr int NB = BMN / 16;
+    static constexpr int NH = BMN / 128;
     static constexpr int NP = BMN / 64;
     const unsigned short *base;
     long long text;
@@ -111,58 +154,124 @@ struct RingDmaMN {
         base = reinterpret_cast<const unsigned short *>(p);
         text = ((long long)(K - 1) * ld + MN) * 2;
         ld2b = (unsigned)(ld * 2);
+        const int kr = lane >> 4, pc = lane & 15;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int sb = 8 * (wave + 8 * i) + (lane >> 3);
-            const int kb = sb / NB, ib = sb % NB;
-            const int k = 4 * kb + ((lane >> 1) & 3);
-            const int col = mn0 + 16 * ib + 8 * (lane & 1);
-            voff[i] = (col + 8 <= MN) ? (unsigned)k * ld2b + 2u * (unsigned)col : BUF_OOB;
+            const int P = wave + 8 * i;
+            const int kb = P / NH, nh = P % NH;
+            const int col = mn0 + nh * 128 + 8 * (pc ^ (4 * kr));
+            voff[i] = (col + 8 <= MN) ? (unsigned)(4 * kb + kr) * ld2b + 2u * (unsigned)col : BUF_OOB;
         }
     }
-    __device__ __forceinline__ void issue(int k0, int K, char *img, char *) const {
-        long long left = (k0 < K) ? text - (long long)k0 * ld2b : 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(base) + (long long)k0 * (ld2b >> 1), 0,
-                                                                           (int)(unsigned)left, 0x00020000);
+    __device__ __forceinline__ u32x4 stage_rsrc(int k0, int K) const {
+        const unsigned left = (k0 < K) ? (unsigned)(text - (long long)k0 * ld2b) : 0u;
+        return ring_rsrc(base + (long long)k0 * (ld2b >> 1), left);
+    }
+    __device__ __forceinline__ void issue_one(const int I, u32x4 rs, unsigned lds0, int img, int) const {
+        ring_dma_piece(rs, lds0 + (unsigned)(img + (wave + 8 * I) * 1024), voff[I]);
+    }
+    __device__ __forceinline__ void issue(int k0, int K, unsigned lds0, int img, int dump) const {
+        const u32x4 rs = stage_rsrc(k0, K);
 #pragma unroll
-        for (int i = 0; i < NP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(img + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
+        for (int i = 0; i < NP; ++i) issue_one(i, rs, lds0, img, dump);
     }
 };
 
-// MFMA fragment (8 consecutive k of row row_base + (lane & 31)) out of a transpose-read image with NB sub-blocks per k group
-template <int NB>
-__device__ __forceinline__ bf16x8 ring_frag_tr(const char *img, int row_base, int ks, int lane) {
+// lane-constant part of the transpose-read address of column block `col_base` (multiple of 32): lane = 16 g + t hands in the
+// 8-byte chunk (row kr = t >> 2, quarter q = t & 3) of sub-block ib = col_base / 16 + (g & 1); k group 2 (g >> 1) (+ 1 for the second read)
+template <int NH>
+__device__ __forceinline__ int ring_tr_lane_off(int col_base, int lane) {
     const int g = lane >> 4, t = lane & 15;
-    const int ib = (row_base >> 4) + (g & 1);
-    const int kb = (ks >> 2) + 2 * (g >> 1);
-    const unsigned short *p = reinterpret_cast<const unsigned short *>(img) + ((kb * NB + ib) * 64 + t * 4);
+    const int kr = t >> 2, q = t & 3;
+    const int ibg = (col_base >> 4) + (g & 1);
+    const int nh = ibg >> 3, ib = ibg & 7;
+    return (2 * (g >> 1) * NH + nh) * 1024 + kr * 256 + (((2 * ib + (q >> 1)) ^ (4 * kr)) * 16) + (q & 1) * 8;
+}
+// MFMA fragment (8 consecutive k, starting at 16 kk + 8 (lane >> 5), of column col_base + (lane & 31)) out of the image
+template <int NH>
+__device__ __forceinline__ bf16x8 ring_frag_tr(const char *img, int lane_off, int kk) {
+    const char *p = img + lane_off + kk * (4 * NH * 1024);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + NB * 64));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + NH * 1024));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// one 64-deep stage: NM (<= TM) row blocks of this wave x TN column blocks x 4 k-steps
-template <int NM, int TM, int TN, bool BKC>
-__device__ __forceinline__ void ring_mma_stage(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, int b_lane, int wn,
-                                               const int (&xo)[4], int lane) {
+// one 64-deep stage: NM (<= TM) row blocks of this wave x TN column blocks x 4 k-steps, with the DMA requests of the stage
+// NS - 1 ahead spread over the k-steps.  First form (measured, profiles/r05_ring_ablation.txt): every wave issued its 7 requests
+// right behind the barrier and multiplied afterwards -- all 8 waves of the workgroup are in the same phase, so nobody used the
+// matrix pipe while the requests were issued (60-180 cycles each) and nobody issued while it ran: loop time = MFMA part + request
+// part.  Now k-step kk carries the pieces [kk PW / 4, (kk + 1) PW / 4) between its MFMAs (sched_group_barrier pins the order)
+// and the fragments of k-step kk + 1 are read before the MFMAs of kk.
+template <int IDX, int P0, int P1, int NPA_, class LA, class LB>
+__device__ __forceinline__ void ring_issue_range(const LA &la, const LB &lb, u32x4 rsa, u32x4 rsb, unsigned lds0, int ia, int ib, int dump, int abl) {
+    if constexpr (IDX < P1) {
+        if constexpr (IDX >= P0) {
+            if constexpr (IDX < NPA_) { if (!(abl & 2)) la.issue_one(IDX, rsa, lds0, ia, dump); }
+            else { if (!(abl & 4)) lb.issue_one(IDX - NPA_, rsb, lds0, ib, dump); }
+        }
+        ring_issue_range<IDX + 1, P0, P1, NPA_>(la, lb, rsa, rsb, lds0, ia, ib, dump, abl);
+    }
+}
+template <int NM, int TM, int TN, bool BKC, bool ABL, class LA, class LB>
+__device__ __forceinline__ void ring_stage(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, int b_lane, const int (&btr)[TN],
+                                           const int (&xo)[4], const LA &la, const LB &lb, int k_next, int K, unsigned lds0, int na, int nb, int dump,
+                                           int abl) {
+    const u32x4 rsa = la.stage_rsrc(k_next, K), rsb = lb.stage_rsrc(k_next, K);
+    constexpr int NPA = TM, NPB = 2 * TN, PW = NPA + NPB;
+    constexpr int READS = NM + TN * (BKC ? 1 : 2), MF = NM * TN;
+    bf16x8 a[2][NM > 0 ? NM : 1], b[2][TN];
+    auto read = [&](const int kk, const int set) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 a[NM], b[TN];
-#pragma unroll
-        for (int mi = 0; mi < NM; ++mi) a[mi] = *reinterpret_cast<const bf16x8 *>(As + a_lane + mi * (32 * RING_STAGE_ROW) + xo[kk]);
+        for (int mi = 0; mi < NM; ++mi) a[set][mi] = *reinterpret_cast<const bf16x8 *>(As + a_lane + mi * (32 * RING_STAGE_ROW) + xo[kk]);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            if constexpr (BKC) b[ni] = *reinterpret_cast<const bf16x8 *>(Bs + b_lane + ni * (32 * RING_STAGE_ROW) + xo[kk]);
-            else b[ni] = ring_frag_tr<TN * 8>(Bs, wn * (32 * TN) + ni * 32, kk * 16, lane);
+            if constexpr (BKC) b[set][ni] = *reinterpret_cast<const bf16x8 *>(Bs + b_lane + ni * (32 * RING_STAGE_ROW) + xo[kk]);
+            else b[set][ni] = ring_frag_tr<TN>(Bs, btr[ni], kk);
         }
+    };
+    if constexpr (NM == 0) {             // a row wave without rows in this tile: it still issues its share of the requests
+        ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, abl);
+        return;
+    } else {
+        if constexpr (ABL) {             // timing experiments (DETR_HIP_RING_ABLATE): requests up front, under their switches; plain k-steps
+            ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, abl);
+            if (abl & 1) return;
 #pragma unroll
-        for (int mi = 0; mi < NM; ++mi)
+            for (int kk = 0; kk < 4; ++kk) {
+                read(kk, 0);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+            }
+            return;
+        } else {
+        read(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) read(kk + 1, (kk + 1) & 1);
+            if (kk == 0) ring_issue_range<0, (0 * PW) / 4, (1 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 1) ring_issue_range<0, (1 * PW) / 4, (2 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 2) ring_issue_range<0, (2 * PW) / 4, (3 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 3) ring_issue_range<0, (3 * PW) / 4, (4 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+        }
+        // pinned order: reads(0) reads(1) | MFMAs(0) + pieces | reads(2) | MFMAs(1) + pieces | reads(3) | MFMAs(2) + pieces | MFMAs(3) + pieces
+        sgb_ds_read<2 * READS>();
+        sgb_mfma_block<MF, 0, (1 * PW) / 4 - (0 * PW) / 4, 0>();
+        sgb_ds_read<READS>();
+        sgb_mfma_block<MF, 0, (2 * PW) / 4 - (1 * PW) / 4, 0>();
+        sgb_ds_read<READS>();
+        sgb_mfma_block<MF, 0, (3 * PW) / 4 - (2 * PW) / 4, 0>();
+        sgb_mfma_block<MF, 0, (4 * PW) / 4 - (3 * PW) / 4, 0>();
+        }
     }
 }
 template <int TM, int TN, bool BKC, int NS>
@@ -199,9 +308,10 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int a_bytes = ra.a_rows8 * RING_STAGE_ROW;
-    char *const dump = ring_smem + ra.dump_off;
-    auto stage_a = [&](int s) { return ring_smem + s * ra.stage_bytes; };
-    auto stage_b = [&](int s) { return ring_smem + s * ra.stage_bytes + a_bytes; };
+    const int dump = ra.dump_off;
+    const unsigned lds0 = ring_lds_addr(ring_smem);
+    auto stage_a = [&](int s) { return s * ra.stage_bytes; };                  // byte offsets into ring_smem
+    auto stage_b = [&](int s) { return s * ra.stage_bytes + a_bytes; };
     // fragment addressing: row (base multiple of 32) + (lane & 31) -> its swizzle term is ((lane & 31) >> 1) & 7 whatever the block
     const int l31 = lane & 31, h = lane >> 5;
     const int sw = (l31 >> 1) & 7;
@@ -210,29 +320,38 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
     for (int kk = 0; kk < 4; ++kk) xo[kk] = 16 * ((2 * kk + h) ^ sw);
     const int a_lane = (wm * T::WTM + l31) * RING_STAGE_ROW;
     const int b_lane = (wn * T::WTN + l31) * RING_STAGE_ROW;
+    int btr[TN];                                        // [k][n] weights: lane-constant transpose-read offsets of this wave's column blocks
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) btr[ni] = ring_tr_lane_off<TN>(wn * T::WTN + ni * 32, lane);
 
     const int nkt = g.K / RING_BK;
+    const int abl = ra.ablate;                          // (kernel argument: uniform)
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) {
-        la.issue(t * RING_BK, g.K, stage_a(t), dump);
-        lb.issue(t * RING_BK, g.K, stage_b(t), dump);
+        if (!(abl & 2)) la.issue(t * RING_BK, g.K, lds0, stage_a(t), dump);
+        if (!(abl & 4)) lb.issue(t * RING_BK, g.K, lds0, stage_b(t), dump);
     }
     // The K loop exists once per block count NM a wave can have (chosen ONCE, outside the loop: a per-stage switch made the
     // compiler shuffle all accumulators between the branches' register assignments every iteration)
-    auto kloop = [&](auto NMC) {
+    auto kloop_ab = [&](auto NMC, auto ABLC) {
         constexpr int NM = decltype(NMC)::value;
+        constexpr bool ABL = decltype(ABLC)::value;
         int cur = 0, nxt = NS - 1;                      // ring slots of stage t and of stage t + NS - 1
-        for (int t = 0; t < nkt; ++t) {
+        for (int t = 0; t < ((abl & 16) ? 0 : nkt); ++t) {
             ring_wait_vmcnt<(NS - 2) * PW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            la.issue((t + NS - 1) * RING_BK, g.K, stage_a(nxt), dump);
-            lb.issue((t + NS - 1) * RING_BK, g.K, stage_b(nxt), dump);
-            if constexpr (NM > 0) ring_mma_stage<NM, TM, TN, BKC>(stage_a(cur), stage_b(cur), acc, a_lane, b_lane, wn, xo, lane);
+            ring_stage<NM, TM, TN, BKC, ABL>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, b_lane, btr, xo, la, lb,
+                                             (t + NS - 1) * RING_BK, g.K, lds0, stage_a(nxt), stage_b(nxt), dump, abl);
             __builtin_amdgcn_sched_barrier(0);
             cur = (cur + 1 == NS) ? 0 : cur + 1;
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
+    };
+    // (the ablation form of the loop is a separate loop as well: a run-time switch inside the loop body costs the accumulator shuffle again)
+    auto kloop = [&](auto NMC) {
+        if (abl) kloop_ab(NMC, std::integral_constant<bool, true>{});
+        else kloop_ab(NMC, std::integral_constant<bool, false>{});
     };
     if (nmi == TM) kloop(std::integral_constant<int, TM>{});
     else if (TM >= 2 && nmi == TM - 1) kloop(std::integral_constant<int, (TM >= 2 ? TM - 1 : 0)>{});
@@ -241,12 +360,23 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
     else kloop(std::integral_constant<int, 0>{});
     ring_wait_vmcnt<0>();                               // the trailing empty requests still write (zeros) into the ring:
     __syncthreads();                                    // nobody reuses the array (epilogue staging) before they have landed
+    if (abl & 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ablate_keep(acc[i][j]);
+        return;
+    }
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(ring_smem), g.C, g.ldc, row_end, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
 template <int TM, int TN, bool BKC, int NS>
 __global__ __launch_bounds__(RING_THREADS) void gemm_ring_kernel(RingArgs ra) {
+    // (device pass only: the host pass of hipcc needs the kernel's symbol, not its body -- and rejects the body's device-function templates
+    //  with a bare "substitution failure" once the loaders are passed down as template arguments)
+#if defined(__HIP_DEVICE_COMPILE__)
     gemm_ring_body<TM, TN, BKC, NS>(ra, xcd_remap((int)blockIdx.x, (int)gridDim.x));
+#endif
 }
 
 }  // namespace detr

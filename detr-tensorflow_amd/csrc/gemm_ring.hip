@@ -27,7 +27,7 @@ static double ring_cost(int M, int N, int K, int bn, int tile_rows, int &tm, int
 
 bool gemm_ring_plan(int M, int N, int K, RingPlan &p) {
     if (M < 1 || N < 128 || K < RING_BK || K % RING_BK != 0) return false;
-    const int force_bn = tune(T_RING_BN), force_wgs = tune(T_RING_WGS), force_ns = tune(T_RING_NS);
+    const int force_bn = tune(T_RING_BN), force_wgs = tune(T_RING_WGS), force_ns = tune(T_RING_NS), force_rows = tune(T_RING_ROWS);
     double best = 1e300;
     bool found = false;
     for (int bn = 128; bn <= 256; bn += 128) {
@@ -42,6 +42,7 @@ bool gemm_ring_plan(int M, int N, int K, RingPlan &p) {
             int rows = cdiv(M, tiles_m);
             rows = (rows + 3) & ~3;
             if (rows < 8) rows = 8;
+            if (force_rows >= 8) rows = (force_rows + 3) & ~3;               // (sweeps: scripts/experiments/ring_sweep.py)
             if (rows > 256) continue;
             int tm, wgs;
             const double c = ring_cost(M, N, K, bn, rows, tm, wgs);
@@ -94,6 +95,7 @@ int gemm_ring_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStream_t 
     ra.a_rows8 = p.a_rows8;
     ra.stage_bytes = p.stage_bytes;
     ra.dump_off = p.dump_off;
+    ra.ablate = tune(T_RING_ABLATE);
     int rc = -1;
     switch (p.tm * 2 + (p.tn - 1)) {
         case 2: rc = ring_launch_tt<1, 1>(ra, p, bk, s); break;

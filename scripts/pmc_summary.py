@@ -9,10 +9,14 @@ import sys
 
 def fold(name):
     """rocprofv3 kernel name -> the family name detr_tf/_hip.py reports: one kernel BODY with every template instantiation
-    pooled (layouts, storage types, tile sizes, K-tile depths; grouped launches folded into their base kernel)."""
-    m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group|_k64)?_kernel<", name)
+    pooled (layouts, storage types, tile sizes, K-tile depths; grouped launches folded into their base kernel).  ONE rule for
+    bench.py, this script and DESIGN (VERDICT r4 #9a): the bf16 tile-GEMM family is gemm_bf16c{,_group,_k64,_ln}_kernel AND the
+    round-5 ring kernel gemm_ring_kernel -- every launch that detr_tf/_hip.py bills to "gemm_bf16c_kernel"."""
+    m = re.search(r"detr::(gemm_(?:bf16c|f32))(?:_group|_k64|_ln)?_kernel<", name)
     if m:
         return f"{m.group(1)}_kernel"
+    if "detr::gemm_ring_kernel" in name:
+        return "gemm_bf16c_kernel"
     if "detr::gemm_stream_bf16_kernel" in name:
         return "gemm_stream_bf16_kernel"
     return None

@@ -1,6 +1,6 @@
 """CPU checks of the ring GEMM's address maps (csrc/gemm_ring.h), restated in numpy: the LDS-DMA writes lane-linearly, so the
 LDS image is defined by which GLOBAL address each lane requests; the fragment reads must then find element (row, k) where
-the MFMA operand map expects it.  Also: the images are bank-conflict free under the guide's ds_read_b128 service groups, and the
+the MFMA operand map expects it.  Also: the images are bank-conflict free under the guide's LDS service groups, and the
 host's tile plans cover every row exactly once.  (The GPU parity tests are in test_gpu_kernels.py; this file needs no GPU.)"""
 import ctypes
 import os
@@ -78,41 +78,64 @@ def test_k_contiguous_image_is_bank_conflict_free():
                 assert len(slots) == 16, (rb, kk, g)
 
 
+def tr_lane_off(NH, col_base, lane):
+    g, t = lane >> 4, lane & 15
+    kr, q = t >> 2, t & 3
+    ibg = (col_base >> 4) + (g & 1)
+    nh, ib = ibg >> 3, ibg & 7
+    return (2 * (g >> 1) * NH + nh) * 1024 + kr * 256 + (((2 * ib + (q >> 1)) ^ (4 * kr)) * 16) + (q & 1) * 8
+
+
 def test_transposed_image_and_fragments():
-    """RingDmaMN + ring_frag_tr: [k][n] operand, sub-blocks of [4 k][16 n]; ds_read_b64_tr_b16 semantics as pinned in round 1
-    (scripts/experiments/tr_b16_probe.*): the 16 lanes of a group hand in the sixteen 8-byte chunks of one sub-block, lane c gets
-    column c = 4 consecutive k."""
+    """RingDmaMN + ring_frag_tr: [k][n] operand in row-major pieces (4 k rows x 128 columns, chunk pc of row kr at position
+    pc ^ 4 kr).  ds_read_b64_tr_b16 semantics as pinned in round 1 (scripts/experiments/tr_b16_probe.*): the 16 lanes of a group hand
+    in sixteen 8-byte chunks -- chunk t = (k row t / 4, four columns 4 (t % 4) ..) of a 4 x 16 block -- and lane c receives column c:
+    its 4 consecutive k.  Also: sixteen consecutive DMA lanes request one contiguous 256-byte segment, and the 32 lanes of a
+    transpose-read service group touch every one of the 64 banks exactly once."""
     rng = np.random.default_rng(7)
     for BN in (128, 256):
-        NB = BN // 16
+        NH = BN // 128
         K, N, n0 = 192, BN + 24, 0
         B = rng.integers(1, 2 ** 40, size=(K, N), dtype=np.int64)
         for k0 in (0, 128):
-            img = np.zeros(BN * BK, dtype=np.int64)
+            img = np.zeros(BN * BK, dtype=np.int64)               # 2-byte elements
             for wave in range(8):
                 for i in range(BN // 64):
                     P = wave + 8 * i
+                    kb, nh = P // NH, P % NH
+                    cols = []
                     for lane in range(64):
-                        sb = 8 * P + (lane >> 3)
-                        kb, ib = sb // NB, sb % NB
-                        k = 4 * kb + ((lane >> 1) & 3)
-                        col = n0 + 16 * ib + 8 * (lane & 1)
-                        src = B[k0 + k, col:col + 8] if col + 8 <= N else np.zeros(8, dtype=np.int64)
+                        kr, pc = lane >> 4, lane & 15
+                        col = n0 + nh * 128 + 8 * (pc ^ (4 * kr))
+                        cols.append((kr, col))
+                        src = B[k0 + 4 * kb + kr, col:col + 8] if col + 8 <= N else np.zeros(8, dtype=np.int64)
                         img[P * 512 + lane * 8: P * 512 + lane * 8 + 8] = src
-            sub = img.reshape(16, NB, 4, 16)              # [kb][ib][k][n]
-            for row_base in range(0, BN, 32):
+                    for kr in range(4):                           # 16 consecutive lanes: one row, one aligned 256-byte segment
+                        seg = sorted(c for r, c in cols[16 * kr:16 * kr + 16])
+                        assert all(r == kr for r, _ in cols[16 * kr:16 * kr + 16]) and seg == list(range(n0 + nh * 128, n0 + nh * 128 + 128, 8))
+            for col_base in range(0, BN, 32):
                 for kk in range(4):
-                    ks = 16 * kk
+                    banks = {0: [], 1: []}
                     for lane in range(64):
+                        off = tr_lane_off(NH, col_base, lane) + kk * 4 * NH * 1024
+                        banks[lane >> 5] += [(off // 4) % 64, (off // 4 + 1) % 64]
                         g, t = lane >> 4, lane & 15
-                        ib = (row_base >> 4) + (g & 1)
-                        kb = (ks >> 2) + 2 * (g >> 1)
-                        lo = sub[kb, ib, :, t]            # transpose read: lane t of the group receives column t of the sub-block
-                        hi = sub[kb + 1, ib, :, t]
-                        got = np.concatenate([lo, hi])
-                        n = row_base + (lane & 31)        # MFMA B operand map: lane -> column n = lane & 31, k = 8 (lane >> 5) .. + 7
-                        want = B[k0 + ks + 8 * (lane >> 5): k0 + ks + 8 * (lane >> 5) + 8, n0 + n]
-                        assert 16 * ib + t == n and np.array_equal(got, want), (BN, k0, row_base, kk, lane)
+                        got = []
+                        for half in range(2):                     # the two transpose reads: k groups 4 kk + 2 (g >> 1) + half
+                            base = off + half * NH * 1024 - (t >> 2) * 256 - ((t & 3) & 1) * 8       # (undo this lane's own chunk: rebuild the block)
+                            # what lane t RECEIVES: column t of the block = element t % 4 of the chunks (kr, t / 4), kr = 0 .. 3
+                            blk_lane0 = (lane & ~15)
+                            vals = []
+                            for kr in range(4):
+                                src_lane = blk_lane0 + 4 * kr + (t >> 2)          # the lane that handed in chunk (kr, quarter t / 4)
+                                o = tr_lane_off(NH, col_base, src_lane) + kk * 4 * NH * 1024 + half * NH * 1024
+                                vals.append(img[o // 2 + (t & 3)])
+                            got += vals
+                        n = col_base + (lane & 31)                # MFMA B operand map: column n = lane & 31, k = 16 kk + 8 (lane >> 5) .. + 7
+                        want = B[k0 + 16 * kk + 8 * (lane >> 5): k0 + 16 * kk + 8 * (lane >> 5) + 8, n0 + n]
+                        assert np.array_equal(np.array(got), want), (BN, k0, col_base, kk, lane)
+                    for grp in banks.values():
+                        assert sorted(grp) == list(range(64)), (BN, col_base, kk)
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
