@@ -582,7 +582,11 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
             return 0;
         }
     }
-    if (p.bf16c) {
+    // split-K weight gradients of the backbone's 1x1 convolutions on 128 x 128 tiles: the 8-wave ring form (gemm_ring.h; bit-identical slabs)
+    if (p.bf16c && p.tile == 1 && g.a16 && g.b16 && !ak && !bk && batch == 1 && p.split > 1 && g.slab_ts && !g.rowsum && d->M % 8 == 0 &&
+        d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) && aligned16(d->B) && tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3) {
+        if (gemm_ring_wgrad_launch(g, cdiv(g.M, 128), cdiv(g.N, 128), p.split, s)) return -1;
+    } else if (p.bf16c) {
         if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk, p.deep);

@@ -56,6 +56,8 @@ struct RingPlan {
     double cost;
 };
 bool gemm_ring_plan(int M, int N, int K, RingPlan &p);
+// split-K weight gradient with tile-ordered slabs on 128 x 128 tiles (tiles_m / tiles_n / split_k / part_stride / slab_ts set by the caller)
+int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s);
 int gemm_ring_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipStream_t s);
 
 template <int N>
@@ -215,17 +217,20 @@ __device__ __forceinline__ void ring_issue_range(const LA &la, const LB &lb, u32
         ring_issue_range<IDX + 1, P0, P1, NPA_>(la, lb, rsa, rsb, lds0, ia, ib, dump, abl);
     }
 }
-template <int NM, int TM, int TN, bool BKC, bool ABL, class LA, class LB>
-__device__ __forceinline__ void ring_stage(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, int b_lane, const int (&btr)[TN],
+template <int NM, int TM, int TN, bool AKC, bool BKC, bool ABL, class LA, class LB>
+__device__ __forceinline__ void ring_stage(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, const int (&atr)[TM], int b_lane, const int (&btr)[TN],
                                            const int (&xo)[4], const LA &la, const LB &lb, int k_next, int K, unsigned lds0, int na, int nb, int dump,
                                            int abl) {
     const u32x4 rsa = la.stage_rsrc(k_next, K), rsb = lb.stage_rsrc(k_next, K);
     constexpr int NPA = TM, NPB = 2 * TN, PW = NPA + NPB;
-    constexpr int READS = NM + TN * (BKC ? 1 : 2), MF = NM * TN;
+    constexpr int READS = NM * (AKC ? 1 : 2) + TN * (BKC ? 1 : 2), MF = NM * TN;
     bf16x8 a[2][NM > 0 ? NM : 1], b[2][TN];
     auto read = [&](const int kk, const int set) {
 #pragma unroll
-        for (int mi = 0; mi < NM; ++mi) a[set][mi] = *reinterpret_cast<const bf16x8 *>(As + a_lane + mi * (32 * RING_STAGE_ROW) + xo[kk]);
+        for (int mi = 0; mi < NM; ++mi) {
+            if constexpr (AKC) a[set][mi] = *reinterpret_cast<const bf16x8 *>(As + a_lane + mi * (32 * RING_STAGE_ROW) + xo[kk]);
+            else a[set][mi] = ring_frag_tr<TM / 2>(As, atr[mi], kk);
+        }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             if constexpr (BKC) b[set][ni] = *reinterpret_cast<const bf16x8 *>(Bs + b_lane + ni * (32 * RING_STAGE_ROW) + xo[kk]);
@@ -320,6 +325,7 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
     for (int kk = 0; kk < 4; ++kk) xo[kk] = 16 * ((2 * kk + h) ^ sw);
     const int a_lane = (wm * T::WTM + l31) * RING_STAGE_ROW;
     const int b_lane = (wn * T::WTN + l31) * RING_STAGE_ROW;
+    int atr_unused[TM] = {};
     int btr[TN];                                        // [k][n] weights: lane-constant transpose-read offsets of this wave's column blocks
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) btr[ni] = ring_tr_lane_off<TN>(wn * T::WTN + ni * 32, lane);
@@ -341,7 +347,7 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
             ring_wait_vmcnt<(NS - 2) * PW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ring_stage<NM, TM, TN, BKC, ABL>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, b_lane, btr, xo, la, lb,
+            ring_stage<NM, TM, TN, true, BKC, ABL>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, atr_unused, b_lane, btr, xo, la, lb,
                                              (t + NS - 1) * RING_BK, g.K, lds0, stage_a(nxt), stage_b(nxt), dump, abl);
             __builtin_amdgcn_sched_barrier(0);
             cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -376,6 +382,94 @@ __global__ __launch_bounds__(RING_THREADS) void gemm_ring_kernel(RingArgs ra) {
     //  with a bare "substitution failure" once the loaders are passed down as template arguments)
 #if defined(__HIP_DEVICE_COMPILE__)
     gemm_ring_body<TM, TN, BKC, NS>(ra, xcd_remap((int)blockIdx.x, (int)gridDim.x));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-K weight gradients on the ring: C[M, N] partial = sum over this split's k of A[k][m] * B[k][n], both operands bf16 and
+// MN-contiguous (the 1x1-convolution weight gradients of the backbone: x^T dy over B*H*W pixels).  Same tile (64 TM x 128 TN), same
+// split ranges, same MFMA order per accumulator and the same tile-ordered slabs as gemm_bf16c_k64_kernel<BM, BN, 2, 2, false, false>
+// (bit-identical; the reduce launch is unchanged) -- but 8 waves per workgroup instead of 4 (the split-K launches run ONE
+// workgroup per CU: the 4-wave engine leaves one wave per SIMD, whose K tile cost ~2500 cycles for 512 of MFMA), both
+// operands by LDS-DMA into transpose-read images, NS - 1 stages in flight.
+// The 2 x 4 wave grid stores its accumulator blocks at the slab positions a 2 x 2 grid would use (gemm_core.h slab_ts_unit):
+// block (wm, wn, mi, ni) is block (w' = 2 wm + (wn >> 1), mi, ni' = (wn & 1) TN + ni) of the 2 x 2 layout with TN' = 2 TN.
+template <int TM, int TN, int NS>
+__device__ __forceinline__ void gemm_ring_wgrad_body(const RingArgs &ra) {
+    constexpr int BM = 64 * TM, BN = 128 * TN, WGM = 2, WGN = 4;
+    static_assert(TM % 2 == 0, "the A image is made of 128-row pieces");
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    extern __shared__ __attribute__((aligned(1024))) char ring_smem[];
+    const GemmArgs &g = ra.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    // (split, tile): the whole list remapped over the XCDs so that the tiles of a split share one L2 (gemm_kernels.h gemm_work_item)
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tile = id % tiles, split = id / tiles;
+    const int tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt32 = (g.K + BF_BK - 1) / BF_BK;
+    const int per = (nkt32 + g.split_k - 1) / g.split_k;
+    const int kbeg = split * per * BF_BK;
+    const int kend = min(g.K, kbeg + per * BF_BK);
+    if (kbeg >= kend) return;
+    RingDmaMN<BM> la;
+    RingDmaMN<BN> lb;
+    la.init(g.A, g.lda, m0, g.M, kend, lane, wave);
+    lb.init(g.B, g.ldb, n0, g.N, kend, lane, wave);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    constexpr int A_BYTES = BM * RING_STAGE_ROW, STAGE = (BM + BN) * RING_STAGE_ROW, PW = TM + 2 * TN;
+    const unsigned lds0 = ring_lds_addr(ring_smem);
+    int atr[TM], btr[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) atr[mi] = ring_tr_lane_off<TM / 2>(wm * T::WTM + mi * 32, lane);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) btr[ni] = ring_tr_lane_off<TN>(wn * T::WTN + ni * 32, lane);
+    const int xo[4] = {0, 0, 0, 0};
+    const int nkt = (kend - kbeg + RING_BK - 1) / RING_BK;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        la.issue(kbeg + t * RING_BK, kend, lds0, t * STAGE, 0);
+        lb.issue(kbeg + t * RING_BK, kend, lds0, t * STAGE + A_BYTES, 0);
+    }
+    int cur = 0, nxt = NS - 1;
+    for (int t = 0; t < nkt; ++t) {
+        ring_wait_vmcnt<(NS - 2) * PW>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ring_stage<TM, TM, TN, false, false, false>(ring_smem + cur * STAGE, ring_smem + cur * STAGE + A_BYTES, acc, 0, atr, 0, btr, xo, la, lb,
+                                                    kbeg + (t + NS - 1) * RING_BK, kend, lds0, nxt * STAGE, nxt * STAGE + A_BYTES, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+    ring_wait_vmcnt<0>();
+    // tile-ordered slab of this (split, tile), in the 2 x 2 grid's unit order
+    float4 *slab = reinterpret_cast<float4 *>(g.C + (long long)split * g.part_stride + (long long)tile * (BM * BN));
+    const int w2 = 2 * wm + (wn >> 1);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int blk = (w2 * TM + mi) * (2 * TN) + (wn & 1) * TN + ni;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                slab[(blk * 4 + q) * 64 + lane] = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+        }
+}
+
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(RING_THREADS) void gemm_ring_wgrad_kernel(RingArgs ra) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    gemm_ring_wgrad_body<TM, TN, NS>(ra);
 #endif
 }
 

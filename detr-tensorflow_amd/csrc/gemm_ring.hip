@@ -5,65 +5,51 @@
 
 namespace detr {
 
-// Cost model of one candidate grid (cycles of the slowest CU, up to a common factor).  A workgroup's K loop is bounded by its
-// MFMA issue (2 waves per SIMD, 32 cycles per 32x32x16 MFMA) and by the bytes it pulls through the CU's vector-memory path
-// (RING_BPC bytes per clock: measured order of magnitude for LDS-DMA out of L2, profiles/r05_*), plus a fixed prologue /
-// epilogue term; workgroups beyond 256 run in further rounds.
-static constexpr double RING_BPC = 24.0;
-static constexpr double RING_FIXED = 6000.0;
-
-static double ring_cost(int M, int N, int K, int bn, int tile_rows, int &tm, int &wgs) {
-    const int tiles_m = cdiv(M, tile_rows), tiles_n = cdiv(N, bn);
-    const int blocks = cdiv(tile_rows, 32);
-    tm = cdiv(blocks, 2);
-    const int tn = bn / 128;
-    wgs = tiles_m * tiles_n;
-    const double mfma = (double)tm * tn * (K / 16) * 32.0 * 2.0;
-    const double traffic = (double)(tile_rows + bn) * K * 2.0 / RING_BPC;
-    const double epi = (double)tile_rows * bn * 4.0 / RING_BPC;
-    const double per = (mfma > traffic ? mfma : traffic) + epi + RING_FIXED;
-    return per * cdiv(wgs, 256);
-}
-
+// Tile plan.  Measured (scripts/experiments/ring_sweep.py, profiles/r05_ring_sweep.txt: every eligible shape of the step x row pitch x
+// column panel x ring depth): one rule wins on all of them within 2-5 % of the per-shape optimum --
+//   * 128-column panels (TN = 1) and a row pitch of 176 (TM = 3: 96 + 80 rows for the two row waves) with a TWO-stage ring: the
+//     workgroup needs 77 KB of LDS, so TWO workgroups share a CU and one's epilogue (the output / residual / mask streams are as
+//     many bytes as the A operand at K = 512) runs under the other's K loop.  256-column panels with a 3-stage ring (one
+//     workgroup per CU, A read once) lose 5-30 %: their epilogue overlaps nothing;
+//   * when the problem does not fill the 512 slots even once (M = 8400 with K = 2048: 212 workgroups), one round of ~200
+//     workgroups with a THREE-stage ring (one workgroup per CU anyway: the deeper ring hides more of the L2 latency).
+// DETR_HIP_RING_BN / _NS / _ROWS / _WGS force the pieces of the plan (sweeps, tests).
 bool gemm_ring_plan(int M, int N, int K, RingPlan &p) {
     if (M < 1 || N < 128 || K < RING_BK || K % RING_BK != 0) return false;
     const int force_bn = tune(T_RING_BN), force_wgs = tune(T_RING_WGS), force_ns = tune(T_RING_NS), force_rows = tune(T_RING_ROWS);
-    double best = 1e300;
-    bool found = false;
-    for (int bn = 128; bn <= 256; bn += 128) {
-        if (force_bn && bn != force_bn) continue;
-        if (bn == 256 && N < 256) continue;
-        if (bn == 128 && N > 256 && N % 256 == 0 && !force_bn) continue;     // wide outputs: 256-column panels (half the A re-reads)
-        const int tiles_n = cdiv(N, bn);
-        for (int target = 64; target <= 256 * 24; target += (target < 256 ? 32 : 64)) {
-            if (force_wgs && target != force_wgs) continue;
-            int tiles_m = target / tiles_n;
-            if (tiles_m < 1) continue;
-            int rows = cdiv(M, tiles_m);
-            rows = (rows + 3) & ~3;
-            if (rows < 8) rows = 8;
-            if (force_rows >= 8) rows = (force_rows + 3) & ~3;               // (sweeps: scripts/experiments/ring_sweep.py)
-            if (rows > 256) continue;
-            int tm, wgs;
-            const double c = ring_cost(M, N, K, bn, rows, tm, wgs);
-            if (c < best) {
-                best = c;
-                found = true;
-                p.tm = tm; p.tn = bn / 128; p.tile_rows = rows; p.tiles_m = cdiv(M, rows); p.tiles_n = tiles_n; p.wgs = wgs;
-            }
-        }
+    int bn = 128;
+    if (force_bn == 256 && N >= 256) bn = 256;
+    const int tiles_n = cdiv(N, bn);
+    int rows = 176, ns = 2;
+    if (cdiv(M, 176) * tiles_n < 320) {                  // a single round: ~200 workgroups, three stages
+        rows = (int)(((long long)M * tiles_n + 199) / 200);
+        rows = (rows + 3) & ~3;
+        if (rows > 176) rows = 176;
+        ns = 3;
     }
-    if (!found) return false;
-    const int bn = 128 * p.tn;
-    p.a_rows8 = (p.tile_rows + 7) & ~7;
+    if (force_wgs > 0) {
+        const int tm_ = force_wgs / tiles_n > 0 ? force_wgs / tiles_n : 1;
+        rows = (cdiv(M, tm_) + 3) & ~3;
+    }
+    if (force_rows >= 8) rows = (force_rows + 3) & ~3;
+    if (rows < 8) rows = 8;
+    if (rows > 256) return false;
+    p.tile_rows = rows;
+    p.tm = cdiv(cdiv(rows, 32), 2);
+    p.tn = bn / 128;
+    p.tiles_m = cdiv(M, rows);
+    p.tiles_n = tiles_n;
+    p.wgs = p.tiles_m * tiles_n;
+    p.a_rows8 = (rows + 7) & ~7;
     p.stage_bytes = (p.a_rows8 + bn) * RING_STAGE_ROW;
     const int epi_bytes = 8 * 32 * (bn / 4 + 4) * 4;                       // the epilogue's wave-private staging strips (gemm_core.h StageCfg)
-    p.ns = (3 * p.stage_bytes + 1024 <= 160 * 1024) ? 3 : 2;
-    if (force_ns == 2 || (force_ns == 3 && p.ns >= 3)) p.ns = force_ns;
+    if (3 * p.stage_bytes + 1024 > 160 * 1024) ns = 2;
+    if (force_ns == 2 || (force_ns == 3 && 3 * p.stage_bytes + 1024 <= 160 * 1024)) ns = force_ns;
+    p.ns = ns;
     p.dump_off = p.ns * p.stage_bytes;
     const int ring_bytes = p.dump_off + 1024;
     p.lds_bytes = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
-    p.cost = best;
+    p.cost = 0.0;
     return p.lds_bytes <= 160 * 1024;
 }
 
@@ -109,6 +95,28 @@ int gemm_ring_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStream_t 
         default: DETR_REQUIRE(false, "gemm (ring): no instantiation for TM=%d TN=%d", p.tm, p.tn);
     }
     return rc;
+}
+
+int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s) {
+    RingArgs ra;
+    ra.g = g;
+    ra.g.tiles_m = tiles_m;
+    ra.g.tiles_n = tiles_n;
+    ra.tile_rows = ra.a_rows8 = ra.stage_bytes = ra.dump_off = ra.ablate = 0;
+    constexpr int STAGE = (128 + 128) * RING_STAGE_ROW;
+    const int ns = tune(T_RING_NS) == 3 ? 3 : 4;
+    const int lds = ns * STAGE;
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_wgrad_kernel<2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_wgrad_kernel<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        DETR_REQUIRE(e == hipSuccess, "gemm (ring wgrad): cannot reserve LDS: %s", hipGetErrorString(e));
+        reserved = true;
+    }
+    const dim3 grid((unsigned)(tiles_m * tiles_n * split));
+    if (ns == 3) hipLaunchKernelGGL((gemm_ring_wgrad_kernel<2, 1, 3>), grid, dim3(RING_THREADS), (size_t)lds, s, ra);
+    else hipLaunchKernelGGL((gemm_ring_wgrad_kernel<2, 1, 4>), grid, dim3(RING_THREADS), (size_t)lds, s, ra);
+    return 0;
 }
 
 }  // namespace detr

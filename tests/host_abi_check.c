@@ -59,10 +59,10 @@ int main(void) {
     EXPECT(detr_hip_workspace_bytes_layernorm(&ln) < 0);
     ln.rows = 800; ln.C = 256;
     EXPECT(detr_hip_workspace_bytes_layernorm(&ln) == (int64_t)100 * 2 * 256 * 4);
-    {   /* tile plan of the ring GEMM: M = 33600 rows in one round of <= 256 row-balanced workgroups of 256 columns */
+    {   /* tile plan of the ring GEMM: M = 33600 x N = 256 as 128-column panels, two workgroups per CU (<= 80 KB of LDS each) */
         int32_t rp[8];
         EXPECT(detr_hip_gemm_ring_plan(33600, 256, 1024, rp) == 1);
-        EXPECT(rp[1] == 2 && rp[5] == 1 && rp[6] <= 256 && rp[3] * rp[4] >= 33600 && rp[3] <= 64 * rp[0] && rp[7] <= 160 * 1024);
+        EXPECT(rp[1] == 1 && rp[5] == 2 && rp[6] == rp[4] * rp[5] && rp[3] * rp[4] >= 33600 && rp[3] <= 64 * rp[0] && rp[7] <= 80 * 1024);
         EXPECT(detr_hip_gemm_ring_plan(33600, 256, 1000, rp) == 0);        /* K % 64 != 0: no plan */
         EXPECT(detr_hip_gemm_ring_plan(8400, 64, 512, NULL) == 0);         /* narrower than one column panel */
     }

@@ -1901,3 +1901,35 @@ def test_gemm_ring_takes_the_step_shapes_and_repeats_exactly(hip):
             finally:
                 hip.set_tuning("DETR_HIP_GEMM_RING", None)
         assert torch.equal(outs[0], outs[1]), (M, N, K, bk, list(plan), int((outs[0] != outs[1]).sum()))
+
+
+@pytest.mark.parametrize("ns", [None, "3"])
+@pytest.mark.parametrize("M,N,K,split", [(256, 1024, 8400, 8), (1024, 256, 4200, 5), (128, 512, 33600, 64), (264, 136, 2100, 3),
+                                         (512, 2048, 1050, 2), (120, 128, 1000, 4)])
+def test_gemm_ring_split_k_weight_gradient_is_bit_identical(hip, ns, M, N, K, split):
+    """The split-K weight gradients of the backbone's 1x1 convolutions (dW = x^T dy, both operands bf16 and M / N-contiguous) on the
+    8-wave ring kernel (gemm_ring.h: gemm_ring_wgrad_kernel) against the 4-wave engine (DETR_HIP_GEMM_RING=3): same 128 x 128 tiles,
+    same split ranges (incl. K that is no multiple of 64 or 32: the last stage is zero-filled by the descriptor bound), same MFMA
+    order, tile-ordered slabs in the same unit order -> the reduced gradient must be IDENTICAL bits; ragged M / N, 3- and 4-stage
+    rings.  Pinned against fp64 as well."""
+    torch.manual_seed(M + N + K)
+    hip.ensure_workspace(DEV)
+    b16 = torch.bfloat16
+    A = g(torch.randn(K, M)).to(b16)
+    Bm = g(torch.randn(K, N) / K ** 0.5).to(b16)
+    outs = []
+    for ring in (None, "3"):
+        env = {"DETR_HIP_GEMM_RING": ring, "DETR_HIP_GEMM_TILE": "1", "DETR_HIP_RING_NS": ns}
+        for k, v in env.items():
+            hip.set_tuning(k, v)
+        try:
+            C = torch.full((M, N), 0.5, device=DEV)
+            hip.gemm(M, N, K, A, M, 0, Bm, N, 0, C, N, compute=1, split_k=split, alpha=0.75)
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                hip.set_tuning(k, None)
+        outs.append(C.cpu())
+    want = 0.5 + 0.75 * (A.double().cpu().t() @ Bm.double().cpu())
+    assert float((outs[1].double() - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[0], outs[1]), (float((outs[0] - outs[1]).abs().max()), int((outs[0] != outs[1]).sum()))
