@@ -562,6 +562,23 @@ static bool gemm_ring_eligible(const GemmPlan &p, RingPlan &rp) {
     return gemm_ring_plan(d->M, d->N, d->K, rp);
 }
 
+// fp32 form (the exact-f32 parity mode): fp32 operands, K-contiguous A, unsplit; DETR_HIP_GEMM_RING as above
+static bool gemm_ring_f32_eligible(const GemmPlan &p, RingPlan &rp) {
+    const detr_gemm_desc *d = p.d;
+    const GemmArgs &g = p.g;
+    const int mode = tune(T_GEMM_RING);
+    if (mode == 2) return false;
+    if (p.bf16c || g.a16 || g.b16 || !p.ak || p.batch != 1 || p.split != 1 || g.rowsum || d->ln_y) return false;
+    if (d->c_dtype || d->r_dtype || d->m_dtype) return false;
+    if (!(d->K % 32 == 0 && d->K >= 64 && d->N >= 128 && d->lda % 4 == 0 && d->ldb % 4 == 0 && aligned16(d->A) && aligned16(d->B) &&
+          (p.bk || d->N % 4 == 0))) return false;
+    // measured (scripts/micro_ring.py, RING_F32=1, second-pass columns -- the first timings of a process run at a lower clock): -3 .. -9 % on
+    // the backbone's M >= 33600 shapes, +-0 .. +3 % on the M = 8400 ones: the fp32 MFMA kernels sit at ~0.6 of the nominal peak whatever
+    // the structure
+    if (mode != 1 && !(d->M >= 16384)) return false;
+    return gemm_ring_f32_plan(d->M, d->N, d->K, rp);
+}
+
 static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const GemmArgs &g = p.g;
     const detr_gemm_desc *d = p.d;
@@ -578,6 +595,12 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         if (gemm_ring_eligible(p, rp)) {
             if (gemm_ring_launch(g, bk, rp, s)) return -1;
             DETR_LAUNCH_CHECK("gemm (ring)");
+            if (d->defer_out) d->defer_out->splits = 0;
+            return 0;
+        }
+        if (gemm_ring_f32_eligible(p, rp)) {
+            if (gemm_ring_f32_launch(g, bk, rp, s)) return -1;
+            DETR_LAUNCH_CHECK("gemm (ring, fp32)");
             if (d->defer_out) d->defer_out->splits = 0;
             return 0;
         }
@@ -650,7 +673,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
             same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
                    p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&
                    !gemm_stream_eligible(p[i]);
-        if (same) { RingPlan rp; for (int i = 0; i < m && same; ++i) same = !gemm_ring_eligible(p[i], rp); }
+        if (same) { RingPlan rp; for (int i = 0; i < m && same; ++i) same = !gemm_ring_eligible(p[i], rp) && !gemm_ring_f32_eligible(p[i], rp); }
         if (!same) {
             for (int i = 0; i < m; ++i)
                 if (gemm_launch(p[i], s)) return -1;

@@ -59,6 +59,9 @@ bool gemm_ring_plan(int M, int N, int K, RingPlan &p);
 // split-K weight gradient with tile-ordered slabs on 128 x 128 tiles (tiles_m / tiles_n / split_k / part_stride / slab_ts set by the caller)
 int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s);
 int gemm_ring_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipStream_t s);
+// fp32 form (exact-f32 parity mode): plan for MFMA-bound work (whole 32-row blocks, per-CU balance), launch
+bool gemm_ring_f32_plan(int M, int N, int K, RingPlan &p);
+int gemm_ring_f32_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipStream_t s);
 
 template <int N>
 __device__ __forceinline__ void ring_wait_vmcnt() {
@@ -91,9 +94,11 @@ __device__ __forceinline__ unsigned ring_lds_addr(char *p) {      // LDS byte ad
 }
 
 // K-contiguous operand [rows][k]: piece P = rows 8P .. 8P+7 of the stage image, lane (r = lane / 8, slot position lane % 8)
-template <int NP>
+// ES: bytes per element (2: bf16, 64-deep stages; 4: fp32, 32-deep stages -- a stage row is 128 bytes either way)
+template <int NP, int ES = 2>
 struct RingDmaK {
-    const unsigned short *base;
+    static constexpr int NPIECES = NP;
+    const char *base;
     long long text;            // bytes from `base` to the end of the operand
     unsigned voff[NP];         // loop-invariant per-lane offsets (BUF_OOB: row outside)
     int lds_off[NP];           // wave-uniform byte offset of piece i inside the stage image
@@ -101,23 +106,23 @@ struct RingDmaK {
     // rows [row0, row_end) of the operand belong to this tile; img_rows8: rows the stage image holds
     __device__ __forceinline__ void init(const void *p, long long ld, int row0, int row_end, int rows_total, int K, int img_rows8,
                                          int lane, int wave) {
-        base = reinterpret_cast<const unsigned short *>(p);
-        text = ((long long)(rows_total - 1) * ld + K) * 2;
+        base = reinterpret_cast<const char *>(p);
+        text = ((long long)(rows_total - 1) * ld + K) * ES;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int P = wave + 8 * i;
             const int r = 8 * P + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);                     // source chunk that belongs at this lane's slot
             const int g = row0 + r;
-            voff[i] = (g < row_end) ? (unsigned)((long long)g * ld * 2) + 16u * (unsigned)c : BUF_OOB;
+            voff[i] = (g < row_end) ? (unsigned)((long long)g * ld * ES) + 16u * (unsigned)c : BUF_OOB;
             lds_off[i] = P * 1024;
             in_img[i] = (8 * P < img_rows8) ? -1 : 0;
         }
     }
     // descriptor of K stage k0: base advanced by k0, an EMPTY range past the last stage (no traffic); scalar instructions only
     __device__ __forceinline__ u32x4 stage_rsrc(int k0, int K) const {
-        const unsigned left = (k0 < K) ? (unsigned)(text - 2ll * k0) : 0u;
-        return ring_rsrc(base + k0, left);
+        const unsigned left = (k0 < K) ? (unsigned)(text - (long long)ES * k0) : 0u;
+        return ring_rsrc(base + (long long)ES * k0, left);
     }
     // piece I (a compile-time constant after inlining).  lds0: LDS byte address of the workgroup's array; img / dump: byte offsets into
     // it.  Branch-free on purpose (mask arithmetic instead of ?: -- pointer- and flag-typed selects compiled to scalar branches,
@@ -382,6 +387,187 @@ __global__ __launch_bounds__(RING_THREADS) void gemm_ring_kernel(RingArgs ra) {
     //  with a bare "substitution failure" once the loaders are passed down as template arguments)
 #if defined(__HIP_DEVICE_COMPILE__)
     gemm_ring_body<TM, TN, BKC, NS>(ra, xcd_remap((int)blockIdx.x, (int)gridDim.x));
+#endif
+}
+
+// ===========================================================================================================================
+// fp32 form of the ring (the exact-f32 parity mode: v_mfma_f32_32x32x2_f32, the reference's own arithmetic).  Same pipeline, same
+// tile grid; a stage is 32 k deep (128-byte rows again).  fp32 GEMMs are MFMA-bound (the f32 MFMA runs at 1/16 of the bf16 rate),
+// and the 4-wave engine sat at 0.50 of that peak: one 32x32 accumulator per wave -- eight dependent MFMAs per K tile back to back,
+// issue stalls 52 % of the cycles.  Here a wave owns TM x TN independent accumulators and consecutive MFMAs never
+// touch the same one.
+//   * K-contiguous operand ([rows][k]): the same XOR-swizzled 128-byte-row image; a lane reads the 16-byte chunk of 4 consecutive k of
+//     its row ONCE per two MFMA steps (both lane halves the same address: broadcast) and picks element 2 j + h for step j -- the
+//     operand map of the 32x32x2 MFMA is lane l -> (row l & 31, k = l >> 5);
+//   * MN-contiguous operand ([k][mn]): the image is the operand's own orientation, one 4 BMN-byte row per k; a fragment is one
+//     ds_read_b32 per MFMA step (lanes 0-31 on consecutive dwords of row 2 s, lanes 32-63 of row 2 s + 1: conflict-free, no
+//     transposition -- the f32 MFMA takes one value per lane).
+// Every accumulator sees k in ascending pairs (2 s, 2 s + 1) like gemm_f32_body: bit-identical results.
+template <int BMN>
+struct RingDmaMN32 {       // [k][mn] fp32: piece = 1 KB = 256 floats = 256 / BMN rows of the stage image; lane: row piece * RPP + lane / LPR, columns 4 (lane % LPR) ..
+    static constexpr int LPR = BMN / 4;                  // lanes per image row
+    static constexpr int RPP = 64 / LPR;                 // image rows per piece
+    static constexpr int NP = (32 / RPP) / 8;            // pieces per wave and stage (32 k rows)
+    static constexpr int NPIECES = NP;
+    static_assert(BMN == 128 || BMN == 256, "128 or 256 columns");
+    const char *base;
+    long long text;
+    unsigned ld4b;
+    unsigned voff[NP];
+    int wave;
+    __device__ __forceinline__ void init(const void *p, long long ld, int mn0, int MN, int K, int lane, int wave_) {
+        wave = wave_;
+        base = reinterpret_cast<const char *>(p);
+        text = ((long long)(K - 1) * ld + MN) * 4;
+        ld4b = (unsigned)(ld * 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int P = wave + 8 * i;
+            const int k = P * RPP + lane / LPR;
+            const int col = mn0 + 4 * (lane % LPR);
+            voff[i] = (col + 4 <= MN) ? (unsigned)k * ld4b + 4u * (unsigned)col : BUF_OOB;
+        }
+    }
+    __device__ __forceinline__ u32x4 stage_rsrc(int k0, int K) const {
+        const unsigned left = (k0 < K) ? (unsigned)(text - (long long)k0 * ld4b) : 0u;
+        return ring_rsrc(base + (long long)k0 * ld4b, left);
+    }
+    __device__ __forceinline__ void issue_one(const int I, u32x4 rs, unsigned lds0, int img, int) const {
+        ring_dma_piece(rs, lds0 + (unsigned)(img + (wave + 8 * I) * 1024), voff[I]);
+    }
+    __device__ __forceinline__ void issue(int k0, int K, unsigned lds0, int img, int dump) const {
+        const u32x4 rs = stage_rsrc(k0, K);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) issue_one(i, rs, lds0, img, dump);
+    }
+};
+
+// one 32-deep fp32 stage: NM x TN accumulators x 16 MFMA steps; the requests of the stage NS - 1 ahead ride between the k groups
+template <int NM, int TM, int TN, bool AKC, bool BKC, int BM, int BN, class LA, class LB>
+__device__ __forceinline__ void ring_stage_f32(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, int b_lane, const int (&xo8)[8],
+                                               int h, const LA &la, const LB &lb, int k_next, int K, unsigned lds0, int na, int nb, int dump) {
+    constexpr int NPA = LA::NPIECES, NPB = LB::NPIECES, PW = NPA + NPB;
+    const u32x4 rsa = la.stage_rsrc(k_next, K), rsb = lb.stage_rsrc(k_next, K);
+    if constexpr (NM == 0) {
+        ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+        return;
+    } else {
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {                 // k group of 4: two MFMA steps
+            float av[2][NM], bv[2][TN];
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi) {
+                if constexpr (AKC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(As + a_lane + mi * (32 * RING_STAGE_ROW) + xo8[gq]);
+                    av[0][mi] = h ? v.y : v.x;
+                    av[1][mi] = h ? v.w : v.z;
+                } else {
+                    av[0][mi] = *reinterpret_cast<const float *>(As + a_lane + mi * 128 + (4 * gq) * (BM * 4));
+                    av[1][mi] = *reinterpret_cast<const float *>(As + a_lane + mi * 128 + (4 * gq + 2) * (BM * 4));
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if constexpr (BKC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(Bs + b_lane + ni * (32 * RING_STAGE_ROW) + xo8[gq]);
+                    bv[0][ni] = h ? v.y : v.x;
+                    bv[1][ni] = h ? v.w : v.z;
+                } else {
+                    bv[0][ni] = *reinterpret_cast<const float *>(Bs + b_lane + ni * 128 + (4 * gq) * (BN * 4));
+                    bv[1][ni] = *reinterpret_cast<const float *>(Bs + b_lane + ni * 128 + (4 * gq + 2) * (BN * 4));
+                }
+            }
+            if (gq == 1) ring_issue_range<0, (0 * PW) / 4, (1 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (gq == 3) ring_issue_range<0, (1 * PW) / 4, (2 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (gq == 5) ring_issue_range<0, (2 * PW) / 4, (3 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (gq == 7) ring_issue_range<0, (3 * PW) / 4, (4 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][mi], bv[j][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+}
+
+// unsplit fp32 GEMM: A [M][K] (K-contiguous), B [N][K] or [K][N]; row-balanced tile grid as in gemm_ring_body
+template <int TM, int TN, bool BKC, int NS>
+__device__ __forceinline__ void gemm_ring_f32_body(const RingArgs &ra, const int id) {
+    constexpr int BM = 64 * TM, BN = 128 * TN, WGM = 2, WGN = 4, BKF = 32;
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    extern __shared__ __attribute__((aligned(1024))) char ring_smem[];
+    const GemmArgs &g = ra.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tn = id % g.tiles_n, tm = id / g.tiles_n;
+    const int m0 = tm * ra.tile_rows, n0 = tn * BN;
+    const int row_end = min(g.M, m0 + ra.tile_rows);
+    const int my_rows = row_end - (m0 + wm * T::WTM);
+    const int nmi = my_rows <= 0 ? 0 : (my_rows >= T::WTM ? TM : (my_rows + 31) >> 5);
+    using LAt = RingDmaK<TM, 4>;
+    LAt la;
+    la.init(g.A, g.lda, m0, row_end, g.M, g.K, ra.a_rows8, lane, wave);
+    using LB = typename std::conditional<BKC, RingDmaK<2 * TN, 4>, RingDmaMN32<BN>>::type;
+    LB lb;
+    if constexpr (BKC) lb.init(g.B, g.ldb, n0, g.N, g.N, g.K, BN, lane, wave);
+    else lb.init(g.B, g.ldb, n0, g.N, g.K, lane, wave);
+    constexpr int PW = LAt::NPIECES + LB::NPIECES;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int a_bytes = ra.a_rows8 * RING_STAGE_ROW;
+    const int dump = ra.dump_off;
+    const unsigned lds0 = ring_lds_addr(ring_smem);
+    auto stage_a = [&](int s) { return s * ra.stage_bytes; };
+    auto stage_b = [&](int s) { return s * ra.stage_bytes + a_bytes; };
+    const int l31 = lane & 31, h = lane >> 5;
+    const int sw = (l31 >> 1) & 7;
+    int xo8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xo8[q] = 16 * (q ^ sw);
+    const int a_lane = (wm * T::WTM + l31) * RING_STAGE_ROW;
+    // [n][k]: row of the column block; [k][n]: dword (wn * WTN + l31) of image row h (the MFMA's k = 2 s + h)
+    const int b_lane = BKC ? (wn * T::WTN + l31) * RING_STAGE_ROW : (wn * T::WTN + l31) * 4 + h * (BN * 4);
+    const int nkt = g.K / BKF;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        la.issue(t * BKF, g.K, lds0, stage_a(t), dump);
+        lb.issue(t * BKF, g.K, lds0, stage_b(t), dump);
+    }
+    auto kloop = [&](auto NMC) {
+        constexpr int NM = decltype(NMC)::value;
+        int cur = 0, nxt = NS - 1;
+        for (int t = 0; t < nkt; ++t) {
+            ring_wait_vmcnt<(NS - 2) * PW>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            ring_stage_f32<NM, TM, TN, true, BKC, BM, BN>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, b_lane, xo8, h, la, lb,
+                                                          (t + NS - 1) * BKF, g.K, lds0, stage_a(nxt), stage_b(nxt), dump);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+    };
+    if (nmi == TM) kloop(std::integral_constant<int, TM>{});
+    else if (TM >= 2 && nmi == TM - 1) kloop(std::integral_constant<int, (TM >= 2 ? TM - 1 : 0)>{});
+    else if (TM >= 3 && nmi == TM - 2) kloop(std::integral_constant<int, (TM >= 3 ? TM - 2 : 0)>{});
+    else if (TM >= 4 && nmi == TM - 3) kloop(std::integral_constant<int, (TM >= 4 ? TM - 3 : 0)>{});
+    else kloop(std::integral_constant<int, 0>{});
+    ring_wait_vmcnt<0>();
+    __syncthreads();
+    epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(ring_smem), g.C, g.ldc, row_end, g.N, m0, n0, wm, wn, lane, wave, g.e);
+}
+
+template <int TM, int TN, bool BKC, int NS>
+__global__ __launch_bounds__(RING_THREADS) void gemm_ring_f32_kernel(RingArgs ra) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    gemm_ring_f32_body<TM, TN, BKC, NS>(ra, xcd_remap((int)blockIdx.x, (int)gridDim.x));
 #endif
 }
 

@@ -97,6 +97,67 @@ int gemm_ring_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStream_t 
     return rc;
 }
 
+// fp32 plan: the f32 MFMA runs at 1/16 of the bf16 rate, so these GEMMs are MFMA-bound and what counts is (a) whole 32-row blocks
+// (a SIMD's time is the number of blocks its two row waves issue) and (b) the same number of blocks on every CU: the pitch is the
+// multiple of 32 in 64 .. 192 that minimises ceil(workgroups / 256) x blocks per workgroup (ties: the larger pitch -- fewer re-reads of
+// the weights); 128-column panels, two stages: <= 80 KB of LDS, two workgroups per CU.
+bool gemm_ring_f32_plan(int M, int N, int K, RingPlan &p) {
+    if (M < 1 || N < 128 || K < 32 || K % 32 != 0) return false;
+    const int bn = 128, tiles_n = cdiv(N, bn);
+    const int force_rows = tune(T_RING_ROWS);
+    long long best = -1;
+    int rows = 64;
+    for (int r = 64; r <= 192; r += 32) {
+        const long long c = (long long)cdiv((long long)cdiv(M, r) * tiles_n, 256) * (r / 32);
+        if (best < 0 || c <= best) { best = c; rows = r; }
+    }
+    if (force_rows >= 8) rows = (force_rows + 3) & ~3;
+    if (rows > 192) return false;
+    p.tile_rows = rows;
+    p.tm = cdiv(cdiv(rows, 32), 2);
+    p.tn = 1;
+    p.tiles_m = cdiv(M, rows);
+    p.tiles_n = tiles_n;
+    p.wgs = p.tiles_m * tiles_n;
+    p.a_rows8 = (rows + 7) & ~7;
+    p.stage_bytes = (p.a_rows8 + bn) * RING_STAGE_ROW;
+    p.ns = 2;
+    p.dump_off = p.ns * p.stage_bytes;
+    const int epi_bytes = 8 * 32 * (bn / 4 + 4) * 4;
+    const int ring_bytes = p.dump_off + (p.a_rows8 < 64 * p.tm ? 1024 : 0);       // (no piece lies past a full-capacity image: no dump area)
+    p.lds_bytes = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
+    p.cost = (double)best;
+    return p.lds_bytes <= 160 * 1024;
+}
+
+template <int TM, bool BKC>
+static int ring_f32_launch_one(const RingArgs &ra, int wgs, int lds, hipStream_t s) {
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_f32_kernel<TM, 1, BKC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        DETR_REQUIRE(e == hipSuccess, "gemm (ring, fp32): cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+        reserved = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_f32_kernel<TM, 1, BKC, 2>), dim3((unsigned)wgs), dim3(RING_THREADS), (size_t)lds, s, ra);
+    return 0;
+}
+
+int gemm_ring_f32_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStream_t s) {
+    RingArgs ra;
+    ra.g = g;
+    ra.g.tiles_m = p.tiles_m;
+    ra.g.tiles_n = p.tiles_n;
+    ra.tile_rows = p.tile_rows;
+    ra.a_rows8 = p.a_rows8;
+    ra.stage_bytes = p.stage_bytes;
+    ra.dump_off = p.dump_off;
+    ra.ablate = 0;
+    DETR_REQUIRE(p.tn == 1 && p.ns == 2 && p.tm >= 1 && p.tm <= 3, "gemm (ring, fp32): no instantiation for TM=%d TN=%d NS=%d", p.tm, p.tn, p.ns);
+    if (p.tm == 1) return bk ? ring_f32_launch_one<1, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<1, false>(ra, p.wgs, p.lds_bytes, s);
+    if (p.tm == 2) return bk ? ring_f32_launch_one<2, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<2, false>(ra, p.wgs, p.lds_bytes, s);
+    return bk ? ring_f32_launch_one<3, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<3, false>(ra, p.wgs, p.lds_bytes, s);
+}
+
 int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s) {
     RingArgs ra;
     ra.g = g;

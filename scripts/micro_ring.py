@@ -36,8 +36,15 @@ if only:
     CASES = [c for c in CASES if any(o in c[0] for o in only.split(","))]
 
 
+F32 = os.environ.get("RING_F32") == "1"          # the fp32 parity mode: fp32 operands and tensors, compute = 0
+
+
 def run(case, mode, reps=30):
     name, M, N, K, bk, kw = case
+    if F32:
+        global bf
+        bf = torch.float32
+        reps = 10
     torch.manual_seed(M + N + K + bk)
     A = torch.randn(M, K, device=dev).to(bf)
     B = ((torch.randn(N, K, device=dev) if bk else torch.randn(K, N, device=dev)) / K ** 0.5).to(bf)
@@ -48,7 +55,7 @@ def run(case, mode, reps=30):
     bias = torch.randn(N, device=dev) if kw.get("bias") else None
     args = (M, N, K, A, K, 1, B, B.stride(0), bk, C, N)
     kws = dict(bias=bias, residual=res, ldr=N if res is not None else 0, mask=msk, ldmask=N if msk is not None else 0, act=kw.get("act", 0),
-               compute=1)
+               compute=0 if F32 else 1)
     for k, v in mode.items():
         hip.set_tuning(k, v)
     try:

@@ -1933,3 +1933,64 @@ def test_gemm_ring_split_k_weight_gradient_is_bit_identical(hip, ns, M, N, K, sp
     want = 0.5 + 0.75 * (A.double().cpu().t() @ Bm.double().cpu())
     assert float((outs[1].double() - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
     assert torch.equal(outs[0], outs[1]), (float((outs[0] - outs[1]).abs().max()), int((outs[0] != outs[1]).sum()))
+
+
+@pytest.mark.parametrize("rows", [None, "64", "96", "160"])
+@pytest.mark.parametrize("M,N,K,bk,epi", [(600, 256, 128, 1, "res_mask"), (600, 256, 128, 0, "bias_relu"), (1333, 128, 64, 0, "plain"),
+                                          (2100, 384, 192, 1, "scale_bias_res_mask_relu"), (840, 256, 2048, 0, "drop_res"),
+                                          (4200, 1024, 512, 1, "bias_res"), (33, 136, 96, 0, "bias")])
+def test_gemm_ring_fp32_is_bit_identical_to_the_tile_engine(hip, rows, M, N, K, bk, epi):
+    """The fp32 form of the ring kernel (csrc/gemm_ring.h gemm_ring_f32_kernel: exact-f32 MFMA, TM x TN independent accumulators per
+    wave) against the 4-wave fp32 engine: every accumulator sees k in the same ascending pairs and the MFMA is an fmaf chain, so the
+    outputs must be IDENTICAL bits -- both weight layouts ([n][k]: 16-byte chunk + lane-half select; [k][n]: one dword per MFMA
+    step), ragged M / N, every epilogue item, several row pitches.  The engine itself is pinned against fp64."""
+    torch.manual_seed(M + N + K + bk)
+    A = g(torch.randn(M, K))
+    Bm = g(torch.randn(N, K) / K ** 0.5) if bk else g(torch.randn(K, N) / K ** 0.5)
+    bias, scale = g(torch.randn(N)), g(torch.rand(N) + 0.5)
+    res, msk = g(torch.randn(M, N)), g(torch.randn(M, N))
+    step = torch.tensor([0x13579bd, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+    kw = dict(compute=0)
+    if "bias" in epi:
+        kw.update(bias=bias)
+    if "scale" in epi:
+        kw.update(scale=scale, alpha=0.75)
+    if "relu" in epi:
+        kw.update(act=1)
+    if "res" in epi:
+        kw.update(residual=res, ldr=N)
+    if "mask" in epi:
+        kw.update(mask=msk, ldmask=N)
+    if "drop" in epi:
+        kw.update(dropout_p=0.1, dropout_seed=11, dropout_step=step)
+    outs = []
+    for ring in ("1", "2"):
+        env = {"DETR_HIP_GEMM_RING": ring, "DETR_HIP_RING_ROWS": rows}
+        for k, v in env.items():
+            hip.set_tuning(k, v)
+        try:
+            C = torch.full((M, N), 7.0, device=DEV)
+            hip.gemm(M, N, K, A, K, 1, Bm, Bm.stride(0), bk, C, N, **kw)
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                hip.set_tuning(k, None)
+        outs.append(C.cpu())
+    ring_out, tile_out = outs
+    want = A.double().cpu() @ (Bm.double().cpu().t() if bk else Bm.double().cpu())
+    if "scale" in epi:
+        want = want * scale.double().cpu()
+    if "bias" in epi:
+        want = want + bias.double().cpu()
+    if "scale" in epi:
+        want = want * 0.75
+    if "drop" not in epi:
+        if "res" in epi:
+            want = want + res.double().cpu()
+        if "relu" in epi:
+            want = torch.relu(want)
+        if "mask" in epi:
+            want = torch.where(msk.double().cpu() > 0, want, torch.zeros_like(want))
+        assert float((tile_out.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    assert float(tile_out.abs().max()) > 0
+    assert torch.equal(ring_out, tile_out), (float((ring_out - tile_out).abs().max()), int((ring_out != tile_out).sum()), ring_out.numel())
