@@ -108,6 +108,7 @@ enum TuneKey {
     T_RING_BN,           // column panel forced (128 / 256); 0 = cost model
     T_RING_WGS,          // workgroup target forced; 0 = cost model
     T_RING_ROWS,         // row pitch forced (sweeps)
+    T_RING_WTILE,        // ring weight gradient on 128 x 256 (1) / 256 x 128 (2) tiles (experiments)
     T_RING_ABLATE,       // timing experiments: RingArgs.ablate bits (results wrong when set)
     T_COUNT
 };

@@ -34,6 +34,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_RING_BN",
     "DETR_HIP_RING_WGS",
     "DETR_HIP_RING_ROWS",
+    "DETR_HIP_RING_WTILE",
     "DETR_HIP_RING_ABLATE",
 };
 static int g_tune[T_COUNT];

@@ -288,6 +288,13 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
         else if (force == 3 || (force == 0 && small)) tile = 0;
         else if (force == 0 && split > 1 && d->M <= 64) tile = 4;     // 64 output rows: half of a 128-row tile would be padding (M64 N256 K534400: 84 -> 74 us)
         else tile = 1;
+        // ring weight gradient (gemm_ring.h) on wider tiles -- experiment hook DETR_HIP_RING_WTILE: 1 = 128 x 256, 2 = 256 x 128
+        if (tile == 1 && split > 1 && batch == 1 && d->a_dtype == 1 && d->b_dtype == 1 && !d->a_kcontig && !d->b_kcontig && !d->rowsum_a &&
+            tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3) {
+            const int wt = tune(T_RING_WTILE);
+            if (wt == 1 && d->N >= 256) tile = 6;
+            else if (wt == 2 && d->M >= 256) tile = 7;
+        }
     } else if (force == 1) tile = 1;
     else if (force == 2) tile = 2;
     else if (force == 3) tile = 0;
@@ -302,6 +309,8 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
 static void gemm_tile_dims(bool bf16c, int tile, int &bm, int &bn, bool &ts_ok) {
     ts_ok = true;
     if (tile == 1) { bm = 128; bn = 128; }
+    else if (tile == 6 && bf16c) { bm = 128; bn = 256; }         // (ring weight gradient only)
+    else if (tile == 7 && bf16c) { bm = 256; bn = 128; }
     else if (tile == 2) { bm = 128; bn = 64; }
     else if (tile == 4 && bf16c) { bm = 64; bn = 128; }
     else if (tile == 0) { bm = 64; bn = 64; }
@@ -558,7 +567,14 @@ static bool gemm_ring_eligible(const GemmPlan &p, RingPlan &rp) {
     if (!(p.bf16c && g.a16 && g.b16 && p.ak && p.batch == 1 && p.split == 1 && !g.rowsum && !d->ln_y)) return false;
     if (!(d->K % RING_BK == 0 && d->K >= 2 * RING_BK && d->N >= 128 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) &&
           aligned16(d->B))) return false;
-    if (mode != 1 && !(d->M >= 4096 && d->K >= 512)) return false;
+    // which shapes (scripts/micro_gemm.py / micro_ring.py, profiles/r05_micro_gemm_ring.txt): every tall K >= 512 GEMM (-15 .. -30 % against the
+    // 4-wave engine); the decoder's 800-row K = 2048 FFN GEMMs (15.2 -> 11.0 us); and, in front of the streaming kernel, two K = 256
+    // families it runs faster than that kernel does: layer3's N = 1024 block outputs / input gradients (M33600: 51.5 -> 45.7,
+    // 62.5 -> 51.8 us) and the encoder FFN's input gradient with [k][n] weights (M8400 N2048: 31.6 -> 26.6 us)
+    const bool tall = d->M >= 4096 && d->K >= 512;
+    const bool dec_ffn = d->M >= 512 && d->K >= 1024;
+    const bool k256 = d->K == 256 && d->N >= 1024 && (d->M >= 16384 || (d->M >= 4096 && !p.bk));
+    if (mode != 1 && !(tall || dec_ffn || k256)) return false;
     return gemm_ring_plan(d->M, d->N, d->K, rp);
 }
 
@@ -585,14 +601,15 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const int batch = p.batch;
     const bool ak = p.ak, bk = p.bk;
     if (d->ln_y) return gemm_ln_launch(p, s);
-    if (gemm_stream_eligible(p)) {
-        gemm_stream_launch(p, s);
-        DETR_LAUNCH_CHECK("gemm (stream)");
-        return 0;
-    }
     {
         RingPlan rp;
-        if (gemm_ring_eligible(p, rp)) {
+        const bool ring_first = tune(T_GEMM_STREAM) != 3 && gemm_ring_eligible(p, rp);      // (DETR_HIP_GEMM_STREAM=3: the streaming kernel keeps its K = 256 shapes)
+        if (!ring_first && gemm_stream_eligible(p)) {
+            gemm_stream_launch(p, s);
+            DETR_LAUNCH_CHECK("gemm (stream)");
+            return 0;
+        }
+        if (ring_first) {
             if (gemm_ring_launch(g, bk, rp, s)) return -1;
             DETR_LAUNCH_CHECK("gemm (ring)");
             if (d->defer_out) d->defer_out->splits = 0;
@@ -606,9 +623,12 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         }
     }
     // split-K weight gradients of the backbone's 1x1 convolutions on 128 x 128 tiles: the 8-wave ring form (gemm_ring.h; bit-identical slabs)
-    if (p.bf16c && p.tile == 1 && g.a16 && g.b16 && !ak && !bk && batch == 1 && p.split > 1 && g.slab_ts && !g.rowsum && d->M % 8 == 0 &&
-        d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) && aligned16(d->B) && tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3) {
-        if (gemm_ring_wgrad_launch(g, cdiv(g.M, 128), cdiv(g.N, 128), p.split, s)) return -1;
+    const bool ring_wgrad = p.bf16c && (p.tile == 1 || p.tile == 6 || p.tile == 7) && g.a16 && g.b16 && !ak && !bk && batch == 1 && p.split > 1 &&
+                            g.slab_ts && !g.rowsum && d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) &&
+                            aligned16(d->B) && tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3;
+    DETR_REQUIRE(ring_wgrad || (p.tile != 6 && p.tile != 7), "gemm: the 128 x 256 / 256 x 128 tiles exist for the ring weight gradient only");
+    if (ring_wgrad) {
+        if (gemm_ring_wgrad_launch(g, p.ts_bm, p.ts_bn, p.split, s)) return -1;
     } else if (p.bf16c) {
         if (p.tile == 2) launch_cfg_bf16<128, 64, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
@@ -787,7 +807,7 @@ extern "C" int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_
             r.ws = d.ws; r.splits = d.splits; r.part_stride = d.part_stride; r.rows = d.rows; r.cols = d.cols; r.C = d.C; r.ldc = d.ldc;
             r.alpha = d.alpha; r.scale = d.scale; r.rs_ws = d.rs_ws; r.rs_out = d.rs_out; r.rs_alpha = d.rs_alpha;
             r.ts_bm = d.ts_bm; r.ts_bn = d.ts_bn; r.ts_tn = d.ts_tiles_n > 0 ? d.ts_tiles_n : 1;
-            DETR_REQUIRE(d.ts_bm == 0 || ((d.ts_bm == 64 || d.ts_bm == 128) && (d.ts_bn == 64 || d.ts_bn == 128) && d.ts_tiles_n > 0 &&
+            DETR_REQUIRE(d.ts_bm == 0 || ((d.ts_bm == 64 || d.ts_bm == 128 || d.ts_bm == 256) && (d.ts_bn == 64 || d.ts_bn == 128 || d.ts_bn == 256) && d.ts_tiles_n > 0 &&
                                           d.part_stride % ((long long)d.ts_bm * d.ts_bn) == 0),
                          "splitk_reduce_many: entry %d has a malformed tile-ordered slab description", i);
             bool small;

@@ -57,7 +57,7 @@ struct RingPlan {
 };
 bool gemm_ring_plan(int M, int N, int K, RingPlan &p);
 // split-K weight gradient with tile-ordered slabs on 128 x 128 tiles (tiles_m / tiles_n / split_k / part_stride / slab_ts set by the caller)
-int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s);
+int gemm_ring_wgrad_launch(const GemmArgs &g, int bm, int bn, int split, hipStream_t s);
 int gemm_ring_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipStream_t s);
 // fp32 form (exact-f32 parity mode): plan for MFMA-bound work (whole 32-row blocks, per-CU balance), launch
 bool gemm_ring_f32_plan(int M, int N, int K, RingPlan &p);
@@ -626,17 +626,23 @@ __device__ __forceinline__ void gemm_ring_wgrad_body(const RingArgs &ra) {
         la.issue(kbeg + t * RING_BK, kend, lds0, t * STAGE, 0);
         lb.issue(kbeg + t * RING_BK, kend, lds0, t * STAGE + A_BYTES, 0);
     }
-    int cur = 0, nxt = NS - 1;
-    for (int t = 0; t < nkt; ++t) {
-        ring_wait_vmcnt<(NS - 2) * PW>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        ring_stage<TM, TM, TN, false, false, false>(ring_smem + cur * STAGE, ring_smem + cur * STAGE + A_BYTES, acc, 0, atr, 0, btr, xo, la, lb,
-                                                    kbeg + (t + NS - 1) * RING_BK, kend, lds0, nxt * STAGE, nxt * STAGE + A_BYTES, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-    }
+    const int abl = ra.ablate;
+    auto kloop = [&](auto ABLC) {
+        constexpr bool ABL = decltype(ABLC)::value;
+        int cur = 0, nxt = NS - 1;
+        for (int t = 0; t < nkt; ++t) {
+            ring_wait_vmcnt<(NS - 2) * PW>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            ring_stage<TM, TM, TN, false, false, ABL>(ring_smem + cur * STAGE, ring_smem + cur * STAGE + A_BYTES, acc, 0, atr, 0, btr, xo, la, lb,
+                                                      kbeg + (t + NS - 1) * RING_BK, kend, lds0, nxt * STAGE, nxt * STAGE + A_BYTES, 0, abl);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+    };
+    if (abl) kloop(std::integral_constant<bool, true>{});      // (DETR_HIP_RING_ABLATE timing experiments: bits 1, 2, 4 as in gemm_ring_body)
+    else kloop(std::integral_constant<bool, false>{});
     ring_wait_vmcnt<0>();
     // tile-ordered slab of this (split, tile), in the 2 x 2 grid's unit order
     float4 *slab = reinterpret_cast<float4 *>(g.C + (long long)split * g.part_stride + (long long)tile * (BM * BN));

@@ -158,26 +158,34 @@ int gemm_ring_f32_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStrea
     return bk ? ring_f32_launch_one<3, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<3, false>(ra, p.wgs, p.lds_bytes, s);
 }
 
-int gemm_ring_wgrad_launch(const GemmArgs &g, int tiles_m, int tiles_n, int split, hipStream_t s) {
-    RingArgs ra;
-    ra.g = g;
-    ra.g.tiles_m = tiles_m;
-    ra.g.tiles_n = tiles_n;
-    ra.tile_rows = ra.a_rows8 = ra.stage_bytes = ra.dump_off = ra.ablate = 0;
-    constexpr int STAGE = (128 + 128) * RING_STAGE_ROW;
-    const int ns = tune(T_RING_NS) == 3 ? 3 : 4;
-    const int lds = ns * STAGE;
+template <int TM, int TN, int NS>
+static int ring_wgrad_launch_one(const RingArgs &ra, int wgs, hipStream_t s) {
+    constexpr int LDS = NS * (64 * TM + 128 * TN) * RING_STAGE_ROW;
+    static_assert(LDS <= 160 * 1024, "ring does not fit the LDS");
     static bool reserved = false;
     if (!reserved) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_wgrad_kernel<2, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_wgrad_kernel<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_wgrad_kernel<TM, TN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         DETR_REQUIRE(e == hipSuccess, "gemm (ring wgrad): cannot reserve LDS: %s", hipGetErrorString(e));
         reserved = true;
     }
-    const dim3 grid((unsigned)(tiles_m * tiles_n * split));
-    if (ns == 3) hipLaunchKernelGGL((gemm_ring_wgrad_kernel<2, 1, 3>), grid, dim3(RING_THREADS), (size_t)lds, s, ra);
-    else hipLaunchKernelGGL((gemm_ring_wgrad_kernel<2, 1, 4>), grid, dim3(RING_THREADS), (size_t)lds, s, ra);
+    hipLaunchKernelGGL((gemm_ring_wgrad_kernel<TM, TN, NS>), dim3((unsigned)wgs), dim3(RING_THREADS), (size_t)LDS, s, ra);
     return 0;
+}
+
+// bm x bn: 128 x 128 (the product), 128 x 256 / 256 x 128 (DETR_HIP_RING_WTILE experiments)
+int gemm_ring_wgrad_launch(const GemmArgs &g, int bm, int bn, int split, hipStream_t s) {
+    RingArgs ra;
+    ra.g = g;
+    ra.g.tiles_m = cdiv(g.M, bm);
+    ra.g.tiles_n = cdiv(g.N, bn);
+    ra.tile_rows = ra.a_rows8 = ra.stage_bytes = ra.dump_off = 0;
+    ra.ablate = tune(T_RING_ABLATE);
+    const int wgs = ra.g.tiles_m * ra.g.tiles_n * split;
+    if (bm == 128 && bn == 128) return tune(T_RING_NS) == 3 ? ring_wgrad_launch_one<2, 1, 3>(ra, wgs, s) : ring_wgrad_launch_one<2, 1, 4>(ra, wgs, s);
+    if (bm == 128 && bn == 256) return ring_wgrad_launch_one<2, 2, 3>(ra, wgs, s);
+    if (bm == 256 && bn == 128) return ring_wgrad_launch_one<4, 1, 3>(ra, wgs, s);
+    DETR_REQUIRE(false, "gemm (ring wgrad): no instantiation for %d x %d tiles", bm, bn);
+    return -1;
 }
 
 }  // namespace detr

@@ -519,7 +519,10 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
             and K in (64, 128, 256) and N % 64 == 0 and M >= (4096 if (K == 256 and N >= 1024) else 16384) and scale is None
             and (K == 256 or (alpha == 1.0 and dropout_p == 0.0))
             and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or d.m_dtype == 2 or (d.m_dtype and ldmask % 8 == 0))
-            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"):
+            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"
+            # (round 5: the ring kernel -- billed to the tile-GEMM family -- has first call on two K = 256 families, gemm_ring_eligible())
+            and not (K == 256 and N >= 1024 and (M >= 16384 or (M >= 4096 and not b_kcontig))
+                     and os.environ.get("DETR_HIP_GEMM_RING") != "2" and os.environ.get("DETR_HIP_GEMM_STREAM") != "3")):
         fam = "gemm_stream_bf16_kernel"          # one kernel body; its K / layout / epilogue instantiations are pooled
     sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} a16{d.a_dtype} b16{d.b_dtype} sk{split_k}"
            f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")

@@ -325,29 +325,33 @@ def test_auto_launch_decision_is_taken_once_per_stepper(hip):
 
 
 def test_bf16_training_curve_tracks_the_fp32_curve(hip):
-    """convergence evidence for the headline precision on CURRENT code.  The full six-layer model is trained for 24
-    steps on one fixed synthetic batch (B = 4, 384x512, dropout 0.1) three times: exact fp32, precision="bf16" with the SAME dropout
-    masks, and exact fp32 with ANOTHER dropout stream -- the yardstick: training on one batch with Hungarian matching is chaotic (a
-    flipped assignment moves the loss by a few %), so "bf16 tracks fp32" is stated relative to how far fp32 strays from itself.
-    All three curves must fall by more than 40 %; the bf16 curve must stay within 8 % of the fp32 curve at every step and, averaged
-    over the second half, no further from it than 1.5 x the fp32-vs-fp32 distance (or 2 % of the loss, whichever is larger).
-    Measured (round 4, GPUTEST box): second-half mean |bf16 - fp32| = 0.34 against |fp32' - fp32| = 0.72 at a loss of ~30."""
+    """convergence evidence for the headline precision on CURRENT code.  The full six-layer model is trained
+    for 100 steps on TWO fixed synthetic batches taken in turn (B = 4, 384x512, dropout 0.1) three times: exact fp32, precision="bf16"
+    with the SAME dropout masks, and exact fp32 with ANOTHER dropout stream -- the yardstick: training on a fixed batch with
+    Hungarian matching is chaotic (a flipped assignment moves the loss by a few %), so "bf16 tracks fp32" is stated relative to how
+    far fp32 strays from itself.  Compared on 10-step window means (the two batches have different loss levels): all three curves
+    must fall by more than 40 %; every window of the bf16 curve within 10 % of the fp32 window; over the second half the bf16 curve no
+    further from fp32 than 1.5 x the fp32-vs-fp32 distance (or 3 % of the loss, whichever is larger)."""
     from detr_tf import training
     from detr_tf.networks.detr import get_detr_model
     from detr_tf.optimizers import setup_optimizers
     from oracle.set_loss_ref import make_targets
     cfg = _cfg()
     cfg.batch_size = 4
-    images = torch.from_numpy(np.random.default_rng(7).normal(size=(4, 384, 512, 3)).astype(np.float32)).cuda()
-    tb, tc = make_targets(4, seed=8, force_full=False)
-    tb, tc = torch.from_numpy(tb).cuda(), torch.from_numpy(tc).cuda()
+    STEPS = 100
+    batches = []
+    for b in range(2):
+        images = torch.from_numpy(np.random.default_rng(7 + b).normal(size=(4, 384, 512, 3)).astype(np.float32)).cuda()
+        tb, tc = make_targets(4, seed=8 + b, force_full=False)
+        batches.append((images, torch.from_numpy(tb).cuda(), torch.from_numpy(tc).cuda()))
     curves = {}
     for tag, prec, skip in (("fp32", "fp32", 0), ("bf16", "bf16", 0), ("fp32_other_masks", "fp32", 1000)):
         model = get_detr_model(cfg, include_top=True, device="cuda:0", seed=0, dropout=0.1, precision=prec)
         opt = setup_optimizers(model, cfg)
-        model.engine._step_no += skip               # another dropout stream: same weights, same batch, other masks
+        model.engine._step_no += skip               # another dropout stream: same weights, same batches, other masks
         losses = []
-        for i in range(24):
+        for i in range(STEPS):
+            images, tb, tc = batches[i % 2]
             out, total, log, steps = training.run_train_step(model, images, tb, tc, opt, cfg)
             for name in steps:
                 training.aggregate_grad_and_apply(name, opt, steps[name]["gradients"], i, cfg)
@@ -355,13 +359,15 @@ def test_bf16_training_curve_tracks_the_fp32_curve(hip):
         curves[tag] = np.array(losses)
         del model, opt
         torch.cuda.empty_cache()
-    f, h, f2 = curves["fp32"], curves["bf16"], curves["fp32_other_masks"]
+    win = lambda c: c.reshape(-1, 10).mean(axis=1)            # 10 steps = 5 of each batch
+    f, h, f2 = (win(curves[k]) for k in ("fp32", "bf16", "fp32_other_masks"))
     for k, v in curves.items():
-        print(f"[train sanity] {k}:", np.round(v, 3).tolist())
+        print(f"[train sanity] {k} (window means):", np.round(win(v), 3).tolist())
     for c in (f, h, f2):
         assert c[-1] < 0.6 * c[0], (c[0], c[-1])
     rel = np.abs(h - f) / np.abs(f)
-    assert rel.max() < 0.08, rel.round(4).tolist()
-    d_bf16, d_self = float(np.abs(h - f)[12:].mean()), float(np.abs(f2 - f)[12:].mean())
-    print(f"[train sanity] second-half mean |bf16 - fp32| = {d_bf16:.3f}, |fp32' - fp32| = {d_self:.3f}")
-    assert d_bf16 <= max(1.5 * d_self, 0.02 * float(f[12:].mean())), (d_bf16, d_self)
+    d_bf16, d_self = float(np.abs(h - f)[5:].mean()), float(np.abs(f2 - f)[5:].mean())
+    print(f"[train sanity] max window |bf16 - fp32| / fp32 = {rel.max():.4f}; second-half mean |bf16 - fp32| = {d_bf16:.3f}, "
+          f"|fp32' - fp32| = {d_self:.3f} at a loss of {float(f[5:].mean()):.2f}")
+    assert rel.max() < 0.10, rel.round(4).tolist()
+    assert d_bf16 <= max(1.5 * d_self, 0.03 * float(f[5:].mean())), (d_bf16, d_self)
