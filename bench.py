@@ -166,7 +166,7 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
     bound = "mfma" if tflops / peak_tf >= gbs / PEAK_HBM_GBS else "hbm"
     traffic = traffic_src = None
     # (the newest committed PMC summary of this precision: profiles/rNN_traffic[_bf16].json)
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         cand = traffic_file.replace("r03", rnd)
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             traffic_file = cand
@@ -178,7 +178,9 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
         if dom in tj.get("per_symbol", {}):
             traffic = round(tj["per_symbol"][dom]["traffic_bytes_per_launch"])
             traffic_src = f"profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
-    r = {"bound": bound, "kernel": "detr::" + dom + " (every template instantiation of the kernel body pooled; plain + grouped launches)",
+    r = {"bound": bound, "kernel": "detr::" + dom + (" (the bf16 tile-GEMM family: gemm_bf16c{,_group,_k64,_ln}_kernel and the round-5 8-wave LDS-DMA ring kernels "
+                                          "gemm_ring{,_wgrad}_kernel, every template instantiation pooled)" if dom == "gemm_bf16c_kernel" else
+                                          " (every template instantiation of the kernel body pooled; plain + grouped launches)"),
          "achieved": round(gbs, 1) if bound == "hbm" else round(tflops, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak_tf,
          "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
          "frac": round(gbs / PEAK_HBM_GBS if bound == "hbm" else tflops / peak_tf, 4),
