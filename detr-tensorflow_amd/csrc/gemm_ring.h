@@ -443,15 +443,19 @@ struct RingDmaMN32 {       // [k][mn] fp32: piece = 1 KB = 256 floats = 256 / BM
 };
 
 // one 32-deep fp32 stage: NM x TN accumulators x 16 MFMA steps; the requests of the stage NS - 1 ahead ride between the k groups
-template <int NM, int TM, int TN, bool AKC, bool BKC, int BM, int BN, class LA, class LB>
+template <int NM, int TM, int TN, bool AKC, bool BKC, int BM, int BN, bool ABL, class LA, class LB>
 __device__ __forceinline__ void ring_stage_f32(const char *As, const char *Bs, f32x16 (&acc)[TM][TN], int a_lane, int b_lane, const int (&xo8)[8],
-                                               int h, const LA &la, const LB &lb, int k_next, int K, unsigned lds0, int na, int nb, int dump) {
+                                               int h, const LA &la, const LB &lb, int k_next, int K, unsigned lds0, int na, int nb, int dump, int abl) {
     constexpr int NPA = LA::NPIECES, NPB = LB::NPIECES, PW = NPA + NPB;
     const u32x4 rsa = la.stage_rsrc(k_next, K), rsb = lb.stage_rsrc(k_next, K);
     if constexpr (NM == 0) {
-        ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+        ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, ABL ? abl : 0);
         return;
     } else {
+        if constexpr (ABL) {             // timing experiments: requests up front under their switches; bit 0: no fragment reads / MFMAs
+            ring_issue_range<0, 0, PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, abl);
+            if (abl & 1) return;
+        }
 #pragma unroll
         for (int gq = 0; gq < 8; ++gq) {                 // k group of 4: two MFMA steps
             float av[2][NM], bv[2][TN];
@@ -477,10 +481,12 @@ __device__ __forceinline__ void ring_stage_f32(const char *As, const char *Bs, f
                     bv[1][ni] = *reinterpret_cast<const float *>(Bs + b_lane + ni * 128 + (4 * gq + 2) * (BN * 4));
                 }
             }
-            if (gq == 1) ring_issue_range<0, (0 * PW) / 4, (1 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (gq == 3) ring_issue_range<0, (1 * PW) / 4, (2 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (gq == 5) ring_issue_range<0, (2 * PW) / 4, (3 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (gq == 7) ring_issue_range<0, (3 * PW) / 4, (4 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if constexpr (!ABL) {
+                if (gq == 1) ring_issue_range<0, (0 * PW) / 4, (1 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+                if (gq == 3) ring_issue_range<0, (1 * PW) / 4, (2 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+                if (gq == 5) ring_issue_range<0, (2 * PW) / 4, (3 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+                if (gq == 7) ring_issue_range<0, (3 * PW) / 4, (4 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -535,24 +541,30 @@ __device__ __forceinline__ void gemm_ring_f32_body(const RingArgs &ra, const int
     // [n][k]: row of the column block; [k][n]: dword (wn * WTN + l31) of image row h (the MFMA's k = 2 s + h)
     const int b_lane = BKC ? (wn * T::WTN + l31) * RING_STAGE_ROW : (wn * T::WTN + l31) * 4 + h * (BN * 4);
     const int nkt = g.K / BKF;
+    const int abl = ra.ablate;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) {
-        la.issue(t * BKF, g.K, lds0, stage_a(t), dump);
-        lb.issue(t * BKF, g.K, lds0, stage_b(t), dump);
+        if (!(abl & 2)) la.issue(t * BKF, g.K, lds0, stage_a(t), dump);
+        if (!(abl & 4)) lb.issue(t * BKF, g.K, lds0, stage_b(t), dump);
     }
-    auto kloop = [&](auto NMC) {
+    auto kloop_ab = [&](auto NMC, auto ABLC) {
         constexpr int NM = decltype(NMC)::value;
+        constexpr bool ABL = decltype(ABLC)::value;
         int cur = 0, nxt = NS - 1;
-        for (int t = 0; t < nkt; ++t) {
+        for (int t = 0; t < ((abl & 16) ? 0 : nkt); ++t) {
             ring_wait_vmcnt<(NS - 2) * PW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            ring_stage_f32<NM, TM, TN, true, BKC, BM, BN>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, b_lane, xo8, h, la, lb,
-                                                          (t + NS - 1) * BKF, g.K, lds0, stage_a(nxt), stage_b(nxt), dump);
+            ring_stage_f32<NM, TM, TN, true, BKC, BM, BN, ABL>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, b_lane, xo8, h, la, lb,
+                                                               (t + NS - 1) * BKF, g.K, lds0, stage_a(nxt), stage_b(nxt), dump, abl);
             __builtin_amdgcn_sched_barrier(0);
             cur = (cur + 1 == NS) ? 0 : cur + 1;
             nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
         }
+    };
+    auto kloop = [&](auto NMC) {
+        if (abl) kloop_ab(NMC, std::integral_constant<bool, true>{});
+        else kloop_ab(NMC, std::integral_constant<bool, false>{});
     };
     if (nmi == TM) kloop(std::integral_constant<int, TM>{});
     else if (TM >= 2 && nmi == TM - 1) kloop(std::integral_constant<int, (TM >= 2 ? TM - 1 : 0)>{});
@@ -561,6 +573,13 @@ __device__ __forceinline__ void gemm_ring_f32_body(const RingArgs &ra, const int
     else kloop(std::integral_constant<int, 0>{});
     ring_wait_vmcnt<0>();
     __syncthreads();
+    if (abl & 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ablate_keep(acc[i][j]);
+        return;
+    }
     epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(ring_smem), g.C, g.ldc, row_end, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 

@@ -151,7 +151,7 @@ int gemm_ring_f32_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStrea
     ra.a_rows8 = p.a_rows8;
     ra.stage_bytes = p.stage_bytes;
     ra.dump_off = p.dump_off;
-    ra.ablate = 0;
+    ra.ablate = tune(T_RING_ABLATE);
     DETR_REQUIRE(p.tn == 1 && p.ns == 2 && p.tm >= 1 && p.tm <= 3, "gemm (ring, fp32): no instantiation for TM=%d TN=%d NS=%d", p.tm, p.tn, p.ns);
     if (p.tm == 1) return bk ? ring_f32_launch_one<1, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<1, false>(ra, p.wgs, p.lds_bytes, s);
     if (p.tm == 2) return bk ? ring_f32_launch_one<2, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<2, false>(ra, p.wgs, p.lds_bytes, s);
