@@ -449,6 +449,53 @@ extern "C" int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int
     return 0;
 }
 
+// deterministic column sums: partial[chunk][c] in a fixed per-thread order, then out[c] += alpha * (partial[0][c] + partial[1][c] + ...)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, float *__restrict__ part, long long rows, int cols,
+                                                             long long ld, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    float s0 = 0.f, s1 = 0.f;
+    long long r = r0;
+    for (; r + 1 < r1; r += 2) {
+        s0 += x[r * ld + c];
+        s1 += x[(r + 1) * ld + c];
+    }
+    if (r < r1) s0 += x[r * ld + c];
+    part[(long long)blockIdx.y * cols + c] = s0 + s1;
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ part, float *__restrict__ out, int chunks, int cols, float alpha) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long long)k * cols + c];
+    out[c] += alpha * s;
+}
+static int colsum_det_rpb(int64_t rows) {
+    int rpb = 64;
+    while ((rows + rpb - 1) / rpb > 256) rpb *= 2;          // <= 256 chunks: the ordered finish pass stays short
+    return rpb;
+}
+extern "C" int64_t detr_hip_colsum_det_scratch_floats(int64_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return -1;
+    const int rpb = colsum_det_rpb(rows);
+    return ((rows + rpb - 1) / rpb) * (int64_t)cols;
+}
+extern "C" int detr_hip_colsum_det_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha, float *scratch,
+                                       int64_t scratch_floats, void *stream) {
+    DETR_REQUIRE(x && out && scratch && rows > 0 && cols > 0, "colsum_det: bad args");
+    const int rpb = colsum_det_rpb(rows);
+    const int chunks = (int)((rows + rpb - 1) / rpb);
+    DETR_REQUIRE(scratch_floats >= (int64_t)chunks * cols, "colsum_det: scratch holds %lld floats, %lld needed", (long long)scratch_floats,
+                 (long long)chunks * cols);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(cols, 256), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, scratch,
+                       (long long)rows, cols, (long long)ld, rpb);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, scratch, out, chunks, cols, alpha);
+    DETR_LAUNCH_CHECK("colsum_det");
+    return 0;
+}
+
 extern "C" int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n, int64_t period,
                                       void *stream) {
     DETR_REQUIRE(x && p && out && n > 0 && period > 0, "add_bcast: bad args");

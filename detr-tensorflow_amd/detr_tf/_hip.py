@@ -142,6 +142,7 @@ _SIGNATURES = {
     "detr_hip_fma_vec_group": [c_void_p, c_int32, c_void_p],
     "detr_hip_set_u32x8": [c_void_p] + [ctypes.c_uint32] * 8 + [c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
+    "detr_hip_colsum_det_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, f32p, c_int64, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],
     "detr_hip_add_f32": [f32p, f32p, f32p, c_int64, c_void_p],
     "detr_hip_sigmoid_bwd_f32": [f32p, f32p, f32p, c_int64, c_void_p],
@@ -164,6 +165,7 @@ _SIGNATURES = {
 }
 # scratch sizing queries (return int64 bytes)
 _SIGNATURES_I64 = {
+    "detr_hip_colsum_det_scratch_floats": [c_int64, c_int32],
     "detr_hip_workspace_bytes_gemm": [POINTER(GemmDesc)],
     "detr_hip_workspace_bytes_conv3x3": [POINTER(Conv3x3Desc), c_int32],
     "detr_hip_workspace_bytes_stem": [POINTER(StemDesc), c_int32],

@@ -268,8 +268,13 @@ class DetrEngine:
             hip.gemm(M_out, N_out, K_red, A, lda, 0, Bm, ldb, 0, C, ldc, alpha=alpha, scale=scale, residual=C, ldr=ldc)
 
     def _colsum(self, x2d, out, alpha=1.0):
-        hip.call("detr_hip_colsum_f32", x2d.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1], x2d.stride(0),
-                 c_float(alpha))
+        """out += alpha * column sums of x2d, in a FIXED order (round 5: the atomic form made input_proj/bias the one gradient of
+        the step that differed between two runs, scripts/experiments/determinism_full.py)."""
+        rows, cols = x2d.shape
+        n = int(hip.load().detr_hip_colsum_det_scratch_floats(rows, cols))
+        scratch = self.buf(f"colsum:{rows}x{cols}", (n,))
+        hip.call("detr_hip_colsum_det_f32", x2d.data_ptr(), out.data_ptr(), rows, cols, x2d.stride(0), c_float(alpha),
+                 scratch.data_ptr(), n)
 
     def _ln_fwd(self, x, pfx, y, tag, add=None, y2=None, y16=None):
         """LayerNormalization(eps 1e-5) transformer.py:151-152; optional fused y2 = y + add[r % rows(add)] -- the

@@ -279,6 +279,12 @@ int detr_hip_layernorm_bwd(const detr_layernorm_desc *d, void *stream);
 /* out[c] += alpha * sum_r x[r*ld + c] (atomic) */
 int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha,
                         void *stream);
+/* The same sum in a FIXED order (round 5: the bias gradients of input_proj and of the heads -- detr.py:172-175, 192-203 -- were the one
+ * gradient of the step that differed between two runs, by float-atomic order): per-chunk partial sums into `scratch` (at least
+ * detr_hip_colsum_det_scratch_floats(rows, cols) floats), then one ordered pass over the chunks.  Two launches, no atomics. */
+int64_t detr_hip_colsum_det_scratch_floats(int64_t rows, int32_t cols);
+int detr_hip_colsum_det_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha, float *scratch,
+                            int64_t scratch_floats, void *stream);
 /* out[i] = x[i] + p[i % period]   (n, period multiples of 4) */
 int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n, int64_t period,
                            void *stream);

@@ -555,6 +555,16 @@ def test_small_elementwise(hip):
     out = torch.zeros(300, device=DEV)
     hip.call("detr_hip_colsum_f32", xd.data_ptr(), out.data_ptr(), 8400, 300, 300, ctypes.c_float(0.5))
     close(out, 0.5 * x.double().sum(0), rtol=2e-5, what="colsum")
+    # the deterministic form (round 5): fixed summation order -> two runs give the same bits, whatever the row count
+    n = int(hip.load().detr_hip_colsum_det_scratch_floats(8400, 300))
+    scr = torch.empty(n, device=DEV)
+    outs = []
+    for _ in range(3):
+        o2 = torch.full((300,), 0.25, device=DEV)
+        hip.call("detr_hip_colsum_det_f32", xd.data_ptr(), o2.data_ptr(), 8400, 300, 300, ctypes.c_float(0.5), scr.data_ptr(), n)
+        outs.append(o2.cpu())
+    close(outs[0], 0.25 + 0.5 * x.double().sum(0), rtol=2e-5, what="colsum_det")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     a, p = torch.randn(4, 50, 256), torch.randn(50, 256)
     ad, pd = g(a), g(p)
     o = torch.zeros(4, 50, 256, device=DEV)
