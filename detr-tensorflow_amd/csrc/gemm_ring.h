@@ -80,6 +80,10 @@ __device__ __forceinline__ void ring_wait_vmcnt() {
 __device__ __forceinline__ void ring_dma_piece(u32x4 rs, unsigned lds_addr, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
 }
+// the same request with the non-temporal hint (a stream that is read once: experiment DETR_HIP_RING_NT)
+__device__ __forceinline__ void ring_dma_piece_nt(u32x4 rs, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
+}
 __device__ __forceinline__ u32x4 ring_rsrc(const void *base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
     u32x4 r;
@@ -95,7 +99,10 @@ __device__ __forceinline__ unsigned ring_lds_addr(char *p) {      // LDS byte ad
 
 // K-contiguous operand [rows][k]: piece P = rows 8P .. 8P+7 of the stage image, lane (r = lane / 8, slot position lane % 8)
 // ES: bytes per element (2: bf16, 64-deep stages; 4: fp32, 32-deep stages -- a stage row is 128 bytes either way)
-template <int NP, int ES = 2>
+#ifndef DETR_RING_NT
+#define DETR_RING_NT 0          // 1: the A requests of gemm_ring_kernel carry the non-temporal hint (A/B builds, scripts/experiments)
+#endif
+template <int NP, int ES = 2, bool NT = false>
 struct RingDmaK {
     static constexpr int NPIECES = NP;
     const char *base;
@@ -129,7 +136,8 @@ struct RingDmaK {
     // which cut the stage into several basic blocks).
     __device__ __forceinline__ void issue_one(const int I, u32x4 rs, unsigned lds0, int img, int dump) const {
         const int off = dump + (in_img[I] & (img + lds_off[I] - dump));      // wave-uniform
-        ring_dma_piece(rs, lds0 + (unsigned)off, voff[I]);
+        if constexpr (NT) ring_dma_piece_nt(rs, lds0 + (unsigned)off, voff[I]);
+        else ring_dma_piece(rs, lds0 + (unsigned)off, voff[I]);
     }
     __device__ __forceinline__ void issue(int k0, int K, unsigned lds0, int img, int dump) const {
         const u32x4 rs = stage_rsrc(k0, K);
@@ -210,8 +218,8 @@ __device__ __forceinline__ bf16x8 ring_frag_tr(const char *img, int lane_off, in
 // NS - 1 ahead spread over the k-steps.  First form (measured, profiles/r05_ring_ablation.txt): every wave issued its 7 requests
 // right behind the barrier and multiplied afterwards -- all 8 waves of the workgroup are in the same phase, so nobody used the
 // matrix pipe while the requests were issued (60-180 cycles each) and nobody issued while it ran: loop time = MFMA part + request
-// part.  Now k-step kk carries the pieces [kk PW / 4, (kk + 1) PW / 4) between its MFMAs (sched_group_barrier pins the order)
-// and the fragments of k-step kk + 1 are read before the MFMAs of kk.
+// part.  Now k-step kk carries the pieces [kk PW / 4, (kk + 1) PW / 4) in front of its MFMAs and the fragments of k-step kk + 1 are read
+// before the MFMAs of kk (sched_group_barrier pins reads against MFMAs).
 template <int IDX, int P0, int P1, int NPA_, class LA, class LB>
 __device__ __forceinline__ void ring_issue_range(const LA &la, const LB &lb, u32x4 rsa, u32x4 rsb, unsigned lds0, int ia, int ib, int dump, int abl) {
     if constexpr (IDX < P1) {
@@ -274,13 +282,14 @@ __device__ __forceinline__ void ring_stage(const char *As, const char *Bs, f32x1
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
         }
         // pinned order: reads(0) reads(1) | MFMAs(0) + pieces | reads(2) | MFMAs(1) + pieces | reads(3) | MFMAs(2) + pieces | MFMAs(3) + pieces
+        // (the requests are inline assembly: `asm volatile` keeps them in source order between the k-steps, sched_group_barrier cannot see them)
         sgb_ds_read<2 * READS>();
-        sgb_mfma_block<MF, 0, (1 * PW) / 4 - (0 * PW) / 4, 0>();
+        sgb_mfma_block<MF, 0, 0, 0>();
         sgb_ds_read<READS>();
-        sgb_mfma_block<MF, 0, (2 * PW) / 4 - (1 * PW) / 4, 0>();
+        sgb_mfma_block<MF, 0, 0, 0>();
         sgb_ds_read<READS>();
-        sgb_mfma_block<MF, 0, (3 * PW) / 4 - (2 * PW) / 4, 0>();
-        sgb_mfma_block<MF, 0, (4 * PW) / 4 - (3 * PW) / 4, 0>();
+        sgb_mfma_block<MF, 0, 0, 0>();
+        sgb_mfma_block<MF, 0, 0, 0>();
         }
     }
 }
@@ -302,7 +311,7 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
     const int nmi = my_rows <= 0 ? 0 : (my_rows >= T::WTM ? TM : (my_rows + 31) >> 5);
 
     constexpr int NPA = TM, NPB = 2 * TN, PW = NPA + NPB;            // DMA pieces per wave and stage
-    RingDmaK<NPA> la;
+    RingDmaK<NPA, 2, DETR_RING_NT != 0> la;
     la.init(g.A, g.lda, m0, row_end, g.M, g.K, ra.a_rows8, lane, wave);
     using LB = typename std::conditional<BKC, RingDmaK<NPB>, RingDmaMN<BN>>::type;
     LB lb;

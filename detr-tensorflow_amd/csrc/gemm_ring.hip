@@ -47,7 +47,7 @@ bool gemm_ring_plan(int M, int N, int K, RingPlan &p) {
     if (force_ns == 2 || (force_ns == 3 && 3 * p.stage_bytes + 1024 <= 160 * 1024)) ns = force_ns;
     p.ns = ns;
     p.dump_off = p.ns * p.stage_bytes;
-    const int ring_bytes = p.dump_off + 1024;
+    const int ring_bytes = p.dump_off + (p.a_rows8 < 64 * p.tm ? 1024 : 0);      // (no piece lies past a full-capacity A image: no dump area)
     p.lds_bytes = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
     p.cost = 0.0;
     return p.lds_bytes <= 160 * 1024;

@@ -31,6 +31,12 @@ CASES = [
     ("ffn lin1 dgrad", 8400, 256, 2048, 0, dict(res=1, r32=1, c32=1)),
     ("l3 conv1 fwd b0 K512", 33600, 256, 512, 0, dict(bias=1, act=1)),
 ]
+if os.environ.get("RING_SMALL") == "1":          # the transformer's projection shapes (what bf16 twins of the LayerNorm outputs would put on the ring)
+    CASES = [("enc qk proj", 8400, 512, 256, 1, dict(bias=1, c32=1)), ("enc v proj", 8400, 256, 256, 1, dict(bias=1, c32=1)),
+             ("enc qkv dgrad", 8400, 256, 768, 0, dict(c32=1)), ("dec q proj", 800, 256, 256, 1, dict(bias=1, c32=1)),
+             ("dec qk proj", 800, 512, 256, 1, dict(bias=1, c32=1)), ("dec kv proj all", 8400, 3072, 256, 1, dict(bias=1, c32=1)),
+             ("dec ffn1", 800, 2048, 256, 1, dict(bias=1, act=1)), ("dec ffn2", 800, 256, 2048, 1, dict(bias=1, res=1, r32=1, c32=1)),
+             ("dec out proj", 800, 256, 256, 1, dict(bias=1, res=1, r32=1, c32=1)), ("enc out proj", 8400, 256, 256, 1, dict(bias=1, res=1, r32=1, c32=1))]
 only = os.environ.get("RING_CASES")
 if only:
     CASES = [c for c in CASES if any(o in c[0] for o in only.split(","))]
