@@ -110,6 +110,7 @@ enum TuneKey {
     T_RING_ROWS,         // row pitch forced (sweeps)
     T_RING_WTILE,        // ring weight gradient on 128 x 256 (1) / 256 x 128 (2) tiles (experiments)
     T_RING_ABLATE,       // timing experiments: RingArgs.ablate bits (results wrong when set)
+    T_CONV_DMA,          // 2: the LDS-DMA form of the halo 3x3 kernel (conv_halo_dma.h, round 5) is off; 3: its requests in front of the fragment reads
     T_COUNT
 };
 int tune(TuneKey k);

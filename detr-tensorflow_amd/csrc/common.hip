@@ -36,6 +36,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_RING_ROWS",
     "DETR_HIP_RING_WTILE",
     "DETR_HIP_RING_ABLATE",
+    "DETR_HIP_CONV_DMA",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {

@@ -36,6 +36,7 @@ struct ConvArgs {
 
 }  // namespace detr
 #include "conv_halo.h"
+#include "conv_halo_dma.h"
 namespace detr {
 
 // tap (kh, kw) of K-tile group t (t-th tap of the launch)
@@ -1345,13 +1346,15 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
                  "conv3x3: a bf16 kernel tensor needs compute = bf16, mode 0/1 and channel counts %% 32 == 0");
     a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
     const bool dgrad = mode == 1;
-    // stride-1 convs on bf16 tensors: the halo-staged kernel (conv_halo.h; DETR_HIP_CONV_HALO=2 = off).  With 4-row tiles it also
+    // stride-1 convs on bf16 tensors: the halo-staged kernel (conv_halo.h; DETR_HIP_CONV_HALO=2 = off), for 128-channel panels on 4-row tiles
+    // its LDS-DMA form (conv_halo_dma.h: bit-identical, 5-10 % faster; DETR_HIP_CONV_DMA=2 = off).  With 4-row tiles it also
     // takes the 512-channel convs of layer4 (25 x 42 maps: 92.9 -> 64.5 us forward, 103.2 -> 65.5 us input gradient against the
     // 64x64 implicit-GEMM tiles; with 8-row tiles -- 64 workgroups x 4 channel slices, half of every tile padding -- it lost).
     if (d->compute == 1 && d->stride == 1 && d->pad == 1 && a.w16 && a.x16 && e.c16 && a.Cs % 32 == 0 && a.Cd % 64 == 0 &&
         a.Cd <= 512 && (!d->mask || e.m16) && !d->residual && !d->scale && d->alpha == 1.0f && (d->act == 0 || d->act == 1) &&
         tune(T_CONV_HALO) != 2) {
-        if (a.Cd >= 128) { if (launch_conv_halo<128>(a, dgrad, s)) return -1; }
+        if (a.Cd >= 128 && a.Cd % 128 == 0 && tune(T_CONV_DMA) != 2 && tune(T_CONV_HALO) != 4) { if (launch_conv_halo_dma(a, dgrad, s)) return -1; }
+        else if (a.Cd >= 128) { if (launch_conv_halo<128>(a, dgrad, s)) return -1; }
         else if (launch_conv_halo<64>(a, dgrad, s)) return -1;
         DETR_LAUNCH_CHECK("conv3x3 (halo)");
         return 0;

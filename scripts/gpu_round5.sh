@@ -13,6 +13,7 @@ for w in "$@"; do
     kernels) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider > $OUT/kernels.log 2>&1; echo "kernels rc=$?" >> $OUT/summary.txt; tail -40 $OUT/kernels.log ;;
     kfast) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider -x -k "${KEXPR:-gemm}" > $OUT/kfast.log 2>&1; echo "kfast rc=$?" >> $OUT/summary.txt; tail -30 $OUT/kfast.log ;;
     kring) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider -k "ring" > $OUT/kring.log 2>&1; echo "kring rc=$?" >> $OUT/summary.txt; grep -E "passed|failed|FAILED|Error|assert " $OUT/kring.log | cut -c1-300 | tail -40 ;;
+    mconv) timeout 600 python scripts/micro_conv.py ${MCONV_ARGS:-DETR_HIP_CONV_DMA=2} > $OUT/mconv.log 2>&1; echo "mconv rc=$?" >> $OUT/summary.txt; grep -v amdgpu.ids $OUT/mconv.log | cut -c1-200 | tail -30 ;;
     mring) timeout 900 python scripts/micro_ring.py $OUT/mring.json ${MRING_ARGS:--} > $OUT/mring.log 2>&1; echo "mring rc=$?" >> $OUT/summary.txt; grep -v amdgpu.ids $OUT/mring.log | tail -30 ;;
     rsweep) timeout 1200 python scripts/experiments/ring_sweep.py $OUT/ring_sweep.json ${RSWEEP_ARGS:-} > $OUT/ring_sweep.log 2>&1; echo "rsweep rc=$?" >> $OUT/summary.txt; grep -v amdgpu.ids $OUT/ring_sweep.log | cut -c1-330 | tail -30 ;;
     model) timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_training.py tests/test_golden.py tests/test_gpu_dp.py -m gpu -q --no-header -p no:cacheprovider > $OUT/model.log 2>&1; echo "model rc=$?" >> $OUT/summary.txt; tail -60 $OUT/model.log ;;

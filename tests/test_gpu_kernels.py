@@ -26,7 +26,7 @@ def _reset_library_tuning():
     yield
     from detr_tf import _hip
     leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_DGRAD_S2_CLASSES", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64", "DETR_HIP_EPI_WIDE",
-                          "DETR_HIP_GEMM_RING", "DETR_HIP_RING_NS", "DETR_HIP_RING_BN", "DETR_HIP_RING_WGS", "DETR_HIP_RING_ROWS", "DETR_HIP_RING_ABLATE")
+                          "DETR_HIP_GEMM_RING", "DETR_HIP_RING_NS", "DETR_HIP_RING_BN", "DETR_HIP_RING_WGS", "DETR_HIP_RING_ROWS", "DETR_HIP_RING_ABLATE", "DETR_HIP_CONV_DMA")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1186,6 +1186,35 @@ def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C, rows):
         diff = (halo - tile).abs()
         assert float((diff > 0).double().mean()) < 5e-3, (what, float((diff > 0).double().mean()))
         assert float((diff / (tile.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7, what
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(1, 8, 32, 128, 128), (2, 25, 70, 256, 256), (3, 9, 31, 128, 256), (1, 13, 42, 512, 512), (2, 50, 84, 256, 128),
+                                         (1, 4, 33, 128, 128), (1, 1, 1, 128, 128), (2, 100, 167, 128, 128), (1, 5, 300, 64, 128), (1, 6, 40, 32, 384)])
+def test_conv3x3_halo_dma_is_bit_identical_to_the_register_staged_kernel(hip, N, H, W, Ci, Co):
+    """The LDS-DMA form of the halo kernel (csrc/conv_halo_dma.h, round 5: patch and kernel tiles requested straight into LDS) against
+    the register-staged kernel (DETR_HIP_CONV_DMA=2) on the same call: same tiles, same wave grid, same MFMA order per accumulator --
+    every output bit equal; forward (+ shift, ReLU) and input gradient (+ ReLU mask), ragged tile rows / columns, a one-pixel map, maps wider
+    than eight tiles, channel counts that differ between the two sides, and twice in a row (the pipeline's trailing requests land in LDS
+    the epilogue reuses: a missing wait shows as a run-to-run difference)."""
+    torch.manual_seed(N * 7 + H + W + Ci + Co)
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    x, dy = b16(torch.randn(N, H, W, Ci)), b16(torch.randn(N, H, W, Co))
+    w = b16(torch.randn(3, 3, Ci, Co) / (3 * Ci ** 0.5))
+    shift, msk = g(torch.randn(Co)), b16(torch.randn(N, H, W, Ci))
+    outs = {}
+    for mode in ("0", "2", "0b", "3"):                   # 3: the requests in front of the fragment reads (A/B form kept in the library)
+        hip.set_tuning("DETR_HIP_CONV_DMA", None if mode in ("0", "0b") else mode)
+        y = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
+        dx = torch.full((N, H, W, Ci), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.conv3x3(0, x, w, y, N, H, W, Ci, H, W, Co, 1, bias=shift, act=1, compute=1)
+        hip.conv3x3(1, dy, w, dx, N, H, W, Ci, H, W, Co, 1, mask=msk, compute=1)
+        torch.cuda.synchronize()
+        outs[mode] = (y.clone(), dx.clone())
+    hip.set_tuning("DETR_HIP_CONV_DMA", None)
+    assert float(outs["2"][0].float().abs().max()) > 0 and float(outs["2"][1].float().abs().max()) > 0
+    for k in ("0", "0b", "3"):
+        assert torch.equal(outs[k][0].view(torch.int16), outs["2"][0].view(torch.int16)), ("forward", k)
+        assert torch.equal(outs[k][1].view(torch.int16), outs["2"][1].view(torch.int16)), ("dgrad", k)
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 19, 45, 64), (1, 8, 64, 128), (2, 25, 70, 256), (1, 41, 33, 64), (1, 14, 42, 512), (3, 9, 31, 128)])
