@@ -44,6 +44,7 @@ struct RingArgs {
     int a_rows8;         // rows of the A stage image: tile_rows rounded up to a DMA piece (8 rows)
     int stage_bytes;     // a_rows8 * 128 + BN * 128
     int dump_off;        // byte offset of the 1 KB dump area behind the ring (pieces past the A image land there)
+    int trace_off;       // -DDETR_ABLATE=64 builds: byte offset of the 1 KB timeline area behind everything else (scripts/experiments/ring_trace.py)
     int ablate;          // timing experiments only (DETR_HIP_RING_ABLATE; results are WRONG with any bit set): 1 no fragment reads / MFMAs,
                          // 2 no A requests, 4 no B requests, 8 no epilogue, 16 no K loop at all
 };
@@ -62,6 +63,18 @@ int gemm_ring_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipSt
 // fp32 form (exact-f32 parity mode): plan for MFMA-bound work (whole 32-row blocks, per-CU balance), launch
 bool gemm_ring_f32_plan(int M, int N, int K, RingPlan &p);
 int gemm_ring_f32_launch(const GemmArgs &g, bool b_kcontig, const RingPlan &p, hipStream_t s);
+
+#if (DETR_ABLATE & 64) != 0
+// timeline experiment: wave 0 of three workgroups stamps s_memtime in front of the counted wait of every K stage, in front of the barrier and
+// behind it; [workgroup][40 stages x 3 + kernel start, loop start, loop end, kernel end, 100 MHz counter at kernel start / end]
+constexpr int RING_TR_STEPS = 40, RING_TR_N = RING_TR_STEPS * 3 + 6;
+extern __device__ long long ring_trace[3][RING_TR_N];
+#define RING_STAMP(idx) do { if (tr_w) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) trl[(idx)] = t_; } } while (0)
+#define RING_STAMP_STEP(s, k) do { if ((s) < RING_TR_STEPS) RING_STAMP((s) * 3 + (k)); } while (0)
+#else
+#define RING_STAMP(idx) do { } while (0)
+#define RING_STAMP_STEP(s, k) do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void ring_wait_vmcnt() {
@@ -99,6 +112,9 @@ __device__ __forceinline__ unsigned ring_lds_addr(char *p) {      // LDS byte ad
 
 // K-contiguous operand [rows][k]: piece P = rows 8P .. 8P+7 of the stage image, lane (r = lane / 8, slot position lane % 8)
 // ES: bytes per element (2: bf16, 64-deep stages; 4: fp32, 32-deep stages -- a stage row is 128 bytes either way)
+#ifndef DETR_RING_ISSUE_STEPS
+#define DETR_RING_ISSUE_STEPS 4   // k-steps of a stage (of 4) that carry its DMA requests (A/B builds: 1, 2, 3)
+#endif
 #ifndef DETR_RING_NT
 #define DETR_RING_NT 0          // 1: the A requests of gemm_ring_kernel carry the non-temporal hint (A/B builds, scripts/experiments)
 #endif
@@ -271,10 +287,13 @@ __device__ __forceinline__ void ring_stage(const char *As, const char *Bs, f32x1
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (kk + 1 < 4) read(kk + 1, (kk + 1) & 1);
-            if (kk == 0) ring_issue_range<0, (0 * PW) / 4, (1 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (kk == 1) ring_issue_range<0, (1 * PW) / 4, (2 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (kk == 2) ring_issue_range<0, (2 * PW) / 4, (3 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
-            if (kk == 3) ring_issue_range<0, (3 * PW) / 4, (4 * PW) / 4, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            // the stage's requests go out during its first RING_ISSUE_STEPS k-steps (a two-stage ring waits for ALL of them at the top of the
+            // next stage: what is requested in the last k-step has its whole latency exposed there -- profiles/r05_ring_trace.txt)
+            constexpr int IS = DETR_RING_ISSUE_STEPS;
+            if (kk == 0) ring_issue_range<0, (0 * PW) / IS, (1 * PW) / IS, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 1 && IS >= 2) ring_issue_range<0, (1 * PW) / IS, (IS >= 2 ? (2 * PW) / IS : PW), NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 2 && IS >= 3) ring_issue_range<0, (IS >= 3 ? (2 * PW) / IS : PW), (IS >= 3 ? (3 * PW) / IS : PW), NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
+            if (kk == 3 && IS >= 4) ring_issue_range<0, (IS >= 4 ? (3 * PW) / IS : PW), PW, NPA>(la, lb, rsa, rsb, lds0, na, nb, dump, 0);
 #pragma unroll
             for (int mi = 0; mi < NM; ++mi)
 #pragma unroll
@@ -346,6 +365,13 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
 
     const int nkt = g.K / RING_BK;
     const int abl = ra.ablate;                          // (kernel argument: uniform)
+#if (DETR_ABLATE & 64) != 0
+    long long *trl = reinterpret_cast<long long *>(ring_smem + ra.trace_off);
+    const int tr_sel = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1));
+    const bool tr_w = tr_sel >= 0 && wave == 0;
+    RING_STAMP(RING_TR_STEPS * 3 + 0);
+    if (tr_w && lane == 0) trl[RING_TR_STEPS * 3 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) {
         if (!(abl & 2)) la.issue(t * RING_BK, g.K, lds0, stage_a(t), dump);
@@ -358,9 +384,12 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
         constexpr bool ABL = decltype(ABLC)::value;
         int cur = 0, nxt = NS - 1;                      // ring slots of stage t and of stage t + NS - 1
         for (int t = 0; t < ((abl & 16) ? 0 : nkt); ++t) {
+            RING_STAMP_STEP(t, 0);
             ring_wait_vmcnt<(NS - 2) * PW>();
+            RING_STAMP_STEP(t, 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            RING_STAMP_STEP(t, 2);
             ring_stage<NM, TM, TN, true, BKC, ABL>(ring_smem + stage_a(cur), ring_smem + stage_b(cur), acc, a_lane, atr_unused, b_lane, btr, xo, la, lb,
                                              (t + NS - 1) * RING_BK, g.K, lds0, stage_a(nxt), stage_b(nxt), dump, abl);
             __builtin_amdgcn_sched_barrier(0);
@@ -373,11 +402,13 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
         if (abl) kloop_ab(NMC, std::integral_constant<bool, true>{});
         else kloop_ab(NMC, std::integral_constant<bool, false>{});
     };
+    RING_STAMP(RING_TR_STEPS * 3 + 1);
     if (nmi == TM) kloop(std::integral_constant<int, TM>{});
     else if (TM >= 2 && nmi == TM - 1) kloop(std::integral_constant<int, (TM >= 2 ? TM - 1 : 0)>{});
     else if (TM >= 3 && nmi == TM - 2) kloop(std::integral_constant<int, (TM >= 3 ? TM - 2 : 0)>{});
     else if (TM >= 4 && nmi == TM - 3) kloop(std::integral_constant<int, (TM >= 4 ? TM - 3 : 0)>{});
     else kloop(std::integral_constant<int, 0>{});
+    RING_STAMP(RING_TR_STEPS * 3 + 2);
     ring_wait_vmcnt<0>();                               // the trailing empty requests still write (zeros) into the ring:
     __syncthreads();                                    // nobody reuses the array (epilogue staging) before they have landed
     if (abl & 8) {
@@ -388,6 +419,15 @@ __device__ __forceinline__ void gemm_ring_body(const RingArgs &ra, const int id)
         return;
     }
     epilogue<BM, BN, WGM, WGN>(acc, reinterpret_cast<float *>(ring_smem), g.C, g.ldc, row_end, g.N, m0, n0, wm, wn, lane, wave, g.e);
+#if (DETR_ABLATE & 64) != 0
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    RING_STAMP(RING_TR_STEPS * 3 + 3);
+    if (tr_w && lane == 0) trl[RING_TR_STEPS * 3 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (tr_w) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < RING_TR_N; i += 64) ring_trace[tr_sel][i] = trl[i];
+    }
+#endif
 }
 
 template <int TM, int TN, bool BKC, int NS>

@@ -62,7 +62,7 @@ static int ring_launch_one(const RingArgs &ra, int wgs, int lds, hipStream_t s) 
         DETR_REQUIRE(e == hipSuccess, "gemm (ring): cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
         reserved = 160 * 1024;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<TM, TN, BKC, NS>), dim3((unsigned)wgs), dim3(RING_THREADS), (size_t)lds, s, ra);
+    hipLaunchKernelGGL((gemm_ring_kernel<TM, TN, BKC, NS>), dim3((unsigned)wgs), dim3(RING_THREADS), (size_t)lds + ((DETR_ABLATE & 64) != 0 ? 1024 : 0), s, ra);
     return 0;
 }
 
@@ -81,6 +81,7 @@ int gemm_ring_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStream_t 
     ra.a_rows8 = p.a_rows8;
     ra.stage_bytes = p.stage_bytes;
     ra.dump_off = p.dump_off;
+    ra.trace_off = p.lds_bytes;
     ra.ablate = tune(T_RING_ABLATE);
     int rc = -1;
     switch (p.tm * 2 + (p.tn - 1)) {
@@ -151,6 +152,7 @@ int gemm_ring_f32_launch(const GemmArgs &g, bool bk, const RingPlan &p, hipStrea
     ra.a_rows8 = p.a_rows8;
     ra.stage_bytes = p.stage_bytes;
     ra.dump_off = p.dump_off;
+    ra.trace_off = 0;
     ra.ablate = tune(T_RING_ABLATE);
     DETR_REQUIRE(p.tn == 1 && p.ns == 2 && p.tm >= 1 && p.tm <= 3, "gemm (ring, fp32): no instantiation for TM=%d TN=%d NS=%d", p.tm, p.tn, p.ns);
     if (p.tm == 1) return bk ? ring_f32_launch_one<1, true>(ra, p.wgs, p.lds_bytes, s) : ring_f32_launch_one<1, false>(ra, p.wgs, p.lds_bytes, s);
@@ -178,7 +180,7 @@ int gemm_ring_wgrad_launch(const GemmArgs &g, int bm, int bn, int split, hipStre
     ra.g = g;
     ra.g.tiles_m = cdiv(g.M, bm);
     ra.g.tiles_n = cdiv(g.N, bn);
-    ra.tile_rows = ra.a_rows8 = ra.stage_bytes = ra.dump_off = 0;
+    ra.tile_rows = ra.a_rows8 = ra.stage_bytes = ra.dump_off = ra.trace_off = 0;
     ra.ablate = tune(T_RING_ABLATE);
     const int wgs = ra.g.tiles_m * ra.g.tiles_n * split;
     if (bm == 128 && bn == 128) return tune(T_RING_NS) == 3 ? ring_wgrad_launch_one<2, 1, 3>(ra, wgs, s) : ring_wgrad_launch_one<2, 1, 4>(ra, wgs, s);
@@ -200,3 +202,10 @@ extern "C" int detr_hip_gemm_ring_plan(int32_t M, int32_t N, int32_t K, int32_t 
     }
     return 1;
 }
+
+#if (DETR_ABLATE & 64) != 0
+namespace detr { __device__ long long ring_trace[3][RING_TR_N]; }
+extern "C" int detr_hip_debug_ring_trace(long long *out) {       // experiment builds only: 3 x RING_TR_N stamps of the last ring GEMM launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(detr::ring_trace), sizeof(detr::ring_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
