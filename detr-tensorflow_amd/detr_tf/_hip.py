@@ -143,6 +143,8 @@ _SIGNATURES = {
     "detr_hip_set_u32x8": [c_void_p] + [ctypes.c_uint32] * 8 + [c_void_p],
     "detr_hip_colsum_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, c_void_p],
     "detr_hip_colsum_det_f32": [f32p, f32p, c_int64, c_int32, c_int64, c_float, f32p, c_int64, c_void_p],
+    "detr_hip_conv1x1_bwd_fused_bf16": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, f32p, c_int64, f32p, c_float,
+                                        c_int64, c_int32, c_int32, f32p, c_int64, c_void_p],
     "detr_hip_add_bcast_f32": [f32p, f32p, f32p, c_int64, c_int64, c_void_p],
     "detr_hip_add_f32": [f32p, f32p, f32p, c_int64, c_void_p],
     "detr_hip_sigmoid_bwd_f32": [f32p, f32p, f32p, c_int64, c_void_p],
@@ -166,13 +168,14 @@ _SIGNATURES = {
 # scratch sizing queries (return int64 bytes)
 _SIGNATURES_I64 = {
     "detr_hip_colsum_det_scratch_floats": [c_int64, c_int32],
+    "detr_hip_conv1x1_bwd_fused_workspace_floats": [c_int64],
     "detr_hip_workspace_bytes_gemm": [POINTER(GemmDesc)],
     "detr_hip_workspace_bytes_conv3x3": [POINTER(Conv3x3Desc), c_int32],
     "detr_hip_workspace_bytes_stem": [POINTER(StemDesc), c_int32],
     "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
-ABI_VERSION = 6
+ABI_VERSION = 7
 # order of detr_hip_struct_layout's `which`
 LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 
@@ -636,6 +639,31 @@ def linear_wgrad(*a, **kw):
 # ------------------------------------------------------------------------------------------
 # conv
 # ------------------------------------------------------------------------------------------
+def conv1x1_bwd_fused_scratch_floats(M):
+    return int(load().detr_hip_conv1x1_bwd_fused_workspace_floats(int(M)))
+
+
+def conv1x1_bwd_fused(dy, a, w, da, dw, scratch, *, scale=None, use_mask=True, alpha=1.0):
+    """Backward of a 64 -> 256 channel 1x1 convolution in one pass over dy (csrc/bwd_fused.hip; resnet_backbone.py:116-137):
+    da = (a > 0 if use_mask) * (dy @ w^T), dw += alpha * scale[n] * (a^T @ dy).  dy [M, 256], a [M, 64], w [64, 256], da [M, 64] bf16;
+    dw [64, 256], scale [256], scratch (conv1x1_bwd_fused_scratch_floats(M) floats) fp32."""
+    M = dy.shape[0]
+    for t, shape, dt in ((dy, (M, 256), torch.bfloat16), (a, (M, 64), torch.bfloat16), (w, (64, 256), torch.bfloat16), (da, (M, 64), torch.bfloat16),
+                         (dw, (64, 256), torch.float32)):
+        if tuple(t.shape) != shape or t.dtype != dt or t.stride(1) != 1:
+            raise ValueError(f"conv1x1_bwd_fused: operand of shape {tuple(t.shape)} / {t.dtype} / strides {t.stride()}, expected {shape} {dt}, unit column stride")
+    if scratch.dtype != torch.float32 or (scale is not None and (scale.dtype != torch.float32 or scale.numel() != 256)):
+        raise ValueError("conv1x1_bwd_fused: scratch / scale must be fp32 (scale: 256 entries)")
+    ev0 = PROFILER.begin() if PROFILER is not None else None
+    _check(load().detr_hip_conv1x1_bwd_fused_bf16(dy.data_ptr(), dy.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), da.data_ptr(),
+                                                  da.stride(0), 1 if use_mask else 0, dw.data_ptr(), dw.stride(0), ptr(scale), c_float(alpha), M,
+                                                  a.shape[1], dy.shape[1], scratch.data_ptr(), scratch.numel(), _stream()),
+           "detr_hip_conv1x1_bwd_fused_bf16")
+    if ev0 is not None:
+        PROFILER.end("conv1x1_bwd_fused", 4.0 * M * a.shape[1] * dy.shape[1], ev0, f"M{M} {a.shape[1]}->{dy.shape[1]}",
+                     float(2 * M * (dy.shape[1] + 2 * a.shape[1])))
+
+
 def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.0, scale=None, bias=None,
             residual=None, mask=None, act=0, split=0, compute=None, maskbits_out=None):
     d = Conv3x3Desc()

@@ -39,6 +39,7 @@ H16 = os.environ.get("DETR_HIP_H16", "1") != "0"
 DEFER_REDUCE = os.environ.get("DETR_HIP_DEFER_REDUCE", "1") != "0"     # queue the weight gradients' split-K reductions (A/B switch)
 WGRAD_STREAM = os.environ.get("DETR_HIP_WGRAD_STREAM", "1") != "0"      # backbone weight gradients on a second HIP stream (A/B switch)
 MASK_BITS = os.environ.get("DETR_HIP_MASK_BITS", "1") != "0"            # ReLU masks of the block outputs as bits (A/B switch, round 4)
+BWD_FUSED = os.environ.get("DETR_HIP_BWD_FUSED", "1") != "0"            # layer1: input + weight gradient of the 64 -> 256 1x1 convolutions in one pass over dY (round 5)
 # bf16 compute mode: the LayerNorm behind an attention out-projection (2, default) / also behind the FFN's second Linear (1) runs in
 # that GEMM's launch (detr_gemm_desc.ln_*, row-complete 32 x 256 tiles; same bits as the two launches); 0 = off.  Measured, same box:
 # 16.53 / 16.56 ms (2) vs 16.53 / 16.61 (0) vs 16.85 / 16.96 (1): the K = 256 launches absorb their LayerNorm at equal time (18 launches
@@ -912,15 +913,25 @@ class DetrEngine:
             strided = m["first"] and stride == 2
             wsd = self._bufs[f"{wk}:{n['down']}/kernel"] if m["first"] else None
             idg, idg_ready = g, None
+            # layer1's 64 -> 256 convolutions on bf16 tensors: g (274 MB at B = 8, 800 x 1333) is read once per convolution, not twice
+            fused_ok = BWD_FUSED and self.compute == 1 and adt == torch.bfloat16 and d2 == 256 and g.is_cuda
+            fuse3, fuse_down = fused_ok and d1 == 64, False
             if m["first"] and not (tfb and strided):
                 # data gradient of the projection shortcut: only the block's last GEMM reads it (as its residual operand)
                 idg = self.buf(f"scratch:idg:{cin}:{h}", (B, h, w, cin), adt)
+
+                # (layer1, bf16: the shortcut's input gradient and weight gradient in ONE pass over g -- csrc/bwd_fused.hip)
+                fuse_down = fused_ok and not strided and cin == 64
 
                 def dg_down(g=g, idg=idg):
                     if strided:
                         dxs = self.buf(f"scratch:dxs:{cin}:{ho}", (B, ho, wo, cin), adt)
                         hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, dxs, cin)
                         hip.call("detr_hip_subsample2_bwd_f32", dxs.data_ptr(), idg.data_ptr(), B, h, w, cin // f32c, ho, wo)
+                    elif fuse_down:
+                        hip.conv1x1_bwd_fused(g.view(M_out, d2), xs.view(M_out, cin), wsd.view(cin, d2), idg.view(M_out, cin), G[f"{n['down']}/kernel"].view(cin, d2),
+                                              self.buf(f"bwdfused:slabs:down:{M_out}", (hip.conv1x1_bwd_fused_scratch_floats(M_out),)),
+                                              scale=self.bn_scale[n["bnd"]], use_mask=False)
                     else:
                         hip.gemm(M_out, cin, d2, g, d2, 1, wsd, d2, 1, idg, cin)
                 on_side(dg_down)
@@ -928,15 +939,22 @@ class DetrEngine:
                     idg_ready = torch.cuda.Event()
                     idg_ready.record(wside)
 
-            def wg3(g=g):
-                self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
+            def wg3(g=g, fuse3=fuse3, fuse_down=fuse_down):
+                if not fuse3:
+                    self._wgrad(d1, d2, M_out, y2, d1, g, d2, G[f"{n['conv3']}/kernel"], d2, scale=self.bn_scale[n["bn3"]])
                 bias_grad(n["conv3"], n["bn3"], g, M_out, d2)
                 if m["first"]:
-                    self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{n['down']}/kernel"], d2, scale=self.bn_scale[n["bnd"]])
+                    if not fuse_down:
+                        self._wgrad(cin, d2, M_out, xs, cin, g, d2, G[f"{n['down']}/kernel"], d2, scale=self.bn_scale[n["bnd"]])
                     bias_grad(n["down"], n["bnd"], g, M_out, d2)
             on_side(wg3)
             dz2 = self.buf(f"scratch:dz2:{d1}:{ho}{par}", (B, ho, wo, d1), adt)
-            hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
+            if fuse3:
+                hip.conv1x1_bwd_fused(g.view(M_out, d2), y2.view(M_out, d1), ws3.view(d1, d2), dz2.view(M_out, d1), G[f"{n['conv3']}/kernel"].view(d1, d2),
+                                      self.buf(f"bwdfused:slabs:{M_out}", (hip.conv1x1_bwd_fused_scratch_floats(M_out),)),
+                                      scale=self.bn_scale[n["bn3"]], use_mask=True)
+            else:
+                hip.gemm(M_out, d1, d2, g, d2, 1, ws3, d2, 1, dz2, d1, mask=y2, ldmask=d1)
             # conv2 (3x3)
 
             def wg2():

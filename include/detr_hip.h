@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 6
+#define DETR_HIP_ABI_VERSION 7
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -285,6 +285,15 @@ int detr_hip_colsum_f32(const float *x, float *out, int64_t rows, int32_t cols, 
 int64_t detr_hip_colsum_det_scratch_floats(int64_t rows, int32_t cols);
 int detr_hip_colsum_det_f32(const float *x, float *out, int64_t rows, int32_t cols, int64_t ld, float alpha, float *scratch,
                             int64_t scratch_floats, void *stream);
+/* Backward of a bottleneck 1x1 convolution 64 -> 256 channels in ONE pass over dY (round 5; reference: resnet_backbone.py:116-137 -- conv3 and the
+ * projection shortcut of a BottleNeck -- and optimizers.py:110-120): da = (use_mask ? (a > 0) : 1) . (dY W^T) and dW += alpha * scale[n] * (a^T dY).
+ * dY [M][ldg] (d2 = 256 columns), a [M][lda] (d1 = 64 columns: weight-gradient operand AND ReLU mask), W [64][ldw] (256 columns contiguous),
+ * da [M][ldda] -- bf16; dW [64][lddw] fp32, scale [256] fp32 or NULL.  workspace: at least detr_hip_conv1x1_bwd_fused_workspace_floats(M) floats
+ * (one 64 x 256 partial per workgroup, summed in a fixed order).  da is bit-identical to detr_hip_gemm_f32 on the same operands. */
+int64_t detr_hip_conv1x1_bwd_fused_workspace_floats(int64_t M);
+int detr_hip_conv1x1_bwd_fused_bf16(const uint16_t *dy, int64_t ldg, const uint16_t *a, int64_t lda, const uint16_t *w, int64_t ldw, uint16_t *da,
+                                    int64_t ldda, int32_t use_mask, float *dw, int64_t lddw, const float *scale, float alpha, int64_t M, int32_t d1,
+                                    int32_t d2, float *workspace, int64_t workspace_floats, void *stream);
 /* out[i] = x[i] + p[i % period]   (n, period multiples of 4) */
 int detr_hip_add_bcast_f32(const float *x, const float *p, float *out, int64_t n, int64_t period,
                            void *stream);

@@ -1188,6 +1188,52 @@ def test_conv3x3_halo_staged_kernel(hip, monkeypatch, N, H, W, C, rows):
         assert float((diff / (tile.abs() + 1e-2 * scale)).max()) <= 2.0 ** -7, what
 
 
+@pytest.mark.parametrize("M,use_mask,pad", [(32, True, 0), (31, True, 0), (33, False, 0), (4096, True, 0), (4100, True, 8), (66800, True, 0), (66811, False, 16), (8, True, 0)])
+def test_conv1x1_backward_fused_reads_dy_once(hip, M, use_mask, pad):
+    """csrc/bwd_fused.hip (round 5): input gradient and weight gradient of a 64 -> 256 channel 1x1 convolution in one pass over dY.  The input
+    gradient must equal the streaming / tile GEMM on the same operands bit for bit (one fp32 accumulator per output, k ascending, one bf16
+    rounding); the weight gradient -- summed over per-workgroup slabs in a fixed order, scaled per output channel and ACCUMULATED into dW --
+    against fp64 on the same bf16 operands, against the split-K GEMM, and twice in a row (bit-identical: no atomics).  Ragged row counts
+    (the last strip is partial: out-of-range rows are zero operands and are not stored), padded leading dimensions, fewer strips than CUs."""
+    torch.manual_seed(M + pad)
+    d1, d2 = 64, 256
+    b16 = lambda t: g(t.float()).to(torch.bfloat16)
+    def padded(rows, cols):
+        full = b16(torch.randn(rows, cols + pad))
+        return full[:, :cols]
+    dy, a, w = padded(M, d2), padded(M, d1), padded(d1, d2)
+    scale = g(torch.rand(d2) + 0.5)
+    dw0 = g(torch.randn(d1, d2))
+    scratch = torch.empty(hip.conv1x1_bwd_fused_scratch_floats(M), device=DEV)
+    outs = []
+    for _ in range(2):
+        da = torch.full((M + 2, d1), 7.0, device=DEV, dtype=torch.bfloat16)            # two guard rows behind the tensor
+        dw = dw0.clone()
+        hip.conv1x1_bwd_fused(dy, a, w, da[:M], dw, scratch, scale=scale, use_mask=use_mask, alpha=0.5)
+        torch.cuda.synchronize()
+        assert float(da[M:].float().min()) == 7.0 and float(da[M:].float().max()) == 7.0, "rows past M were written"
+        outs.append((da[:M].clone(), dw.clone()))
+    nda = int((outs[0][0].view(torch.int16) != outs[1][0].view(torch.int16)).sum())
+    ndw = int((outs[0][1] != outs[1][1]).sum())
+    assert nda == 0 and ndw == 0, f"run-to-run: {nda} input-gradient and {ndw} weight-gradient entries differ"
+    # the two-launch form
+    da_ref = torch.empty(M, d1, device=DEV, dtype=torch.bfloat16)
+    hip.gemm(M, d1, d2, dy, dy.stride(0), 1, w, w.stride(0), 1, da_ref, d1, mask=(a if use_mask else None), ldmask=(a.stride(0) if use_mask else 0), compute=1)
+    dw_ref = dw0.clone()
+    sk = hip.pick_split_k(d1, d2, M)
+    if sk > 1:
+        hip.gemm(d1, d2, M, a, a.stride(0), 0, dy, dy.stride(0), 0, dw_ref, d2, alpha=0.5, scale=scale, split_k=sk, compute=1)
+    else:
+        hip.gemm(d1, d2, M, a, a.stride(0), 0, dy, dy.stride(0), 0, dw_ref, d2, alpha=0.5, scale=scale, residual=dw_ref, ldr=d2, compute=1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0].view(torch.int16), da_ref.view(torch.int16)), "input gradient differs from the GEMM's"
+    a64, dy64 = a.double().cpu(), dy.double().cpu()
+    want = dw0.double().cpu() + 0.5 * scale.double().cpu()[None, :] * (a64.t() @ dy64)
+    tol = 2e-6 * float((a64.abs().t() @ dy64.abs()).max()) + 1e-6
+    assert float((outs[0][1].double().cpu() - want).abs().max()) <= tol
+    assert float((dw_ref.double().cpu() - want).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co", [(1, 8, 32, 128, 128), (2, 25, 70, 256, 256), (3, 9, 31, 128, 256), (1, 13, 42, 512, 512), (2, 50, 84, 256, 128),
                                          (1, 4, 33, 128, 128), (1, 1, 1, 128, 128), (2, 100, 167, 128, 128), (1, 5, 300, 64, 128), (1, 6, 40, 32, 384)])
 def test_conv3x3_halo_dma_is_bit_identical_to_the_register_staged_kernel(hip, N, H, W, Ci, Co):
