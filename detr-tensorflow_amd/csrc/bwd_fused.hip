@@ -29,7 +29,13 @@
 
 namespace detr {
 
-constexpr int BF_D1 = 64, BF_D2 = 256, BF_SR = 32, BF_NS = 4;
+#ifndef DETR_BF_NS
+#define DETR_BF_NS 4
+#endif
+#ifndef DETR_BF_NT
+#define DETR_BF_NT 0           // 1: the strip requests carry the non-temporal hint (A/B builds)
+#endif
+constexpr int BF_D1 = 64, BF_D2 = 256, BF_SR = 32, BF_NS = DETR_BF_NS;
 constexpr int BF_WAVES = 6, BF_THREADS = 64 * BF_WAVES;
 constexpr int BF_W_BYTES = BF_D1 * BF_D2 * 2;                    // 32 KB
 constexpr int BF_G_BYTES = BF_SR * BF_D2 * 2, BF_Y_BYTES = BF_SR * BF_D1 * 2, BF_STAGE = BF_G_BYTES + BF_Y_BYTES;      // 16 + 4 KB
@@ -83,8 +89,12 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             const u32x4 ry = ring_rsrc(reinterpret_cast<const char *>(a.y) + row0 * a.ldy * 2, (unsigned)(yb > 0xFFFFFFFFull ? 0xFFFFFFFFull : yb));
             const unsigned base = lds0 + (unsigned)(BF_OFF_RING + stage * BF_STAGE);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ring_dma_piece(rg, base + (unsigned)((wave + 4 * i) * 1024), gvoff[i]);
-            ring_dma_piece(ry, base + (unsigned)(BF_G_BYTES + wave * 1024), yvoff);
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (DETR_BF_NT != 0) ring_dma_piece_nt(rg, base + (unsigned)((wave + 4 * i) * 1024), gvoff[i]);
+                else ring_dma_piece(rg, base + (unsigned)((wave + 4 * i) * 1024), gvoff[i]);
+            }
+            if constexpr (DETR_BF_NT != 0) ring_dma_piece_nt(ry, base + (unsigned)(BF_G_BYTES + wave * 1024), yvoff);
+            else ring_dma_piece(ry, base + (unsigned)(BF_G_BYTES + wave * 1024), yvoff);
         };
         // W image: row n = 512 bytes, chunk c at position c ^ (n & 15); piece = 2 rows, lane: row 2 P + lane / 32, slot position lane & 31
         {
@@ -124,12 +134,12 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(bf16x8, v);
         };
+        int stage = 0, nxt = BF_NS - 1;                  // ring slots of strip s and of strip s + NS - 1
         for (int s = s0; s < s1; ++s) {
             ring_wait_vmcnt<(BF_NS - 2) * BF_PW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const int stage = (s - s0) & (BF_NS - 1);
-            issue_strip(s + BF_NS - 1, (stage + BF_NS - 1) & (BF_NS - 1));
+            issue_strip(s + BF_NS - 1, nxt);
             const char *st = bf_smem + BF_OFF_RING + stage * BF_STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -144,6 +154,8 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
                     for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[mb], fg[nb], acc[mb][nb], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            stage = (stage + 1 == BF_NS) ? 0 : stage + 1;
+            nxt = (nxt + 1 == BF_NS) ? 0 : nxt + 1;
         }
         ring_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                    // (pairs with the other role's last barrier)
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
         const int grow = (l31 >> 2) * 2048 + (l31 & 3) * 256;       // dY row fragment: piece pair of row group l31 >> 2, row l31 & 3
         const int gsw = (4 * (l31 & 3)) ^ (l31 >> 3);
         unsigned short *dz = a.dz;
+        int stage = 0;
         auto store_strip = [&](const int s) {        // rows 16 d .. 16 d + 15 of strip s out of staging buffer s & 1: two passes of 8 rows x 128 bytes
             const char *sb = bf_smem + BF_OFF_ST + (s & 1) * (BF_SR * BF_ST_PITCH);
 #pragma unroll
@@ -181,8 +194,8 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s > s0) store_strip(s - 1);
-            const int stage = (s - s0) & (BF_NS - 1);
             const char *st = bf_smem + BF_OFF_RING + stage * BF_STAGE;
+            stage = (stage + 1 == BF_NS) ? 0 : stage + 1;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;

@@ -17,7 +17,8 @@ dev = "cuda"
 hip.ensure_workspace(dev)
 hip.COMPUTE_BF16 = 1
 bf = lambda *s: (torch.randn(*s, device=dev) * 0.1).to(torch.bfloat16)
-for (M, d1, d2) in [(534400, 64, 256), (133600, 128, 512)]:
+FUSED_ONLY = os.environ.get("PROBE_FUSED_ONLY") == "1"
+for (M, d1, d2) in ([(534400, 64, 256)] if FUSED_ONLY else [(534400, 64, 256), (133600, 128, 512)]):
     g, y2, w3 = bf(M, d2), bf(M, d1), bf(d1, d2)
     dz2 = torch.empty(M, d1, device=dev, dtype=torch.bfloat16)
     G = torch.zeros(d1, d2, device=dev)
@@ -53,7 +54,7 @@ for (M, d1, d2) in [(534400, 64, 256), (133600, 128, 512)]:
 
     only_d = timed(lambda: hip.gemm(M, d1, d2, g, d2, 1, w3, d2, 1, dz2, d1, mask=y2, ldmask=d1))
     print(f"M{M} {d1}->{d2}: input gradient alone {only_d:.1f} us; g is {M * d2 * 2 / 1e6:.0f} MB")
-    for chunks in (1, 2, 4, 8, 16):
+    for chunks in (() if FUSED_ONLY else (1, 2, 4, 8, 16)):
         print(f"   pair in {chunks:2d} chunk(s): {timed(lambda: run(chunks)):.1f} us")
     if (d1, d2) == (64, 256):
         scratch = torch.empty(hip.conv1x1_bwd_fused_scratch_floats(M), device=dev)
