@@ -185,6 +185,43 @@ def test_second_launch_stream_does_not_change_the_step(hip, small, monkeypatch):
         model.engine.compute = 0
 
 
+def test_fused_1x1_backward_equals_the_two_launch_form(hip, small, monkeypatch):
+    """engine.BWD_FUSED (default on, bf16 step): layer1's 64 -> 256 1x1 convolutions (conv3 of every block, the projection shortcut of block 0)
+    run their backward as ONE kernel that reads dY once (csrc/bwd_fused.hip).  Its input gradient is bit-identical to the GEMM's, so every
+    gradient of the step that is not one of those four kernels' own weight gradients must equal the two-launch step BIT FOR BIT; the four weight
+    gradients are the same sums in another (fixed) order: equal to 1e-5 of their norm, and bit-identical between two fused runs."""
+    from detr_tf import engine as E, training
+    from detr_tf.optimizers import setup_optimizers
+    model = small["model"]
+    opt = setup_optimizers(model, small["cfg"])
+    assert E.BWD_FUSED
+    try:
+        model.engine.compute = 1
+
+        def run():
+            out, total, _, _ = training.run_train_step(model, small["images"], small["t_bbox"], small["t_class"], opt, small["cfg"])
+            torch.cuda.synchronize()
+            return {k: v.detach().clone() for k, v in model.engine.P.gviews.items()}
+        monkeypatch.setattr(E, "BWD_FUSED", False)
+        g_pair = run()
+        monkeypatch.setattr(E, "BWD_FUSED", True)
+        g_fused = [run() for _ in range(3)]
+        differing = []
+        for name, ref in g_pair.items():
+            for rep, gf in enumerate(g_fused):
+                assert torch.equal(gf[name], g_fused[0][name]), f"{name}: fused run {rep} differs from fused run 0"
+            if not torch.equal(g_fused[0][name], ref):
+                differing.append(name)
+                err = float((g_fused[0][name].double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+                assert err < 1e-5, (name, err)
+        # exactly the weight gradients of the fused launches may differ: kernels with 64 input and 256 output channels in the first stage
+        assert 1 <= len(differing) <= 4, differing
+        for name in differing:
+            assert name.endswith("/kernel") and tuple(g_pair[name].shape[-2:]) == (64, 256), (name, tuple(g_pair[name].shape))
+    finally:
+        model.engine.compute = 0
+
+
 def test_backward_small_shapes_vs_oracle(hip):
     """Same check on the reduced model / tiny feature map (3x4 tokens) used by the train-step test:
     exercises the partial-tile and split-free code paths of every backward kernel."""

@@ -257,6 +257,31 @@ def test_workspace_bytes_queries_and_tuning_reload():
     assert lib.detr_hip_workspace_bytes_layernorm(byref(ln)) == 512 * 2 * 256 * 4
 
 
+def test_fused_1x1_backward_sizing_and_rejections():
+    """detr_hip_conv1x1_bwd_fused_bf16 (ABI 7): the workspace query is host arithmetic (one 64 x 256 slab per workgroup, at most 256), and every
+    argument the kernel is not built for is REJECTED before anything is launched (no GPU needed: the pointers below are never dereferenced) --
+    the caller keeps the two-launch form for those."""
+    import ctypes
+    _hip, lib = _hip_lib()
+    q = lib.detr_hip_conv1x1_bwd_fused_workspace_floats
+    assert q(534400) == 256 * 64 * 256 and q(32) == 64 * 256 and q(33) == 2 * 64 * 256 and q(8191) == 256 * 64 * 256
+    f = lib.detr_hip_conv1x1_bwd_fused_bf16
+    P = 1 << 20                                      # "pointers": 16-byte aligned, never touched
+    ok = dict(dy=P, ldg=256, a=P, lda=64, w=P, ldw=256, da=P, ldda=64, use_mask=1, dw=P, lddw=256, scale=None, alpha=1.0, M=4096, d1=64, d2=256,
+              ws=P, wsf=256 * 64 * 256, stream=None)
+
+    def call(**kw):
+        v = dict(ok, **kw)
+        return f(v["dy"], v["ldg"], v["a"], v["lda"], v["w"], v["ldw"], v["da"], v["ldda"], v["use_mask"], v["dw"], v["lddw"], v["scale"],
+                 ctypes.c_float(v["alpha"]), v["M"], v["d1"], v["d2"], v["ws"], v["wsf"], v["stream"])
+    for bad, what in ((dict(d1=128), "built for"), (dict(d2=512), "built for"), (dict(ldg=255), "leading"), (dict(lda=60), "leading"),
+                      (dict(dy=P + 2), "alignment"), (dict(ws=P + 4), "alignment"), (dict(wsf=64 * 256 * 127), "workspace"), (dict(M=0), "bad operands"),
+                      (dict(dw=None), "bad operands"), (dict(M=1 << 24, wsf=1 << 40), "descriptor")):
+        assert call(**bad) != 0, bad
+        msg = lib.detr_hip_last_error().decode()
+        assert what in msg, (bad, msg)
+
+
 def test_host_side_of_the_c_abi_under_address_sanitizer():
     """SURVEY section 5 stance: the host side of the boundary (descriptor validation, planning, scratch-size queries, layout
     self-check) built with -fsanitize=address and driven by tests/host_abi_check.c (plain C, no GPU): every rejection path
