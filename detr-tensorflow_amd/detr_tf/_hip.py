@@ -686,7 +686,9 @@ def conv3x3(mode, x, w, y, N, Hi, Wi, Ci, Ho, Wo, Co, stride, *, pad=1, alpha=1.
     _check(load().detr_hip_conv3x3_f32(byref(d), mode, _stream()), "detr_hip_conv3x3_f32")
     if ev0 is not None:
         rows = N * (Hi * Wi if mode == 1 else Ho * Wo)
-        PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * rows * 9 * Ci * Co, ev0,
+        # FLOPs: every mode performs the forward convolution's multiply-adds, N Ho Wo 9 Ci Co (until round 5 the input gradient was counted over its
+        # OUTPUT rows N Hi Wi: four times too many for the three stride-2 convolutions, which inflated conv3x3_dgrad's rate by 1.56x)
+        PROFILER.end(("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")[mode], 2.0 * (N * Ho * Wo) * 9 * Ci * Co, ev0,
                      f"N{N} {Hi}x{Wi}x{Ci}->{Ho}x{Wo}x{Co} s{stride}",
                      float(x.element_size() * (N * Hi * Wi * Ci if mode != 1 else N * Ho * Wo * Co)
                            + (w.element_size() * 9 * Ci * Co if mode != 2 else w.element_size() * N * Ho * Wo * Co)
