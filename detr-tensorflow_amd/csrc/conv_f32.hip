@@ -644,20 +644,35 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 3 : 1) void 
 // cut into [4 px][16 ch] sub-blocks of 128 B) and every tap reads its MFMA fragments with ds_read_b64_tr_b16 at a
 // shifted pixel row -- the per-tap kernel above re-loads x and dy for every tap (4.2x the LDS fill per MFMA).
 // ------------------------------------------------------------------------------------------------
-constexpr int WF_ROW = 9 * 4 * 64;        // shorts per patch row: 9 pixel groups x 4 ci blocks x [4][16]
+// STR = 2 (round 5; bf16 storage only): the stride-2 convolutions of layer2-4 (resnet_backbone.py:123-126 with strides 2) took the per-tap kernel
+// until now (100 us per launch against 63 for the same FLOPs at stride 1).  A unit of 32 output pixels reads input columns 2 j + kw - 1: the
+// patch is 3 rows x 65 pixels, staged DE-INTERLEAVED -- even patch columns in slots 0..32, odd ones in slots 33..65 -- so that the tap kw of
+// output pixel j sits at slot (kw & 1) * 33 + j + (kw >> 1): consecutive slots for consecutive j, the same transpose-read fragments as at stride 1.
+template <int STR>
+struct WgradFusedGeom {
+    static constexpr int PC = STR == 1 ? 34 : 66;                 // pixel slots of a patch row (stride 2: 33 even + 33 odd columns, the last odd one unused)
+    static constexpr int NG = (PC + 3) / 4;                       // pixel groups of 4
+    static constexpr int ROW = NG * 4 * 64;                       // shorts per patch row: pixel groups x 4 ci blocks x [4][16]
+    __device__ static constexpr int slot(int c) { return STR == 1 ? c : (c & 1) * 33 + (c >> 1); }
+};
+constexpr int WF_ROW = WgradFusedGeom<1>::ROW;
 
+template <int STR>
 struct WgradFusedSmem {
-    unsigned short X[2][3 * WF_ROW];      // haloed input patch
+    unsigned short X[2][3 * WgradFusedGeom<STR>::ROW];      // haloed input patch
     unsigned short D[2][32 * 64];         // dy tile (transpose-read image, BMN = 64)
 };
 
-template <bool S16>
+template <bool S16, int STR = 1>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kernel(ConvWgradArgs a, int units_per_split,
                                                                                  int chunks) {
-    constexpr int SMEM = (int)sizeof(WgradFusedSmem) > SmemBytes<64, 64, 2>::VALUE ? (int)sizeof(WgradFusedSmem)
-                                                                                    : SmemBytes<64, 64, 2>::VALUE;
+    static_assert(STR == 1 || S16, "the stride-2 form exists for bf16-stored tensors");
+    using WG = WgradFusedGeom<STR>;
+    constexpr int WF_ROW = WG::ROW, PC = WG::PC, NPP = 3 * PC;
+    constexpr int SMEM = (int)sizeof(WgradFusedSmem<STR>) > SmemBytes<64, 64, 2>::VALUE ? (int)sizeof(WgradFusedSmem<STR>)
+                                                                                         : SmemBytes<64, 64, 2>::VALUE;
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM];
-    WgradFusedSmem &sm = *reinterpret_cast<WgradFusedSmem *>(smem_raw);
+    WgradFusedSmem<STR> &sm = *reinterpret_cast<WgradFusedSmem<STR> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tn = blockIdx.x % a.tiles_n, tm = blockIdx.x / a.tiles_n;
@@ -679,7 +694,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
     // S16: 16-byte granules (8 channels of one pixel; two adjacent 8-byte units of the transpose-read images) -- 5 requests
     // and 5 ds_write_b128 per thread and unit instead of 9 + 9 eight-byte ones; fp32 storage: float4 = 4 channels
     typedef typename std::conditional<S16, uint4, float4>::type Reg;
-    constexpr int NRX = S16 ? 4 : 7, NRD = S16 ? 1 : 2;
+    constexpr int NRX = (NPP * (S16 ? 8 : 16) + 255) / 256, NRD = S16 ? 1 : 2;      // stride 1: 4 (bf16) / 7 (fp32); stride 2: 7
     // two register sets: the operand pipeline is two units deep (see gemm_bf16c_body); requests past u_end take the
     // out-of-range offset and every unit is stored, so that the vmcnt waits in front of the LDS stores stay exact
     Reg rx0[NRX], rd0[NRD], rx1[NRX], rd1[NRD];
@@ -708,14 +723,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             if constexpr (S16) rd[i] = ds.ld16(ok ? off : BUF_OOB);
             else rd[i] = ds.ld4(ok ? off : BUF_OOB);
         }
-        // input patch: slot v -> (patch pixel pp in [0, 102), channel granule): S16 8 granules of 8 channels, fp32 16 of 4
+        // input patch: slot v -> (patch pixel pp in [0, 3 PC), channel granule): S16 8 granules of 8 channels, fp32 16 of 4
 #pragma unroll
         for (int i = 0; i < NRX; ++i) {
             const int v = tid + 256 * i;
             const int pp = S16 ? v >> 3 : v >> 4, c4 = S16 ? 2 * (v & 7) : v & 15;
-            const int kh = pp / 34, c = pp - kh * 34;
-            const int hi = ho - 1 + kh, wi = wo0 - 1 + c;
-            const bool ok = live && pp < 102 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+            const int kh = pp / PC, c = pp - kh * PC;
+            const int hi = STR * ho - 1 + kh, wi = STR * wo0 - 1 + c;
+            const bool ok = live && pp < NPP && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
             const unsigned off = ((unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.Ci + (unsigned)(ci0 + 4 * c4)) * (S16 ? 2u : 4u);
             if constexpr (S16) rx[i] = xs.ld16(ok ? off : BUF_OOB);
             else rx[i] = xs.ld4(ok ? off : BUF_OOB);
@@ -731,8 +746,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
         for (int i = 0; i < NRX; ++i) {
             const int v = tid + 256 * i;
             const int pp = S16 ? v >> 3 : v >> 4, c4 = S16 ? 2 * (v & 7) : v & 15;
-            if (pp < 102) {
-                const int kh = pp / 34, c = pp - kh * 34;
+            if (pp < NPP) {
+                const int kh = pp / PC, c = WG::slot(pp - kh * PC);
                 const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (c & 3) * 16 + (c4 & 3) * 4;
                 if constexpr (S16) *reinterpret_cast<uint4 *>(&sm.X[buf][o]) = rx[i];
                 else *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int c = jbase + kw + 4 * h;
+                const int c = STR == 1 ? jbase + kw + 4 * h : (kw & 1) * 33 + jbase + (kw >> 1) + 4 * h;
                 xo[s2][kw][h] = ((c >> 2) * 4 + cib) * 64 + (c & 3) * 16 + (t16 & 3) * 4;
             }
         dofs[s2] = ((4 * s2 + 2 * (g >> 1)) * 4 + 2 * wn + (g & 1)) * 64 + t16 * 4;
@@ -1228,7 +1243,8 @@ static void launch_wgrad_fused(const ConvWgradArgs &a0, int split, float *ws, lo
         a.e.atomic = 1;   // accumulate onto dw (split == 1, or the atomic fallback without a workspace)
     }
     dim3 grid((unsigned)tiles, 1, (unsigned)split), block(GEMM_THREADS);
-    if (a.s16) hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<true>, grid, block, 0, s, a, ups, chunks);
+    if (a.stride == 2) hipLaunchKernelGGL((conv3x3_wgrad_fused_bf16_kernel<true, 2>), grid, block, 0, s, a, ups, chunks);
+    else if (a.s16) hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<true>, grid, block, 0, s, a, ups, chunks);
     else hipLaunchKernelGGL(conv3x3_wgrad_fused_bf16_kernel<false>, grid, block, 0, s, a, ups, chunks);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s, nullptr, nullptr, 1.0f,
                                       ts ? 64 : 0, ts ? 64 : 0, a.tiles_n);
@@ -1240,7 +1256,13 @@ using namespace detr;
 
 static bool wgrad_is_fused(const detr_conv3x3_desc *d) {
     const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
-    return bf && d->stride == 1 && d->pad == 1 && d->Ci % 64 == 0 && d->Co % 64 == 0 && tune(T_WGRAD_FUSED) != 2;
+    // stride 2 (round 5): bf16-stored tensors only, and only up to 128 channels -- measured (scripts/micro_conv.py, profiles/r05_micro_conv_dma.txt;
+    // nine-tap | per-tap, us): 200x334x128 -> 100x167 100.1 | 115.9, 100x167x256 -> 50x84 96.7 | 90.5, 50x84x512 -> 25x42 116.0 | 105.0: the stride-2
+    // patch is twice the bytes per MFMA of the stride-1 one and every (ci, co) tile re-fetches it.  DETR_HIP_WGRAD_FUSED = 3: per-tap kernel for all
+    // stride-2 convolutions, 4: nine-tap kernel for all (A/B).
+    const int fmode = tune(T_WGRAD_FUSED);
+    const bool s_ok = d->stride == 1 || (d->stride == 2 && d->x_dtype == 1 && d->w_dtype == 1 && fmode != 3 && (fmode == 4 || (d->Ci <= 128 && d->Co <= 128)));
+    return bf && s_ok && d->pad == 1 && d->Ci % 64 == 0 && d->Co % 64 == 0 && tune(T_WGRAD_FUSED) != 2;
 }
 
 extern "C" int64_t detr_hip_workspace_bytes_conv3x3(const detr_conv3x3_desc *d, int32_t mode) {

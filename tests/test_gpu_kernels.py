@@ -26,7 +26,7 @@ def _reset_library_tuning():
     yield
     from detr_tf import _hip
     leaked = [k for k in ("DETR_HIP_STEM_ROWS", "DETR_HIP_CONV_HALO", "DETR_HIP_DGRAD_S2_CLASSES", "DETR_HIP_GEMM_STREAM", "DETR_HIP_GEMM_TILE", "DETR_HIP_ATTN_SPLIT", "DETR_HIP_GEMM_K64", "DETR_HIP_EPI_WIDE",
-                          "DETR_HIP_GEMM_RING", "DETR_HIP_RING_NS", "DETR_HIP_RING_BN", "DETR_HIP_RING_WGS", "DETR_HIP_RING_ROWS", "DETR_HIP_RING_ABLATE", "DETR_HIP_CONV_DMA")
+                          "DETR_HIP_GEMM_RING", "DETR_HIP_RING_NS", "DETR_HIP_RING_BN", "DETR_HIP_RING_WGS", "DETR_HIP_RING_ROWS", "DETR_HIP_RING_ABLATE", "DETR_HIP_CONV_DMA", "DETR_HIP_WGRAD_FUSED")
               if k in os.environ]
     for k in leaked:
         _hip.set_tuning(k, None)
@@ -1106,7 +1106,7 @@ def test_gemm_bf16_activation_storage(hip, M, N, K, bk):
     close(outs[0], dy.double().t() @ x.double(), rtol=5e-5, what="bf16-storage wgrad")
 
 
-@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 25, 42, 256, 256, 1)])
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 13, 17, 64, 64, 1), (1, 20, 27, 128, 128, 2), (2, 25, 42, 256, 256, 1), (2, 21, 67, 64, 128, 2), (1, 9, 131, 256, 64, 2)])
 def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stride):
     """conv3x3 forward / dgrad / wgrad and the stem max pooling on bf16-STORED tensors: bit-identical to bf16(result of the
     fp32-storage kernels) on the same (bf16-representable) values; weight gradients (fp32) identical."""
@@ -1129,11 +1129,22 @@ def test_conv3x3_bf16_activation_storage(hip, monkeypatch, N, H, W, Ci, Co, stri
     hip.conv3x3(1, b16(dy), w16, dx16, N, H, W, Ci, Ho, Wo, Co, stride, mask=b16(msk), compute=1)
     assert torch.equal(dx16, b16(dx32)) and float(dx32.abs().max()) > 0
     dws = []
+    if stride == 2:
+        hip.set_tuning("DETR_HIP_WGRAD_FUSED", "4")      # the nine-tap kernel's stride-2 form whatever the channel count
     for cast in (lambda t: t, b16):
         dw = torch.zeros(3, 3, Ci, Co, device=DEV)
         hip.conv3x3(2, cast(x), cast(dy), dw, N, H, W, Ci, Ho, Wo, Co, stride, split=5, compute=1)
         dws.append(dw)
-    assert torch.equal(dws[0], dws[1]) and float(dws[0].abs().max()) > 0
+    # stride 1: both storage types take the nine-tap kernel (same sums, same order: identical bits).  Stride 2 (round 5): bf16-stored tensors take the
+    # nine-tap kernel's stride-2 form, fp32-stored ones the per-tap kernel -- the same products summed in another order; both against fp64
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), stride=stride, padding=1)
+    ref = ref.permute(2, 3, 1, 0)                    # (Co, Ci, kh, kw) -> (kh, kw, Ci, Co)
+    scale = float(ref.abs().max())
+    for dw in dws:
+        assert float((dw.double().cpu() - ref).abs().max()) <= 2e-5 * scale, float((dw.double().cpu() - ref).abs().max()) / scale
+    if stride == 1:
+        assert torch.equal(dws[0], dws[1])
+    assert float(dws[0].abs().max()) > 0
     if stride == 1 and Ci == 64:          # the stem pooling pair on the same tensors
         C = Ci
         H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
