@@ -32,6 +32,7 @@ struct ConvArgs {
     // all four parity classes in ONE launch of the halo kernel's class form (conv_halo.h): class k = 0..3 is (ph, pw) =
     // (1,1), (0,1), (1,0), (0,0) -- heaviest first --, owns workgroups [cls_off[k], cls_off[k + 1]) and cls_hp / cls_wp tiles along H / W
     int cls_off[5], cls_hp[4], cls_wp[4];
+    int cls_mix;                 // 1: the classes' workgroups round-robin in the grid instead of one class after the other (conv_halo.h)
 };
 
 }  // namespace detr
@@ -1367,6 +1368,7 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
     DETR_REQUIRE(d->w_dtype == 0 || (d->w_dtype == 1 && d->compute == 1 && mode != 2 && d->Ci % 32 == 0 && d->Co % 32 == 0),
                  "conv3x3: a bf16 kernel tensor needs compute = bf16, mode 0/1 and channel counts %% 32 == 0");
     a.par_on = 0; a.Hp = a.Wp = a.ph = a.pw = a.kh0 = a.kw0 = 0; a.nth = a.ntw = 3;
+    a.cls_mix = 0;
     const bool dgrad = mode == 1;
     // stride-1 convs on bf16 tensors: the halo-staged kernel (conv_halo.h; DETR_HIP_CONV_HALO=2 = off), for 128-channel panels on 4-row tiles
     // its LDS-DMA form (conv_halo_dma.h: bit-identical, 5-10 % faster; DETR_HIP_CONV_DMA=2 = off).  With 4-row tiles it also

@@ -155,8 +155,29 @@ __global__ __launch_bounds__(GEMM_THREADS, TH == 8 ? 2 : 3) void conv3x3_halo_bf
     int id = xcd_remap(blockIdx.x, gridDim.x);
     int ph = 0, pw = 0, Hp = a.Hp, Wp = a.Wp;
     if constexpr (S2C) {                                 // the four classes share the launch: [cls_off[k], cls_off[k + 1])
-        const int k = (id >= a.cls_off[1]) + (id >= a.cls_off[2]) + (id >= a.cls_off[3]);
-        id -= a.cls_off[k];
+        int k;
+        if (a.cls_mix) {
+            // Grid order: the four classes ROUND-ROBIN (workgroup id -> class id & 3), the classes' surplus tiles behind them.  A class writes (and reads the mask
+            // of) the pixels of ONE column parity only -- at 128 channels that is address bit 8, every other 256-byte block of the tensor, for the whole lifetime
+            // of its workgroups -- so with one class after the other (round 3's "heaviest first") the launch used half of the memory channels at a time:
+            // 120.2 / 94.1 / 113.9 us at 128 / 256 / 512 channels against 115.5 / 81.7 / 99.6 round-robin (profiles/r05_ab_results.txt #9).
+            const int nk[4] = {a.cls_off[1], a.cls_off[2] - a.cls_off[1], a.cls_off[3] - a.cls_off[2], a.cls_off[4] - a.cls_off[3]};
+            int m = nk[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) m = nk[q] < m ? nk[q] : m;
+            if (id < 4 * m) { k = id & 3; id >>= 2; }
+            else {
+                int j = id - 4 * m;
+                k = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (k == q && j >= nk[q] - m) { j -= nk[q] - m; k = q + 1; }
+                id = m + j;
+            }
+        } else {
+            k = (id >= a.cls_off[1]) + (id >= a.cls_off[2]) + (id >= a.cls_off[3]);
+            id -= a.cls_off[k];
+        }
         ph = (k == 0 || k == 2) ? 1 : 0;
         pw = (k == 0 || k == 1) ? 1 : 0;
         Hp = a.cls_hp[k];
@@ -372,6 +393,7 @@ static int launch_conv_halo_s2classes(const ConvArgs &a0, hipStream_t s) {
         a.cls_off[k + 1] = a.cls_off[k] + a.N * a.cls_hp[k] * a.cls_wp[k] * a.tiles_n;
     }
     if (a.cls_off[4] <= 0) return 0;
+    a.cls_mix = tune(T_DGRAD_S2_CLASSES) == 4 ? 0 : 1;       // DETR_HIP_DGRAD_S2_CLASSES = 4: one class after the other (A/B of the grid order)
     constexpr int smem = ConvHaloSmemBytes<BN, TH>::VALUE;
     static bool reserved = false;
     const void *fn = reinterpret_cast<const void *>(conv3x3_halo_bf16_kernel<BN, true, TH, true>);

@@ -1304,6 +1304,15 @@ def test_conv3x3_stride2_dgrad_halo_classes(hip, N, H, W, C):
             hip.set_tuning("DETR_HIP_DGRAD_S2_CLASSES", None)
         outs[mode] = dx.float().cpu().double()
     halo, tile = outs[None], outs["3"]
+    # the grid order of the class workgroups (round 5: round-robin; DETR_HIP_DGRAD_S2_CLASSES=4: one class after the other) changes nothing but time
+    hip.set_tuning("DETR_HIP_DGRAD_S2_CLASSES", "4")
+    try:
+        dx = torch.full((N, H, W, C), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.conv3x3(1, dyd, wd, dx, N, H, W, C, Ho, Wo, C, 2, mask=md, compute=1)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_tuning("DETR_HIP_DGRAD_S2_CLASSES", None)
+    assert torch.equal(dx.float().cpu().double(), halo), "class grid order changed the result"
     scale = float(ref.abs().max())
     assert scale > 0
     assert float(((tile - ref).abs() / (ref.abs() + 1e-2 * scale)).max()) < 2.0 ** -8 * 1.1
