@@ -32,6 +32,9 @@ namespace detr {
 #ifndef DETR_BF_NS
 #define DETR_BF_NS 4
 #endif
+#ifndef DETR_BF_INTERLEAVE
+#define DETR_BF_INTERLEAVE 0   // 1: workgroup w takes strips w, w + nwg, w + 2 nwg, ... (one sweep over the tensors) instead of a contiguous range (A/B builds)
+#endif
 #ifndef DETR_BF_NT
 #define DETR_BF_NT 0           // 1: the strip requests carry the non-temporal hint (A/B builds)
 #endif
@@ -61,7 +64,11 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = ring_lds_addr(bf_smem);
     const int wg = blockIdx.x;
-    const int s0 = (int)((long long)a.nstrips * wg / a.nwg), s1 = (int)((long long)a.nstrips * (wg + 1) / a.nwg);
+    // strips of this workgroup: v = 0 .. cnt - 1 -> strip sv(v)
+    const int s0 = DETR_BF_INTERLEAVE ? wg : (int)((long long)a.nstrips * wg / a.nwg);
+    const int cnt = DETR_BF_INTERLEAVE ? (a.nstrips - wg + a.nwg - 1) / a.nwg : (int)((long long)a.nstrips * (wg + 1) / a.nwg) - s0;
+    const int sstep = DETR_BF_INTERLEAVE ? a.nwg : 1;
+    auto sv = [&](const int v) { return s0 + v * sstep; };
     const int l31 = lane & 31, hh = lane >> 5;
 
     if (wave < 4) {
@@ -80,9 +87,9 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             const int r = 8 * wave + (lane >> 3), pos = lane & 7;
             yvoff = (unsigned)r * (unsigned)a.ldy * 2u + 16u * (unsigned)(pos ^ (4 * ((r >> 1) & 1)));
         }
-        auto issue_strip = [&](const int s, const int stage) {
-            const long long row0 = (long long)s * BF_SR;
-            const long long left = (s < s1 && row0 < a.M) ? (long long)a.M - row0 : 0;             // rows of the strip onwards (0: nothing to fetch)
+        auto issue_strip = [&](const int v, const int stage) {
+            const long long row0 = (long long)sv(v) * BF_SR;
+            const long long left = (v < cnt && row0 < a.M) ? (long long)a.M - row0 : 0;            // rows of the strip onwards (0: nothing to fetch)
             const unsigned long long gb = left > 0 ? (unsigned long long)((left - 1) * a.ldg + BF_D2) * 2ull : 0ull;
             const unsigned long long yb = left > 0 ? (unsigned long long)((left - 1) * a.ldy + BF_D1) * 2ull : 0ull;
             const u32x4 rg = ring_rsrc(reinterpret_cast<const char *>(a.g) + row0 * a.ldg * 2, (unsigned)(gb > 0xFFFFFFFFull ? 0xFFFFFFFFull : gb));
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             }
         }
 #pragma unroll
-        for (int t = 0; t < BF_NS - 1; ++t) issue_strip(s0 + t, t);
+        for (int t = 0; t < BF_NS - 1; ++t) issue_strip(t, t);
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -135,11 +142,11 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
             return __builtin_bit_cast(bf16x8, v);
         };
         int stage = 0, nxt = BF_NS - 1;                  // ring slots of strip s and of strip s + NS - 1
-        for (int s = s0; s < s1; ++s) {
+        for (int v = 0; v < cnt; ++v) {
             ring_wait_vmcnt<(BF_NS - 2) * BF_PW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_strip(s + BF_NS - 1, nxt);
+            issue_strip(v + BF_NS - 1, nxt);
             const char *st = bf_smem + BF_OFF_RING + stage * BF_STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -178,8 +185,9 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
         const int gsw = (4 * (l31 & 3)) ^ (l31 >> 3);
         unsigned short *dz = a.dz;
         int stage = 0;
-        auto store_strip = [&](const int s) {        // rows 16 d .. 16 d + 15 of strip s out of staging buffer s & 1: two passes of 8 rows x 128 bytes
-            const char *sb = bf_smem + BF_OFF_ST + (s & 1) * (BF_SR * BF_ST_PITCH);
+        auto store_strip = [&](const int v) {        // rows 16 d .. 16 d + 15 of this workgroup's strip v out of staging buffer v & 1: two passes of 8 rows x 128 bytes
+            const int s = sv(v);
+            const char *sb = bf_smem + BF_OFF_ST + (v & 1) * (BF_SR * BF_ST_PITCH);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = 16 * d + 8 * i + (lane >> 3), c = lane & 7;
@@ -188,12 +196,12 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
                 if (row < a.M) *reinterpret_cast<uint4 *>(dz + row * a.lddz + c * 8) = v;
             }
         };
-        for (int s = s0; s < s1; ++s) {
+        for (int v = 0; v < cnt; ++v) {
             // (a raw s_barrier orders nothing by itself: the staged rows of the previous strip must have been WRITTEN before the other wave reads them)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (s > s0) store_strip(s - 1);
+            if (v > 0) store_strip(v - 1);
             const char *st = bf_smem + BF_OFF_RING + stage * BF_STAGE;
             stage = (stage + 1 == BF_NS) ? 0 : stage + 1;
             f32x16 acc;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fg, acc, 0, 0, 0);
             }
             // lane: row l31, columns 32 d + 8 j + 4 hh .. + 3 in acc[4 j .. 4 j + 3]
-            char *sb = bf_smem + BF_OFF_ST + (s & 1) * (BF_SR * BF_ST_PITCH);
+            char *sb = bf_smem + BF_OFF_ST + (v & 1) * (BF_SR * BF_ST_PITCH);
             const char *ym = st + BF_G_BYTES + (l31 >> 3) * 1024 + (l31 & 7) * 128 + hh * 8;
             const int ysw = 4 * ((l31 >> 1) & 1);
 #pragma unroll
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(BF_THREADS, 1) void conv1x1_bwd_fused_bf16_kernel(B
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s1 > s0) store_strip(s1 - 1);
+        if (cnt > 0) store_strip(cnt - 1);
     }
 #endif
 }
