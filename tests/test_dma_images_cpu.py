@@ -232,3 +232,41 @@ def test_halo_dma_kernel_tile_images():
                     slots[lane] = (addr // 16) % 16
                 for grp in B128_GROUPS:
                     assert len({slots[l] for l in grp}) == 16
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# csrc/conv_halo.h: grid order of the stride-2 input gradient's parity classes
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def s2_class_of_workgroup(wid, nk):
+    """restatement of the cls_mix branch of conv3x3_halo_bf16_kernel<.., S2C = true>: workgroup id -> (class, tile index inside the class)"""
+    m = min(nk)
+    if wid < 4 * m:
+        return wid & 3, wid >> 2
+    j, k = wid - 4 * m, 0
+    for q in range(3):
+        if k == q and j >= nk[q] - m:
+            j -= nk[q] - m
+            k = q + 1
+    return k, m + j
+
+
+def test_stride2_class_round_robin_covers_every_tile_once():
+    """Every (class, tile) pair is produced by exactly one workgroup id, for equal, unequal and EMPTY classes (a one-row map has no (1, .) class;
+    sizes as launch_conv_halo_s2classes computes them: N * ceil(Hc / 4) * ceil(Wc / 32) * channel panels)."""
+    import itertools
+    cases = [[5, 5, 5, 5], [6, 6, 5, 5], [7, 5, 6, 4], [0, 3, 0, 3], [0, 0, 0, 2], [4, 0, 4, 0], [1, 2, 3, 4], [9, 1, 1, 1], [0, 0, 0, 0]]
+    for N, H, W, panels in itertools.product((1, 3), (1, 2, 7, 50), (1, 5, 84, 167), (1, 4)):
+        nk = []
+        for k in range(4):
+            ph, pw = (1 if k in (0, 2) else 0), (1 if k in (0, 1) else 0)
+            Hc, Wc = (H - ph + 1) // 2, (W - pw + 1) // 2
+            nk.append(N * -(-Hc // 4) * -(-Wc // 32) * panels)
+        cases.append(nk)
+    for nk in cases:
+        seen = set()
+        for wid in range(sum(nk)):
+            k, idx = s2_class_of_workgroup(wid, nk)
+            assert 0 <= k < 4 and 0 <= idx < nk[k], (nk, wid, k, idx)
+            assert (k, idx) not in seen, (nk, wid)
+            seen.add((k, idx))
+        assert len(seen) == sum(nk)
