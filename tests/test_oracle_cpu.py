@@ -248,6 +248,29 @@ def test_workspace_bytes_queries_and_tuning_reload():
     finally:
         os.environ.pop("DETR_HIP_WGRAD_FUSED", None)
         lib.detr_hip_reload_tuning()
+    # round 5: the nine-tap kernel's stride-2 form is taken for bf16-STORED tensors up to 128 channels (the query follows the launch's choice);
+    # DETR_HIP_WGRAD_FUSED = 3 / 4 force the per-tap / the nine-tap kernel for every stride-2 weight gradient
+    s2 = _hip.Conv3x3Desc()
+    s2.N, s2.Hi, s2.Wi, s2.Ci, s2.Ho, s2.Wo, s2.Co, s2.stride, s2.pad, s2.compute = 8, 200, 334, 128, 100, 167, 128, 2, 1, 1
+    s2.x_dtype = s2.w_dtype = 1                      # (mode 2: `w` carries dy)
+    nine_tap = 127 * 9 * 128 * 128 * 4               # 4800 units of 32 output pixels over 512 / 4 (ci, co) tiles = 128 splits of 38 units: 127 non-empty
+    assert lib.detr_hip_workspace_bytes_conv3x3(byref(s2), 2) == nine_tap
+    s2.x_dtype = s2.w_dtype = 0                      # fp32-stored: per-tap kernel
+    per_tap_128 = lib.detr_hip_workspace_bytes_conv3x3(byref(s2), 2)
+    assert per_tap_128 != nine_tap and per_tap_128 % (9 * 128 * 128 * 4) == 0
+    s2.x_dtype = s2.w_dtype = 1
+    s2.Ci = s2.Co = 256
+    s2.Hi, s2.Wi, s2.Ho, s2.Wo = 100, 167, 50, 84
+    per_tap_256 = lib.detr_hip_workspace_bytes_conv3x3(byref(s2), 2)
+    _hip.set_tuning("DETR_HIP_WGRAD_FUSED", 4)
+    forced = lib.detr_hip_workspace_bytes_conv3x3(byref(s2), 2)
+    _hip.set_tuning("DETR_HIP_WGRAD_FUSED", None)
+    assert forced == 32 * 9 * 256 * 256 * 4 and per_tap_256 != forced
+    s2.Ci = s2.Co = 128
+    s2.Hi, s2.Wi, s2.Ho, s2.Wo = 200, 334, 100, 167
+    _hip.set_tuning("DETR_HIP_WGRAD_FUSED", 3)
+    assert lib.detr_hip_workspace_bytes_conv3x3(byref(s2), 2) == per_tap_128
+    _hip.set_tuning("DETR_HIP_WGRAD_FUSED", None)
     st = _hip.StemDesc()
     st.N, st.H, st.W, st.Ho, st.Wo, st.compute, st.w_dtype, st.split = 8, 800, 1333, 400, 667, 1, 1, 512
     assert lib.detr_hip_workspace_bytes_stem(byref(st), 0) == 0
