@@ -85,7 +85,7 @@ __device__ __forceinline__ void halo_epilogue(const f32x16 (&acc)[TH / 2][BN / 6
             mk[it] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
             if (mask && row_ok && tw < wn_ok) {
                 if (e.m16 == 2) mk[it].x = reinterpret_cast<const unsigned char *>(e.mask)[(prow0 + PS * tw) * e.ldmask + (col >> 3)];   // 8 mask bits
-                else mk[it] = *reinterpret_cast<const uint4 *>(mask + (prow0 + PS * tw) * e.ldmask + col);
+                else mk[it] = epi_ld16(mask + (prow0 + PS * tw) * e.ldmask + col);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -360,6 +360,20 @@ __device__ __forceinline__ float epi_one(float v, float sc, float bi, const EpiA
 // (16-byte bf16 accesses, a wave instruction covers whole 128 / 256-byte row segments), the residual and mask rows of ALL passes
 // of a 32-row strip are requested before the accumulators are even staged, and the per-column scale / bias are loaded once.
 // The arithmetic per element is epi_one, unchanged: results are bit-identical to the 4-column form.
+// residual / mask operands of the wide epilogues: read once by the launch.  DETR_EPI_NT = 1 requests them non-temporal (A/B builds; the streaming
+// kernel gained 0.2 ms from the same hint, gemm_stream.h)
+#ifndef DETR_EPI_NT
+#define DETR_EPI_NT 0
+#endif
+__device__ __forceinline__ uint4 epi_ld16(const unsigned short *p) {
+#if DETR_EPI_NT
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
 template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
                                                 float *stage_base, float *C, long long ldc, int M, int N, int m0, int n0,
@@ -410,10 +424,10 @@ __device__ __forceinline__ void epilogue_wide16(const f32x16 (&acc)[TileCfg<BM, 
             prow[p] = prow_of(row);
             rr[p] = make_uint4(0u, 0u, 0u, 0u);
             mm[p] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-            if (ok && res16) rr[p] = *reinterpret_cast<const uint4 *>(res16 + prow[p] * e.ldr + col);
+            if (ok && res16) rr[p] = epi_ld16(res16 + prow[p] * e.ldr + col);
             if (ok && msk16) {
                 if (e.m16 == 2) mm[p].x = reinterpret_cast<const unsigned char *>(e.mask)[prow[p] * e.ldmask + (col >> 3)];      // 8 mask bits
-                else mm[p] = *reinterpret_cast<const uint4 *>(msk16 + prow[p] * e.ldmask + col);
+                else mm[p] = epi_ld16(msk16 + prow[p] * e.ldmask + col);
             }
         }
         // the staging region is wave-private: only the first strip needs the workgroup (the main loop / a row-sum finish of the
