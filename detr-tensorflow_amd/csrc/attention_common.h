@@ -175,5 +175,7 @@ static int attn_waves(int rows, int bh) {
 
 int attn_fwd_bf16_launch(const AttnArgs &a, hipStream_t s);      // attention_bf16.hip
 int attn_bwd_bf16_launch(const AttnArgs &a, hipStream_t s);
+int attn2_fwd_from_desc(const detr_attn_desc *d, hipStream_t s);    // attention_dma.hip (io_dtype = 1)
+int attn2_bwd_from_desc(const detr_attn_desc *d, hipStream_t s);
 
 }  // namespace detr

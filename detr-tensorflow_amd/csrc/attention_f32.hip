@@ -360,6 +360,9 @@ using namespace detr;
 /* one entry point per direction; detr_attn_desc.compute selects the exact-fp32 kernels above or the bf16-MFMA kernels of
  * attention_bf16.hip */
 extern "C" int detr_hip_attention_fwd(const detr_attn_desc *d, void *stream) {
+    DETR_REQUIRE(d, "attention: null descriptor");
+    if (d->io_dtype == 1) return attn2_fwd_from_desc(d, (hipStream_t)stream);      // all-bf16 operands: attention_dma.hip
+    DETR_REQUIRE(d->io_dtype == 0, "attention: io_dtype must be 0 (fp32 tensors) or 1 (bf16 tensors)");
     AttnArgs a;
     if (attn_from_desc(d, 0, a)) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -371,6 +374,9 @@ extern "C" int detr_hip_attention_fwd(const detr_attn_desc *d, void *stream) {
 }
 
 extern "C" int detr_hip_attention_bwd(const detr_attn_desc *d, void *stream) {
+    DETR_REQUIRE(d, "attention: null descriptor");
+    if (d->io_dtype == 1) return attn2_bwd_from_desc(d, (hipStream_t)stream);
+    DETR_REQUIRE(d->io_dtype == 0, "attention: io_dtype must be 0 (fp32 tensors) or 1 (bf16 tensors)");
     AttnArgs a;
     if (attn_from_desc(d, 1, a)) return -1;
     hipStream_t s = (hipStream_t)stream;

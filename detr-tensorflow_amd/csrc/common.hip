@@ -174,6 +174,7 @@ extern "C" int detr_hip_struct_layout(int32_t which, int32_t *out, int32_t cap) 
         DETR_PUT(DETR_OFF(detr_attn_desc, lddk)); DETR_PUT(DETR_OFF(detr_attn_desc, dv)); DETR_PUT(DETR_OFF(detr_attn_desc, lddv));
         DETR_PUT(DETR_OFF(detr_attn_desc, delta)); DETR_PUT(DETR_OFF(detr_attn_desc, scale)); DETR_PUT(DETR_OFF(detr_attn_desc, dropout_p));
         DETR_PUT(DETR_OFF(detr_attn_desc, dropout_site)); DETR_PUT(DETR_OFF(detr_attn_desc, dropout_step)); DETR_PUT(DETR_OFF(detr_attn_desc, compute));
+        DETR_PUT(DETR_OFF(detr_attn_desc, io_dtype)); DETR_PUT(DETR_OFF(detr_attn_desc, dropmask));
         break;
     case 6:   // detr_setloss_desc
         DETR_PUT((int32_t)sizeof(detr_setloss_desc));

@@ -53,7 +53,7 @@ class AttnDesc(Structure):
                 ("d_o", c_void_p), ("ldd_o", c_int64), ("dq", c_void_p), ("lddq", c_int64), ("dk", c_void_p), ("lddk", c_int64),
                 ("dv", c_void_p), ("lddv", c_int64), ("delta", c_void_p),
                 ("scale", c_float), ("dropout_p", c_float), ("dropout_site", ctypes.c_uint32), ("dropout_step", c_void_p),
-                ("compute", c_int32)]
+                ("compute", c_int32), ("io_dtype", c_int32), ("dropmask", c_void_p)]       # ABI 8: all-bf16 operands + keep bits
 
 
 class LayerNormDesc(Structure):
@@ -136,6 +136,7 @@ _SIGNATURES = {
     "detr_hip_layernorm_bwd": [POINTER(LayerNormDesc), c_void_p],
     "detr_hip_attention_fwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_attention_bwd": [POINTER(AttnDesc), c_void_p],
+    "detr_hip_attention_dropmask": [POINTER(AttnDesc), c_void_p],
     "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p, c_void_p],
     "detr_hip_multi_copy": [c_void_p, c_int32, c_int32, c_void_p],
     "detr_hip_colsum_scaled": [c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p],
@@ -167,6 +168,7 @@ _SIGNATURES = {
 }
 # scratch sizing queries (return int64 bytes)
 _SIGNATURES_I64 = {
+    "detr_hip_attention_dropmask_words": [c_int32, c_int32, c_int32, c_int32],
     "detr_hip_colsum_det_scratch_floats": [c_int64, c_int32],
     "detr_hip_conv1x1_bwd_fused_workspace_floats": [c_int64],
     "detr_hip_workspace_bytes_gemm": [POINTER(GemmDesc)],
@@ -175,7 +177,7 @@ _SIGNATURES_I64 = {
     "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
-ABI_VERSION = 7
+ABI_VERSION = 8
 # order of detr_hip_struct_layout's `which`
 LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 
@@ -734,38 +736,70 @@ def zero_(t):
 # ------------------------------------------------------------------------------------------
 # attention / LayerNorm descriptors
 # ------------------------------------------------------------------------------------------
-def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_site=0, dropout_step=None, compute=None,
-              d_o=None, dq=None, dk=None, dv=None, delta=None):
-    """Fused attention core (include/detr_hip.h detr_attn_desc).  q / k / v / o (and the gradients) are 2-D views
-    [rows, >= H*32] whose row stride is taken from the tensor, so they may be column blocks of a packed projection buffer.
-    Forward when d_o is None, otherwise the backward (dq / dk / dv / delta written)."""
+def attention_dropmask_words(B, H, T, S):
+    """uint32 words of the keep-bit buffer of one attention site (detr_hip_attention_dropmask_words)."""
+    return int(load().detr_hip_attention_dropmask_words(B, H, T, S))
+
+
+def attention_dropmask(mask, B, H, T, S, *, dropout_p, dropout_site=0, dropout_step=None):
+    """Fills `mask` (int32 / uint32 tensor of attention_dropmask_words(...) words) with the keep bits of the attention-probability
+    dropout of (site, *step): what the all-bf16 attention kernels read instead of hashing (detr_hip_attention_dropmask)."""
     d = AttnDesc()
     d.B, d.H, d.T, d.S = B, H, T, S
+    d.dropout_p, d.dropout_site, d.dropout_step = dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
+    if mask.numel() * mask.element_size() < 4 * attention_dropmask_words(B, H, T, S):
+        raise ValueError("attention_dropmask: buffer too small")
+    d.dropmask = mask.data_ptr()
+    _check(load().detr_hip_attention_dropmask(byref(d), _stream()), "detr_hip_attention_dropmask")
+
+
+def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_site=0, dropout_step=None, compute=None,
+              d_o=None, dq=None, dk=None, dv=None, delta=None, dropmask=None):
+    """Fused attention core (include/detr_hip.h detr_attn_desc).  q / k / v / o (and the gradients) are 2-D views
+    [rows, >= H*32] whose row stride is taken from the tensor, so they may be column blocks of a packed projection buffer.
+    Forward when d_o is None, otherwise the backward (dq / dk / dv / delta written).
+    All-bf16 operands (io_dtype = 1, csrc/attention_dma.hip): every tensor bf16, q pre-multiplied by scale * log2(e), delta with
+    2*B*H*T floats, and -- with dropout -- the keep bits of attention_dropmask() in `dropmask`."""
+    d = AttnDesc()
+    d.B, d.H, d.T, d.S = B, H, T, S
+    io16 = q.dtype == torch.bfloat16
+    want = torch.bfloat16 if io16 else torch.float32
     for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
-        if t.stride(1) != 1 or t.dtype != torch.float32:
-            raise TypeError(f"attention: {name} must be fp32 with a unit column stride")
+        if t.stride(1) != 1 or t.dtype != want:
+            raise TypeError(f"attention: {name} must be {want} with a unit column stride")
         setattr(d, name, t.data_ptr())
         setattr(d, "ld" + name, t.stride(0))
     d.lse = lse.data_ptr()
     d.scale, d.dropout_p, d.dropout_site, d.dropout_step = scale, dropout_p, dropout_site & 0xFFFFFFFF, ptr(dropout_step)
     d.compute = COMPUTE_BF16 if compute is None else int(compute)
+    d.io_dtype = 1 if io16 else 0
+    if io16:
+        d.compute = 1
+        if dropout_p > 0.0:
+            if dropmask is None:
+                raise ValueError("attention: bf16 operands with dropout need the keep bits (attention_dropmask)")
+            d.dropmask = dropmask.data_ptr()
     ev0 = PROFILER.begin() if PROFILER is not None else None
+    esz = 2.0 if io16 else 4.0
     prods = 2.0 * B * H * T * S * 32                   # FLOPs of one [T,S,32] product over all (batch, head) problems
-    io = 4.0 * 256 * (2 * B * T + 2 * B * S)           # q, o + k, v rows (fp32), once each
+    io = esz * 256 * (2 * B * T + 2 * B * S)           # q, o + k, v rows, once each
+    bits = (B * H * T * S / 8.0) if (io16 and dropout_p > 0.0) else 0.0      # keep bits, one layout per kernel
     if d_o is None:
         _check(load().detr_hip_attention_fwd(byref(d), _stream()), "detr_hip_attention_fwd")
         if ev0 is not None:
-            PROFILER.end("attention_fwd", 2 * prods, ev0, f"B{B} H{H} T{T} S{S}", io)
+            PROFILER.end("attention_fwd", 2 * prods, ev0, f"B{B} H{H} T{T} S{S}", io + bits)
         return
     for name, ldn, t in (("d_o", "ldd_o", d_o), ("dq", "lddq", dq), ("dk", "lddk", dk), ("dv", "lddv", dv)):
-        if t.stride(1) != 1 or t.dtype != torch.float32:
-            raise TypeError(f"attention: {name} must be fp32 with a unit column stride")
+        if t.stride(1) != 1 or t.dtype != want:
+            raise TypeError(f"attention: {name} must be {want} with a unit column stride")
         setattr(d, name, t.data_ptr())
         setattr(d, ldn, t.stride(0))
+    if io16 and delta.numel() < 2 * B * H * T:
+        raise ValueError("attention: bf16 operands need 2*B*H*T floats of `delta` scratch")
     d.delta = delta.data_ptr()
     _check(load().detr_hip_attention_bwd(byref(d), _stream()), "detr_hip_attention_bwd")
     if ev0 is not None:      # dQ kernel: S, dP, dQ; dK/dV kernel: S, dP, dV, dK (the probabilities are recomputed twice)
-        PROFILER.end("attention_bwd", 7 * prods, ev0, f"B{B} H{H} T{T} S{S}", 2.5 * io)
+        PROFILER.end("attention_bwd", 7 * prods, ev0, f"B{B} H{H} T{T} S{S}", 2.5 * io + 2 * bits)
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, add=None, y2=None, y16=None):

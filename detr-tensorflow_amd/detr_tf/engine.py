@@ -45,6 +45,11 @@ BWD_FUSED = os.environ.get("DETR_HIP_BWD_FUSED", "1") != "0"            # layer1
 # 16.53 / 16.56 ms (2) vs 16.53 / 16.61 (0) vs 16.85 / 16.96 (1): the K = 256 launches absorb their LayerNorm at equal time (18 launches
 # fewer per step), the K = 2048 ones lose 0.35 ms -- a 32-row tile walks 64 K tiles behind one barrier each
 LN_FUSE = int(os.environ.get("DETR_HIP_LN_FUSE", "2"))
+# bf16 compute mode, round 6: the attention operands Q / K / V / O / dO / dQ / dK / dV are STORED in bf16 (the projection GEMMs write them, Q with
+# scale * log2(e) as its alpha) and the attention core is csrc/attention_dma.hip (LDS-DMA K / V rings per wave, dropout keep flags as bits
+# generated once per step).  DETR_HIP_ATTN16=0: the round-3 kernels on fp32 tensors (A/B switch)
+ATTN16 = os.environ.get("DETR_HIP_ATTN16", "1") != "0"
+QK_ALPHA = float(HD) ** -0.5 * 1.4426950408889634      # what the stored bf16 query carries: softmax scale (transformer.py:307) * log2(e)
 
 
 def mix32(x):
@@ -365,16 +370,62 @@ class DetrEngine:
     # with N = 512 against rows 0..511 of in_proj_kernel.  The query scaling head_dim**-0.5 (:307) is folded into the
     # attention kernels (detr_attn_desc.scale).  In the backward the packed dQKV buffer turns the three data gradients
     # and the three residual-style adds into ONE GEMM with K = 768:  d_x = dQKV @ in_proj_kernel + d_residual.
+    @property
+    def attn16(self):
+        return self.compute == 1 and ATTN16
+
+    def _dropmask(self, site, B, T, S):
+        """Keep bits of the attention-probability dropout of `site` (hip.attention_dropmask): one buffer per site, filled once per
+        step by _gen_dropmasks()."""
+        return self.buf(f"dropmask:{site}", (hip.attention_dropmask_words(B, HEADS, T, S),), torch.int32)
+
+    def _gen_dropmasks(self, B, L):
+        """All keep-bit buffers of this step's attention sites, on a stream of their own behind the seed write (they depend on nothing
+        else); joined in front of the first encoder attention.  Pure integer VALU work next to the backbone's HBM- / MFMA-bound kernels."""
+        dp, _ = self._drop
+        if not (self.attn16 and dp > 0.0):
+            return
+        Q = self.Q
+        sites = [(16 * i, L, L) for i in range(self.num_enc)]
+        for i in range(self.num_dec):
+            ds = 16 * (32 + i)
+            sites += [(ds, Q, Q), (ds + 2, Q, L)]
+        main = torch.cuda.current_stream()
+        if getattr(self, "_mask_stream", None) is None:
+            self._mask_stream = torch.cuda.Stream(device=main.device)
+        bufs = [(site, T, S, self._dropmask(site, B, T, S)) for site, T, S in sites]       # (allocated on the main stream)
+        self._mask_stream.wait_stream(main)
+        with torch.cuda.stream(self._mask_stream):
+            for site, T, S, m in bufs:
+                hip.attention_dropmask(m, B, HEADS, T, S, dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)
+        self._mask_pending = True
+
+    def _join_dropmasks(self):
+        if getattr(self, "_mask_pending", False):
+            torch.cuda.current_stream().wait_stream(self._mask_stream)
+            self._mask_pending = False
+
     def _self_attn_fwd(self, tag, pfx, qk_in, v_in, B, T, out, site, ln=None):
         W, bias = self._w(f"{pfx}/in_proj_kernel"), self.P.views[f"{pfx}/in_proj_bias"]
-        QKV = self.buf(f"{tag}:QKV", (B * T, 3 * D))
-        hip.gemm_group([hip.linear_fwd_call(qk_in, W[0:2 * D], bias[0:2 * D], QKV[:, 0:2 * D]),        # :294-300
-                        hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], QKV[:, 2 * D:])])          # :302-304
-        O = self.buf(f"{tag}:O", (B * T, D))
-        lse = self.buf(f"{tag}:lse", (B * HEADS, T))
         dp, _ = self._drop
-        hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, lse, B, HEADS, T, T, scale=float(HD) ** -0.5,
-                      dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)                    # :307-345
+        lse = self.buf(f"{tag}:lse", (B * HEADS, T))
+        if self.attn16:
+            # bf16 operands: three members of one grouped launch (Q alone carries the alpha), bf16 O straight into the out-projection
+            QKV = self.buf(f"{tag}:QKV16", (B * T, 3 * D), torch.bfloat16)
+            hip.gemm_group([hip.linear_fwd_call(qk_in, W[0:D], bias[0:D], QKV[:, 0:D], alpha=QK_ALPHA),          # :294-300, :307
+                            hip.linear_fwd_call(qk_in, W[D:2 * D], bias[D:2 * D], QKV[:, D:2 * D]),
+                            hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], QKV[:, 2 * D:])])                  # :302-304
+            O = self.buf(f"{tag}:O16", (B * T, D), torch.bfloat16)
+            self._join_dropmasks()
+            hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, lse, B, HEADS, T, T, scale=float(HD) ** -0.5, dropout_p=dp,
+                          dropout_site=site, dropout_step=self._seed_dev, dropmask=self._dropmask(site, B, T, T) if dp > 0.0 else None)
+        else:
+            QKV = self.buf(f"{tag}:QKV", (B * T, 3 * D))
+            hip.gemm_group([hip.linear_fwd_call(qk_in, W[0:2 * D], bias[0:2 * D], QKV[:, 0:2 * D]),        # :294-300
+                            hip.linear_fwd_call(v_in, W[2 * D:], bias[2 * D:], QKV[:, 2 * D:])])          # :302-304
+            O = self.buf(f"{tag}:O", (B * T, D))
+            hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, lse, B, HEADS, T, T, scale=float(HD) ** -0.5,
+                          dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)                    # :307-345
         hip.linear_fwd(O, self._w(f"{pfx}/out_proj_kernel"), self.P.views[f"{pfx}/out_proj_bias"], out, residual=v_in,
                        dropout_p=dp, dropout_seed=site + 1, dropout_step=self._seed_dev, ln=ln)        # :346-347 + :169 (+ the LayerNorm behind it)
 
@@ -385,20 +436,27 @@ class DetrEngine:
         (the decoder's query_pos gradient)."""
         G = self.P.gviews
         W, gW, gb = self._w(f"{pfx}/in_proj_kernel"), G[f"{pfx}/in_proj_kernel"], G[f"{pfx}/in_proj_bias"]
-        QKV, O = self._bufs[f"{tag}:QKV"], self._bufs[f"{tag}:O"]
-        dO = self.buf(f"scratch:dO:{B * T}", (B * T, D))
+        a16 = self.attn16
+        adt = torch.bfloat16 if a16 else torch.float32
+        QKV, O = self._bufs[f"{tag}:QKV16" if a16 else f"{tag}:QKV"], self._bufs[f"{tag}:O16" if a16 else f"{tag}:O"]
+        dO = self.buf(f"scratch:dO:{B * T}:{int(a16)}", (B * T, D), adt)
         hip.linear_dgrad(d_out, self._w(f"{pfx}/out_proj_kernel"), dO)
-        dQKV = self.buf(f"scratch:dQKV:{B * T}{self._sx(tag)}", (B * T, 3 * D))
-        delta = self.buf(f"scratch:delta:{B * T}", (B * HEADS, T))
+        dQKV = self.buf(f"scratch:dQKV:{B * T}:{int(a16)}{self._sx(tag)}", (B * T, 3 * D), adt)
+        delta = self.buf(f"scratch:delta:{B * T}", (2 * B * HEADS, T))       # (bf16 operands: delta / scale | lse * log2 e - log2 scale)
         dp, _ = self._drop
         hip.attention(QKV[:, 0:D], QKV[:, D:2 * D], QKV[:, 2 * D:], O, self._bufs[f"{tag}:lse"], B, HEADS, T, T,
                       scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev,
-                      d_o=dO, dq=dQKV[:, 0:D], dk=dQKV[:, D:2 * D], dv=dQKV[:, 2 * D:], delta=delta)
-        # weight gradients (bias gradients fused: row sums of dy^T), one grouped launch
-        self._side(lambda: hip.gemm_group([
-            hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"]),
-            hip.linear_wgrad_call(dQKV[:, 0:2 * D], qk_in, gW[0:2 * D], bias_grad=gb[0:2 * D]),
-            hip.linear_wgrad_call(dQKV[:, 2 * D:], v_in, gW[2 * D:], bias_grad=gb[2 * D:])]))
+                      d_o=dO, dq=dQKV[:, 0:D], dk=dQKV[:, D:2 * D], dv=dQKV[:, 2 * D:], delta=delta,
+                      dropmask=self._dropmask(site, B, T, T) if (a16 and dp > 0.0) else None)
+        # weight gradients (bias gradients fused: row sums of dy^T), one grouped launch (bf16 operands: the out-projection's pair has
+        # other storage types than the in-projections' and is a launch of its own)
+        wg_out = hip.linear_wgrad_call(d_out, O, G[f"{pfx}/out_proj_kernel"], bias_grad=G[f"{pfx}/out_proj_bias"])
+        wg_in = [hip.linear_wgrad_call(dQKV[:, 0:2 * D], qk_in, gW[0:2 * D], bias_grad=gb[0:2 * D]),
+                 hip.linear_wgrad_call(dQKV[:, 2 * D:], v_in, gW[2 * D:], bias_grad=gb[2 * D:])]
+        if a16:
+            self._side(lambda: (hip.gemm(*wg_out[0], **wg_out[1]), hip.gemm_group(wg_in)))
+        else:
+            self._side(lambda: hip.gemm_group([wg_out] + wg_in))
         calls = []
         if acc_qk is not None:
             calls.append(hip.linear_dgrad_call(dQKV[:, 0:2 * D], W[0:2 * D], acc_qk, residual=acc_qk))
@@ -531,6 +589,11 @@ class DetrEngine:
         dp, dseed = self._drop
         B, H, W, _ = images.shape
         self._shape = (B, H, W)
+        if dp > 0.0:
+            hf, wf = H, W
+            for _ in range(5):                                   # stem conv, max-pool, layer2..4: each ceil(n / 2)
+                hf, wf = (hf - 1) // 2 + 1, (wf - 1) // 2 + 1
+            self._gen_dropmasks(B, hf * wf)
         self.images = images
         V = self.P.views
         self.phase("fwd backbone")
@@ -648,7 +711,8 @@ class DetrEngine:
         ct = self._cross_tables()
         if self._stale(f"cross:{self.compute}"):
             hip.multi_copy(ct["gather"])
-        KV = self.buf("dec:KV", (B * L, 2 * nd * D))
+        a16 = self.attn16
+        KV = self.buf("dec:KV16" if a16 else "dec:KV", (B * L, 2 * nd * D), torch.bfloat16 if a16 else torch.float32)
         # (second stream: the first decoder self-attention block -- 800-row kernels -- does not need it)
         self._side(lambda: hip.gemm_group([hip.linear_fwd_call(mem_pos, ct["Wkv"][0:nd * D], ct["bkv"][0:nd * D], KV[:, 0:nd * D]),
                                            hip.linear_fwd_call(memory, ct["Wkv"][nd * D:], ct["bkv"][nd * D:], KV[:, nd * D:])]))
@@ -667,14 +731,15 @@ class DetrEngine:
             # cross attention: Q from this layer, K / V column blocks of the shared projection buffer
             cp = f"{pfx}/multihead_attn"
             Wc, bc = self._w(f"{cp}/in_proj_kernel"), V[f"{cp}/in_proj_bias"]
-            Qc = self.buf(f"{tag}:ca:Q", (B * Q, D))
-            hip.linear_fwd(q2, Wc[0:D], bc[0:D], Qc)
+            Qc = self.buf(f"{tag}:ca:Q16" if a16 else f"{tag}:ca:Q", (B * Q, D), torch.bfloat16 if a16 else torch.float32)
+            hip.linear_fwd(q2, Wc[0:D], bc[0:D], Qc, alpha=QK_ALPHA if a16 else 1.0)
             if i == 0:
                 self._side_join()                                # K / V of all layers
-            Oc = self.buf(f"{tag}:ca:O", (B * Q, D))
+            Oc = self.buf(f"{tag}:ca:O16" if a16 else f"{tag}:ca:O", (B * Q, D), torch.bfloat16 if a16 else torch.float32)
             lse = self.buf(f"{tag}:ca:lse", (B * HEADS, Q))
             hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, lse, B, HEADS, Q, L,
-                          scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev)
+                          scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev,
+                          dropmask=self._dropmask(ds + 2, B, Q, L) if (a16 and dp > 0.0) else None)
             a2 = self.buf(f"{tag}:a2", (B * Q, D))
             t2 = self.buf(f"{tag}:t2", (B * Q, D))
             t2h = self.buf(f"{tag}:t2h", (B * Q, D), torch.bfloat16) if self.ffn16 else None
@@ -773,12 +838,14 @@ class DetrEngine:
         nd = self.num_dec
         memory = self._bufs[f"enc{self.num_enc - 1}:x2"] if self.num_enc > 0 else self._bufs["enc:src0"]
         mem_pos = self._bufs["dec:mem_pos"] if self.num_enc > 0 else self._bufs["enc0:qk"]
-        KV = self._bufs["dec:KV"]
+        a16 = self.attn16
+        adt16 = torch.bfloat16 if a16 else torch.float32
+        KV = self._bufs["dec:KV16" if a16 else "dec:KV"]
         ct = self._cross_tables()
         qpos, g_qpos = V["query_embed/kernel"], G["query_embed/kernel"]
         BQ = B * Q
         dp, _ = self._drop
-        dKV = self.buf("scratch:dKV", (B * L, 2 * nd * D))           # every column block is written by its layer's attention backward
+        dKV = self.buf(f"scratch:dKV:{int(a16)}", (B * L, 2 * nd * D), adt16)      # every column block is written by its layer's attention backward
         acc_qpos = self.buf("scratch:acc_qpos", (BQ, D))             # sum over layers / sites of d(tgt + query_pos): query_pos gradient
         hip.zero_(acc_qpos)
         d_next = None                       # gradient flowing into t3 of layer i from layer i+1
@@ -802,14 +869,15 @@ class DetrEngine:
             d_out = self._ln_bwd(d_t2, a2, f"{pfx}/norm2", d_a2, f"{tag}:ln2", drop_site=ds + 3)
             # ---- cross attention
             Wc = self._w(f"{cp}/in_proj_kernel")
-            Qc, Oc = self._bufs[f"{tag}:ca:Q"], self._bufs[f"{tag}:ca:O"]
-            dO = self.buf(f"scratch:dO:{BQ}", (BQ, D))
+            Qc, Oc = self._bufs[f"{tag}:ca:Q16" if a16 else f"{tag}:ca:Q"], self._bufs[f"{tag}:ca:O16" if a16 else f"{tag}:ca:O"]
+            dO = self.buf(f"scratch:dO:{BQ}:{int(a16)}", (BQ, D), adt16)
             hip.linear_dgrad(d_out, self._w(f"{cp}/out_proj_kernel"), dO)
-            dQc = self.buf(f"scratch:dQc{self._sx(tag)}", (BQ, D))
-            delta = self.buf(f"scratch:delta:{BQ}", (B * HEADS, Q))
+            dQc = self.buf(f"scratch:dQc:{int(a16)}{self._sx(tag)}", (BQ, D), adt16)
+            delta = self.buf(f"scratch:delta:{BQ}", (2 * B * HEADS, Q))
             hip.attention(Qc, KV[:, i * D:(i + 1) * D], KV[:, (nd + i) * D:(nd + i + 1) * D], Oc, self._bufs[f"{tag}:ca:lse"],
                           B, HEADS, Q, L, scale=float(HD) ** -0.5, dropout_p=dp, dropout_site=ds + 2, dropout_step=self._seed_dev,
-                          d_o=dO, dq=dQc, dk=dKV[:, i * D:(i + 1) * D], dv=dKV[:, (nd + i) * D:(nd + i + 1) * D], delta=delta)
+                          d_o=dO, dq=dQc, dk=dKV[:, i * D:(i + 1) * D], dv=dKV[:, (nd + i) * D:(nd + i + 1) * D], delta=delta,
+                          dropmask=self._dropmask(ds + 2, B, Q, L) if (a16 and dp > 0.0) else None)
             self._side(lambda d_out=d_out, Oc=Oc, dQc=dQc, q2=q2, cp=cp: hip.gemm_group([
                 hip.linear_wgrad_call(d_out, Oc, G[f"{cp}/out_proj_kernel"], bias_grad=G[f"{cp}/out_proj_bias"]),
                 hip.linear_wgrad_call(dQc, q2, G[f"{cp}/in_proj_kernel"][0:D], bias_grad=G[f"{cp}/in_proj_bias"][0:D])]))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 7
+#define DETR_HIP_ABI_VERSION 8
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -373,9 +373,22 @@ typedef struct {
     /* 0 = exact fp32 MFMA; 1 = bf16 MFMA operands (Q, K, V, P, dO, dS rounded to bf16; accumulation, softmax
      * statistics, LSE, delta and outputs fp32; csrc/attention_bf16.hip) */
     int32_t compute;
+    /* ABI 8.  io_dtype = 1 (compute = 1 only; csrc/attention_dma.hip): q, k, v, o, d_o, dq, dk, dv point to bf16 data (uint16, RNE;
+     * row strides in elements, multiples of 8), `q` holds bf16(scale * log2(e) * q_unscaled) -- the projection GEMM's alpha -- and dq
+     * is still the gradient w.r.t. the UNSCALED q; lse stays fp32 and `delta` must hold 2*B*H*T floats (delta / keep-scale and
+     * lse * log2(e) - log2(keep-scale), handed from the dQ kernel to the dK / dV kernel).  With dropout_p > 0 the keep flags are read
+     * as BITS from `dropmask` (detr_hip_attention_dropmask_words(B, H, T, S) uint32 words), which detr_hip_attention_dropmask fills
+     * from (dropout_site, *dropout_step) -- the same function as the keyed counter hash above, evaluated once per step instead of in
+     * each of the three kernels. */
+    int32_t io_dtype;
+    uint32_t *dropmask;
 } detr_attn_desc;
 int detr_hip_attention_fwd(const detr_attn_desc *d, void *stream);
 int detr_hip_attention_bwd(const detr_attn_desc *d, void *stream);
+/* keep bits of the attention-probability dropout of one site and step (io_dtype = 1): uses B, H, T, S, dropout_p, dropout_site,
+ * dropout_step and dropmask of the descriptor */
+int64_t detr_hip_attention_dropmask_words(int32_t B, int32_t H, int32_t T, int32_t S);
+int detr_hip_attention_dropmask(const detr_attn_desc *d, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,
