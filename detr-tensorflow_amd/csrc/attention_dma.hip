@@ -41,12 +41,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int A2_TILE = 2048;            // one 32-row x 64-byte head tile image
 constexpr int A2_AUX = 256;              // one 64-lane x 4-byte piece (flag words / row statistics)
 constexpr int A2_RING = 3;
-constexpr float A2_THR = 6.0f;           // log2 units: the running reference moves when a tile maximum exceeds it by more than this
+constexpr float A2_SUM_LIMIT = 4096.0f;  // a lane's 16-key sum of exp2(score - reference) above this moves the reference (forward kernel)
 // timing experiments only (scripts/experiments/attn2_ablate.sh; results are WRONG with any bit set): 1 = no DMA requests inside the key loop,
 // 2 = no fragment reads / MFMAs / softmax inside the key loop, 4 = no softmax arithmetic (the scores go straight into the PV product)
 #ifndef A2_ABLATE
 #define A2_ABLATE 0
 #endif
+// (bit 8: the exponentials of the forward kernel as one v_add each -- what the transcendental rate costs)
+__device__ __forceinline__ float a2_exp2(float x) { return (A2_ABLATE & 8) ? x + 1.0f : __builtin_amdgcn_exp2f(x); }
 
 struct Attn2Args {
     const unsigned short *Q, *K, *V;
@@ -54,8 +56,8 @@ struct Attn2Args {
     float *LSE;
     const unsigned short *dO;
     unsigned short *dQ, *dK, *dV;
-    float *stats;                        // [2][B*H*T]: delta / scale | lse * log2 e - log2 scale
-    const uint32_t *maskQ, *maskK;       // keep bits, see attn2_dropmask_kernel
+    float *stats;                        // [2][B*H*T]: delta / scale | -(lse * log2 e - log2 scale)
+    const uint32_t *maskQ;               // keep bits, see attn2_dropmask_kernel
     int B, H, T, S;
     long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;     // row strides in elements
     float qscale, drop_scale;
@@ -155,6 +157,12 @@ __device__ __forceinline__ float a2_keep(float x, unsigned w) {
     asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"((R & 3) + 8 * (R >> 2)));
     return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
 }
+// the same with the bit index in a register (the dK / dV kernel: bit = the lane's key)
+__device__ __forceinline__ float a2_keep_bit(float x, unsigned w, int bit) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "v"(bit));
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+}
 template <int... R>
 __device__ __forceinline__ void a2_keep16(float (&p)[16], unsigned w, std::integer_sequence<int, R...>) {
     ((p[R] = a2_keep<R>(p[R], w)), ...);
@@ -242,7 +250,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int s = 0; s < 2; ++s) qb[c][s] = a2_ld_row8(Qb, a.ldq, q0 + 32 * c + l31, a.T, 16 * s + 8 * hi);
 
     const float lg2scale = DROP ? __log2f(a.drop_scale) : 0.0f;
-    const float thr = A2_THR + lg2scale;
     f32x16 o[2], negm[2];
     float lsum[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -284,30 +291,52 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     if ((r & 3) + 8 * (r >> 2) >= nv) s[c][r] = -INFINITY;
             }
             if constexpr ((A2_ABLATE & 4) != 0) {
-                float p[16];
+                float pa[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = s[c][r];
-                o[c] = A2_MFMA(v0, a2_pack8(p), o[c]);
-                o[c] = A2_MFMA(v1, a2_pack8(p + 8), o[c]);
+                for (int r = 0; r < 16; ++r) pa[r] = s[c][r];
+                o[c] = A2_MFMA(v0, a2_pack8(pa), o[c]);
+                o[c] = A2_MFMA(v1, a2_pack8(pa + 8), o[c]);
                 continue;
             }
-            const float mx = halves_max(tree_max16(s[c]));
-            if (first || __builtin_amdgcn_ballot_w64(mx > thr) != 0ull) {
-                // move the reference: exactly to the maximum in a run's first tile (o = l = 0 there), upwards only afterwards
-                const float d = first ? mx - lg2scale : fmaxf(mx - lg2scale, 0.0f);
-                const float corr = first ? 0.0f : fast_exp2(-d);
-                lsum[c] *= corr;
+            if (first) {
+                // a run's first tile sets the reference exactly to its maximum (o = l = 0 there)
+                A2_NO_IFCVT();
+                const float d = halves_max(tree_max16(s[c])) - lg2scale;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    o[c][r] *= corr;
                     negm[c][r] -= d;
                     s[c][r] -= d;
                 }
             }
             float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[c][r]);
-            lsum[c] += tree_sum16(p);
+            for (int r = 0; r < 16; ++r) p[r] = a2_exp2(s[c][r]);
+            float ls = tree_sum16(p);
+            // No maximum per tile: the lane's 16-key sum bounds every exponential in it.  Only when a sum leaves the safe range
+            // (or is inf / NaN) -- a score far above everything seen so far -- the reference moves up and the tile is redone
+            if (__builtin_amdgcn_ballot_w64(!(ls <= A2_SUM_LIMIT)) != 0ull) {
+                A2_NO_IFCVT();
+                // (the scores are recomputed from the stage rather than kept alive across the exponentials: 16 registers in the hot path)
+                f32x16 s2 = A2_MFMA(a2_frag_row(st, fr, 0), qb[c][0], negm[c]);
+                s2 = A2_MFMA(a2_frag_row(st, fr, 1), qb[c][1], s2);
+                if (ragged) {
+                    const int nv = a.S - kbase - 4 * hi;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((r & 3) + 8 * (r >> 2) >= nv) s2[r] = -INFINITY;
+                }
+                const float d = fmaxf(halves_max(tree_max16(s2)) - lg2scale, 0.0f);
+                const float corr = a2_exp2(-d);
+                lsum[c] *= corr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[c][r] *= corr;
+                    negm[c][r] -= d;
+                    p[r] = a2_exp2(s2[r] - d);
+                }
+                ls = tree_sum16(p);
+            }
+            lsum[c] += ls;
             if constexpr (DROP) a2_keep16(p, w[c]);
             o[c] = A2_MFMA(v0, a2_pack8(p), o[c]);
             o[c] = A2_MFMA(v1, a2_pack8(p + 8), o[c]);
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int c = 0; c < 2; ++c) {
                 const float mb = cb[(18 * c) * 64], lb = cb[(18 * c + 1) * 64];
                 const float mn = fmaxf(m[c], mb);
-                const float ca = fast_exp2(m[c] - mn), cbf = fast_exp2(mb - mn);       // (a run without keys: m = -inf, l = 0)
+                const float ca = a2_exp2(m[c] - mn), cbf = a2_exp2(mb - mn);       // (a run without keys: m = -inf, l = 0)
                 l[c] = l[c] * ca + lb * cbf;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[c][r] = o[c][r] * ca + cb[(18 * c + 2 + r) * 64] * cbf;
@@ -433,14 +462,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dlq[c] = dl * inv_scale;
         if (ok && hi == 0 && kp == 0) {
             a.stats[(long long)bh * a.T + tq] = dlq[c];
-            a.stats[(long long)a.B * a.H * a.T + (long long)bh * a.T + tq] = Lq[c];
+            a.stats[(long long)a.B * a.H * a.T + (long long)bh * a.T + tq] = -Lq[c];       // (negated: the dK / dV kernel feeds it to its MFMAs as C)
         }
     }
-    f32x16 dq[2];
+    f32x16 dq[2], negL[2];               // -L' is the C operand of the first score MFMA: exp2(s - L') costs no subtraction
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[c][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { dq[c][r] = 0.0f; negL[c][r] = -Lq[c]; }
 
     auto tile = [&](auto stg_c, int i) {
         constexpr int STG = decltype(stg_c)::value;
@@ -454,8 +483,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[c][r] = 0.0f; dp[c][r] = 0.0f; }
-            s[c] = A2_MFMA(k0, qb[c][0], s[c]);
+            for (int r = 0; r < 16; ++r) dp[c][r] = 0.0f;
+            s[c] = A2_MFMA(k0, qb[c][0], negL[c]);
             dp[c] = A2_MFMA(vr0, dob[c][0], dp[c]);
             s[c] = A2_MFMA(k1, qb[c][1], s[c]);
             dp[c] = A2_MFMA(vr1, dob[c][1], dp[c]);
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) dpm[r] = dp[c][r];
             if constexpr (DROP) a2_keep16(dpm, w[c]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[c][r] - Lq[c]) * (dpm[r] - dlq[c]);
+            for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[c][r]) * (dpm[r] - dlq[c]);
             if (ragged) {                               // (zero K rows make s = 0: exp2(-Lq) may be anything)
                 A2_NO_IFCVT();
                 const int nv = a.S - kbase - 4 * hi;
@@ -549,20 +578,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long long BHT = (long long)a.B * a.H * a.T;
     const u32x4 srs = ring_rsrc(a.stats, (unsigned)(2 * BHT * 4));
     const unsigned svoff = (unsigned)(((hi ? 0ll : BHT) + (long long)bh * a.T + l31) * 4);
-    // flag words: [bh][query tile][Sp32], lane -> key key0 + lane (chain = lane >> 5)
-    const int Sp32 = ((a.S + 31) / 32) * 32;
+    // flag words [bh][key tile][Tp] (bit = key): lanes 0..31 <- the words of (key tile of chain 0, queries tile * 32 + l31), lanes 32..63 <- chain 1
+    const int Tp = ntiles * 32, nkt = (a.S + 31) / 32;
     u32x4 mrs = ring_rsrc(nullptr, 0);
     unsigned mvoff = 0;
     if constexpr (DROP) {
-        mrs = ring_rsrc(a.maskK + (long long)bh * ntiles * Sp32, (unsigned)((long long)t1 * Sp32 * 4));
-        mvoff = (unsigned)min(key0 + lane, Sp32 - 1) * 4u;
+        mrs = ring_rsrc(a.maskQ + (long long)bh * nkt * Tp, (unsigned)((long long)nkt * Tp * 4));
+        const int kt = min(key0 / 32 + hi, nkt - 1);            // (a second chain past the last key tile: any words, its keys are not stored)
+        mvoff = (unsigned)(kt * Tp + l31) * 4u;
     }
     auto issue = [&](int stg, int tile) {
         const unsigned st = ring_lds + (unsigned)(stg * STAGE);
         qsrc.issue(st, tile);
         dsrc.issue(st + A2_TILE, tile);
         a2_dma4(srs, st + 2 * A2_TILE, (tile < t1) ? svoff + (unsigned)tile * 128u : BUF_OOB);
-        if constexpr (DROP) a2_dma4(mrs, st + 2 * A2_TILE + A2_AUX, mvoff + (unsigned)tile * (unsigned)Sp32 * 4u);
+        if constexpr (DROP) a2_dma4(mrs, st + 2 * A2_TILE + A2_AUX, (tile < t1) ? mvoff + (unsigned)tile * 128u : BUF_OOB);
     };
     issue(0, t0);
     issue(1, t0 + 1);
@@ -596,13 +626,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bf16x8 qc0 = a2_frag_col(st, fr, 0), qc1 = a2_frag_col(st, fr, 1);
         const bf16x8 dc0 = a2_frag_col(st + A2_TILE, fr, 0), dc1 = a2_frag_col(st + A2_TILE, fr, 1);
         // lse' / delta' of the 16 queries krow(r, hi): four runs of four consecutive floats each
-        float Lr[16], Dr[16];
+        f32x16 negLr;                   // -lse' of the lane's 16 queries = the C operand of the score MFMAs (register r <-> query krow(r, hi))
+        float Dr[16];
         const float *sl = reinterpret_cast<const float *>(st + 2 * A2_TILE);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 x = *reinterpret_cast<const float4 *>(sl + 8 * g + 4 * hi);
             const float4 y = *reinterpret_cast<const float4 *>(sl + 32 + 8 * g + 4 * hi);
-            Lr[4 * g] = x.x; Lr[4 * g + 1] = x.y; Lr[4 * g + 2] = x.z; Lr[4 * g + 3] = x.w;
+            negLr[4 * g] = x.x; negLr[4 * g + 1] = x.y; negLr[4 * g + 2] = x.z; negLr[4 * g + 3] = x.w;
             Dr[4 * g] = y.x; Dr[4 * g + 1] = y.y; Dr[4 * g + 2] = y.z; Dr[4 * g + 3] = y.w;
         }
         const bool ragged = qbase + 32 > a.T;           // wave-uniform: the last query tile only
@@ -610,20 +641,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int c = 0; c < 2; ++c) {
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            s = A2_MFMA(qr0, kb[c][0], s);
+            for (int r = 0; r < 16; ++r) dp[r] = 0.0f;
+            s = A2_MFMA(qr0, kb[c][0], negLr);
             dp = A2_MFMA(dr0, vb[c][0], dp);
             s = A2_MFMA(qr1, kb[c][1], s);
             dp = A2_MFMA(dr1, vb[c][1], dp);
-            unsigned w = 0u;
-            if constexpr (DROP) w = *reinterpret_cast<const unsigned *>(st + 2 * A2_TILE + A2_AUX + 128 * c + 4 * l31) >> (4 * hi);
             float p[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = fast_exp2(s[r] - Lr[r]);                                 // P (* scale with dropout)
+                p[r] = fast_exp2(s[r]);                                         // P (* scale with dropout)
                 ds[r] = -(p[r] * Dr[r]);
             }
-            if constexpr (DROP) a2_keep16(p, w);                                // dV uses the dropped probabilities
+            if constexpr (DROP) {                                               // dV uses the dropped probabilities
+                // the flag of (query krow(r, hi), this lane's key) is bit l31 of that query's word: one broadcast read per four queries
+                const unsigned *mw = reinterpret_cast<const unsigned *>(st + 2 * A2_TILE + A2_AUX + 128 * c);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 wq = *reinterpret_cast<const uint4 *>(mw + 8 * g + 4 * hi);
+                    p[4 * g] = a2_keep_bit(p[4 * g], wq.x, l31);
+                    p[4 * g + 1] = a2_keep_bit(p[4 * g + 1], wq.y, l31);
+                    p[4 * g + 2] = a2_keep_bit(p[4 * g + 2], wq.z, l31);
+                    p[4 * g + 3] = a2_keep_bit(p[4 * g + 3], wq.w, l31);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = __builtin_fmaf(p[r], dp[r], ds[r]);   // (P scale) ((keep ? dP : 0) - delta / scale)
             if (ragged) {                               // (zero Q / dO rows and a neighbour's statistics: exp2 may be anything)
@@ -679,20 +719,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// dropout keep bits of one attention site and step (common.h::drop_keep of element (row * Sp + key), row = bh * T + query)
-//   maskQ[(bh * nkt + kt) * Tp + q]      bit j = keep(q, kt * 32 + j)        Tp = 32 ceil(T / 32), nkt = ceil(S / 32)
-//   maskK[(bh * nqt + qt) * Sp32 + k]    bit j = keep(qt * 32 + j, k)        Sp32 = 32 ceil(S / 32), nqt = ceil(T / 32)
-// A wave owns 64 queries (lane = query) x one key tile: 16 pair hashes per lane give its maskQ word; the transposed words are the
-// ballots of its bits (lanes 0..31 = query tile 2 x, lanes 32..63 = query tile 2 x + 1), collected one per lane and stored.
+// dropout keep bits of one attention site and step (common.h::drop_keep of element (row * Sp + key), row = bh * T + query):
+//   mask[(bh * nkt + kt) * Tp + q]      bit j = keep(q, kt * 32 + j)        Tp = 32 ceil(T / 32), nkt = ceil(S / 32)
+// One lane per (query, key tile): 16 pair hashes give its word.  All three kernels read this layout (the forward / dQ kernels one
+// word per lane and tile, the dK / dV kernel -- whose lanes own keys -- the words of its 16 queries with the lane's key as the bit index).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn2_dropmask_kernel(uint32_t *maskQ, uint32_t *maskK, int BH, int T, int S, uint32_t thresh16,
-                                                             uint32_t site, const uint32_t *step) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nkt = (S + 31) / 32, nqt = (T + 31) / 32, Tp = nqt * 32, Sp32 = nkt * 32;
-    const int kt = blockIdx.x * 4 + wave, xq = blockIdx.y, bh = blockIdx.z;
-    if (kt >= nkt) return;
+__global__ __launch_bounds__(256) void attn2_dropmask_kernel(uint32_t *mask, int BH, int T, int S, uint32_t thresh16, uint32_t site,
+                                                             const uint32_t *step) {
+    const int nkt = (S + 31) / 32, Tp = ((T + 31) / 32) * 32;
+    const int q = blockIdx.x * 256 + threadIdx.x, kt = blockIdx.y, bh = blockIdx.z;
+    if (q >= Tp) return;
     const uint32_t key = drop_key(site, step);
-    const int q = xq * 64 + lane;
     const unsigned long long Sp = (unsigned long long)((S + 1) & ~1);
     const unsigned long long pb = (((unsigned long long)bh * T + q) * Sp + (unsigned)(kt * 32)) >> 1;
     uint32_t w = 0;
@@ -702,16 +739,7 @@ __global__ __launch_bounds__(256) void attn2_dropmask_kernel(uint32_t *maskQ, ui
         w |= ((hsh & 0xFFFFu) >= thresh16 ? 1u : 0u) << (2 * i);
         w |= ((hsh >> 16) >= thresh16 ? 1u : 0u) << (2 * i + 1);
     }
-    if (q < Tp) maskQ[((long long)bh * nkt + kt) * Tp + q] = w;
-    uint32_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(((w >> j) & 1u) != 0u);
-        mine = (lane == j) ? (uint32_t)bal : mine;
-        mine = (lane == 32 + j) ? (uint32_t)(bal >> 32) : mine;
-    }
-    const int qt = 2 * xq + (lane >> 5);
-    if (qt < nqt) maskK[((long long)bh * nqt + qt) * Sp32 + kt * 32 + (lane & 31)] = mine;
+    mask[((long long)bh * nkt + kt) * Tp + q] = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,22 +749,16 @@ static int a2_stage_bytes(int kind, bool drop) {       // kind 0: forward / dQ, 
     return 2 * A2_TILE + (kind ? A2_AUX : 0) + (drop ? A2_AUX : 0);
 }
 
-// waves per workgroup (runs of the streamed dimension).  The aim: enough waves to fill the chip several times over with short
-// units -- a wave of two chains at ~150 (forward) / ~200 (backward) VGPRs leaves room for 3 / 2 per SIMD, and whole "rounds" of
-// resident waves quantise badly when a unit is long -- but at least 4 streamed tiles per run.  DETR_HIP_ATTN_SPLIT=n forces.
-static int a2_parts(int blocks, int tiles, int per_simd) {
+// waves per workgroup (runs of the streamed dimension).  Measured (scripts/micro_attn2.py, profiles/r06_micro_attn2.txt): four runs are
+// best or within 3 % of the best on every shape of the step (encoder 1050 x 1050: forward 49 / 32 / 30 / 30 / 48 us at 5 / 2 / 3 / 4 / 6 runs --
+// from five runs on, a workgroup's rings leave room for two workgroups per CU only); short streams keep at least 4 tiles per run.
+// DETR_HIP_ATTN_SPLIT=n forces.
+static int a2_parts(int blocks, int tiles) {
     const int force = tune(T_ATTN_SPLIT);
-    int p;
-    if (force >= 1 && force <= 8) p = force;
-    else {
-        const long long target = 1024ll * per_simd * 3 / 2;      // 1.5 rounds of resident waves
-        p = (int)((target + blocks - 1) / blocks);
-    }
+    int p = (force >= 1 && force <= 8) ? force : 4;
     const int cap = tiles >= 4 ? tiles / 4 : 1;
     if (p > cap) p = cap;
-    if (p > 8) p = 8;
-    if (p < 1) p = 1;
-    return p;
+    return p < 1 ? 1 : p;
 }
 
 template <typename K>
@@ -760,7 +782,7 @@ int attn2_fwd_launch(Attn2Args a, hipStream_t s) {
     int nblk, blocks;
     a2_grid(a, a.T, nblk, blocks);
     const bool drop = a.drop_scale != 0.0f;
-    a.parts = a2_parts(blocks, cdiv(a.S, 32), 3);
+    a.parts = a2_parts(blocks, cdiv(a.S, 32));
     const int lds = a.parts * A2_RING * a2_stage_bytes(0, drop);
     if (drop) { if (a2_launch(attn2_fwd_kernel<true>, a, blocks, lds, s, "attention fwd (bf16 io)")) return -1; }
     else if (a2_launch(attn2_fwd_kernel<false>, a, blocks, lds, s, "attention fwd (bf16 io)")) return -1;
@@ -772,13 +794,13 @@ int attn2_bwd_launch(Attn2Args a, hipStream_t s) {
     int nblk, blocks;
     const bool drop = a.drop_scale != 0.0f;
     a2_grid(a, a.T, nblk, blocks);
-    a.parts = a2_parts(blocks, cdiv(a.S, 32), 2);
+    a.parts = a2_parts(blocks, cdiv(a.S, 32));
     int lds = a.parts * A2_RING * a2_stage_bytes(0, drop);
     if (drop) { if (a2_launch(attn2_bwd_dq_kernel<true>, a, blocks, lds, s, "attention bwd dq (bf16 io)")) return -1; }
     else if (a2_launch(attn2_bwd_dq_kernel<false>, a, blocks, lds, s, "attention bwd dq (bf16 io)")) return -1;
     DETR_LAUNCH_CHECK("attention bwd dq (bf16 io)");
     a2_grid(a, a.S, nblk, blocks);
-    a.parts = a2_parts(blocks, cdiv(a.T, 32), 2);
+    a.parts = a2_parts(blocks, cdiv(a.T, 32));
     lds = a.parts * A2_RING * a2_stage_bytes(1, drop);
     if (drop) { if (a2_launch(attn2_bwd_dkv_kernel<true>, a, blocks, lds, s, "attention bwd dkv (bf16 io)")) return -1; }
     else if (a2_launch(attn2_bwd_dkv_kernel<false>, a, blocks, lds, s, "attention bwd dkv (bf16 io)")) return -1;
@@ -787,7 +809,7 @@ int attn2_bwd_launch(Attn2Args a, hipStream_t s) {
 }
 
 static long long a2_mask_words(int B, int H, int T, int S) {
-    return 2ll * B * H * cdiv(T, 32) * cdiv(S, 32) * 32;
+    return 1ll * B * H * cdiv(T, 32) * cdiv(S, 32) * 32;
 }
 
 static int a2_check_ld(long long ld, int H, const char *what) {
@@ -820,7 +842,6 @@ static int a2_from_desc(const detr_attn_desc *d, int bwd, Attn2Args &a) {
     a.drop_seed = d->dropout_site;
     a.drop_step = d->dropout_step;
     a.maskQ = d->dropmask;
-    a.maskK = d->dropmask ? d->dropmask + a2_mask_words(d->B, d->H, d->T, d->S) / 2 : nullptr;
     if (bwd) {
         DETR_REQUIRE(d->d_o && d->dq && d->dk && d->dv && d->delta, "attention bwd: null operand");
         if (a2_check_ld(d->ldd_o, d->H, "d_o") || a2_check_ld(d->lddq, d->H, "dq") || a2_check_ld(d->lddk, d->H, "dk") ||
@@ -862,10 +883,9 @@ extern "C" int detr_hip_attention_dropmask(const detr_attn_desc *d, void *stream
     DETR_REQUIRE(d->dropmask, "attention dropmask: null output");
     DETR_REQUIRE(d->dropout_p > 0.0f && d->dropout_p < 1.0f, "attention dropmask: dropout p=%f out of range", d->dropout_p);
     const int bh = d->B * d->H;
-    DETR_REQUIRE(bh <= 65535 && cdiv(d->T, 64) <= 65535, "attention dropmask: grid too large");
-    const long long half = a2_mask_words(d->B, d->H, d->T, d->S) / 2;
-    const dim3 grid((unsigned)cdiv(cdiv(d->S, 32), 4), (unsigned)cdiv(d->T, 64), (unsigned)bh);
-    hipLaunchKernelGGL(attn2_dropmask_kernel, grid, dim3(256), 0, (hipStream_t)stream, d->dropmask, d->dropmask + half, bh, d->T, d->S,
+    DETR_REQUIRE(bh <= 65535 && cdiv(d->S, 32) <= 65535, "attention dropmask: grid too large");
+    const dim3 grid((unsigned)cdiv(cdiv(d->T, 32) * 32, 256), (unsigned)cdiv(d->S, 32), (unsigned)bh);
+    hipLaunchKernelGGL(attn2_dropmask_kernel, grid, dim3(256), 0, (hipStream_t)stream, d->dropmask, bh, d->T, d->S,
                        drop_thresh16(d->dropout_p), d->dropout_site, d->dropout_step);
     DETR_LAUNCH_CHECK("attention dropmask");
     return 0;

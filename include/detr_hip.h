@@ -377,7 +377,8 @@ typedef struct {
      * row strides in elements, multiples of 8), `q` holds bf16(scale * log2(e) * q_unscaled) -- the projection GEMM's alpha -- and dq
      * is still the gradient w.r.t. the UNSCALED q; lse stays fp32 and `delta` must hold 2*B*H*T floats (delta / keep-scale and
      * lse * log2(e) - log2(keep-scale), handed from the dQ kernel to the dK / dV kernel).  With dropout_p > 0 the keep flags are read
-     * as BITS from `dropmask` (detr_hip_attention_dropmask_words(B, H, T, S) uint32 words), which detr_hip_attention_dropmask fills
+     * as BITS from `dropmask` (detr_hip_attention_dropmask_words(B, H, T, S) uint32 words: one word per (query, 32-key tile), word
+     * (bh * ceil(S/32) + tile) * 32 ceil(T/32) + query, bit = key), which detr_hip_attention_dropmask fills
      * from (dropout_site, *dropout_step) -- the same function as the keyed counter hash above, evaluated once per step instead of in
      * each of the three kernels. */
     int32_t io_dtype;
