@@ -252,14 +252,20 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = auto)")
     ap.add_argument("--grad-buckets", choices=("fp32", "bf16"), default="fp32",
                     help="N > 1: dtype of the gradient buckets on the wire (bf16 = half the bytes over xGMI, fp32 master update; parallel.DataParallel)")
+    ap.add_argument("--dp-timeout", type=float, default=float(os.environ.get("DETR_DP_TIMEOUT_S", "120")),
+                    help="N > 1: seconds a phase (rendezvous, a warm-up or timed step, a barrier) may take before the rank dumps its stacks and exits 1")
     ap.add_argument("--phase-events", action="store_true", help="after the timed region: 5 eager steps with HIP events at the phase "
                     "boundaries of the launch sequence (backbone / encoder / decoder / heads / set loss, forward and backward, optimiser)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves and relay rank 0's line
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        import socket
         import subprocess
-        port = 29500 + (os.getpid() % 2000)
+        sock = socket.socket()                      # a port that is free right now (a fixed one collides with a concurrent run)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
@@ -272,7 +278,11 @@ def main():
     from detr_tf.optimizers import setup_optimizers
     from detr_tf.training_config import TrainingConfig
 
-    rank, world = parallel.init_distributed(backend=args.dist_backend)
+    # N > 1: every phase is bounded (parallel.Watchdog: stack dump + exit 1 when a phase exceeds --dp-timeout seconds; the process
+    # group carries the same timeout), so a stalled or dead rank costs that long -- not the lease
+    wd = parallel.Watchdog(args.dp_timeout if (args.gpus > 1 or os.environ.get("DETR_DP_FORCE") == "1") else 0.0)
+    wd.feed("rendezvous")
+    rank, world = parallel.init_distributed(backend=args.dist_backend, timeout_s=args.dp_timeout)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -325,10 +335,13 @@ def main():
         out = model(images, training=False)
         return get_losses(out, tb, tc, cfg)[0]
 
-    def barrier():
+    def barrier(phase="barrier"):
         if world > 1:
-            dist.barrier()
+            parallel.checked_barrier(wd, phase)
         torch.cuda.synchronize()
+        wd.feed(phase + " passed")
+        if os.environ.get("DETR_BENCH_STALL_RANK") == str(rank) and phase == "timed region start":
+            time.sleep(10 * max(args.dp_timeout, 1.0))      # test hook: this rank never reaches the timed steps (tests/test_parallel_cpu.py)
 
     def timed(n, first=0):
         barrier()
@@ -344,6 +357,7 @@ def main():
     # warm-up: at least until the stepper's launch path is final ("auto": eager step, recording pass, 3 timed replays, 3 timed
     # eager steps -- all ordinary training steps; which path wins depends on the host, and the ranks agree through a MAX all-reduce)
     for i in range(max(args.warmup, stepper.settle_calls if args.mode == "train" else 1)):
+        wd.feed(f"warm-up step {i}")
         last = step(i)
         if i == 0 and loss_first is None:
             loss_first = last.clone()      # device scalar: read after the timed region
@@ -356,13 +370,14 @@ def main():
     ev_steps = 0 if (args.no_kernel_events or rank != 0 or args.mode != "train") else max(1, min(args.event_steps, args.steps))
     if ev_steps:
         prof = _hip.KernelProfiler(prealloc=1400 * ev_steps, f32=(args.precision == "fp32"))     # event objects exist before the timed region
-    barrier()
+    barrier("timed region start")
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof is not None and i == args.steps - ev_steps:
             _hip.PROFILER = prof
         last = step(args.warmup + i)
-    barrier()
+        wd.feed(f"timed step {i}")
+    barrier("timed region end")
     dt = time.perf_counter() - t0
     _hip.PROFILER = None
     loss_val = float(last)
@@ -557,8 +572,9 @@ def main():
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
-        dist.barrier()
+        parallel.checked_barrier(wd, "shutdown")
         dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

@@ -9,14 +9,67 @@ only exchange step of the hot path:
      collective overlaps the remaining backward.  xGMI is point-to-point, so few large buckets
      (~70 / 60 / 28 / 6 MB) are preferred over many small ones.
 """
+import datetime
+import faulthandler
 import os
+import socket
+import sys
 
 import torch
 import torch.distributed as dist
 
+# Every blocking step of the multi-process path is bounded (round 6): the process group carries a timeout (DETR_DP_TIMEOUT_S,
+# default 120 s: a rendezvous that never completes or a collective that a dead / stalled rank never joins raises instead of
+# waiting forever), and Watchdog below covers what a timeout inside the transport cannot -- a rank stuck in a device
+# synchronisation behind a collective kernel that spins on a peer.
+DEFAULT_TIMEOUT_S = float(os.environ.get("DETR_DP_TIMEOUT_S", "120"))
 
-def init_distributed(backend=None):
-    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (for launchers that pick MASTER_PORT themselves)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class Watchdog:
+    """Bounds the time between two `feed()` calls: when a phase takes longer than `timeout_s`, every thread's Python stack is
+    written to stderr and the process exits with status 1 (faulthandler.dump_traceback_later: a C-level timer thread that needs
+    neither the GIL nor a responsive main thread, so it also fires while the main thread sits in hipStreamSynchronize or inside a
+    collective).  Under torchrun the launcher then tears the other ranks down and returns non-zero: a stalled rank costs
+    `timeout_s`, not the lease.  timeout_s <= 0 disables it."""
+
+    def __init__(self, timeout_s=None, what="data-parallel step"):
+        self.timeout_s = DEFAULT_TIMEOUT_S if timeout_s is None else float(timeout_s)
+        self.what = what
+        self.armed = False
+
+    def feed(self, phase=""):
+        if self.timeout_s <= 0:
+            return
+        self.phase = phase
+        faulthandler.dump_traceback_later(self.timeout_s, repeat=False, file=sys.stderr, exit=True)
+        self.armed = True
+
+    def stop(self):
+        if self.armed:
+            faulthandler.cancel_dump_traceback_later()
+            self.armed = False
+
+    def __enter__(self):
+        self.feed("start")
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+        return False
+
+
+def init_distributed(backend=None, timeout_s=None):
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).  timeout_s (default DETR_DP_TIMEOUT_S = 120):
+    the process group's timeout -- rendezvous and every collective."""
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -27,12 +80,31 @@ def init_distributed(backend=None):
     os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
+    if "MASTER_PORT" not in os.environ:
+        # only a group of ONE may choose its own port (every rank of a larger group must be told the same one by its launcher)
+        if int(os.environ["WORLD_SIZE"]) > 1:
+            raise RuntimeError("init_distributed: WORLD_SIZE > 1 without MASTER_PORT (launch with torch.distributed.run, or set it)")
+        os.environ["MASTER_PORT"] = str(free_port())
     if torch.cuda.is_available():
         # one process per GPU; ranks wrap around when a test box has fewer devices than ranks (gloo only)
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-    dist.init_process_group(backend=backend)
+    t = DEFAULT_TIMEOUT_S if timeout_s is None else float(timeout_s)
+    dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=t))
     return dist.get_rank(), dist.get_world_size()
+
+
+def checked_barrier(watchdog=None, phase="barrier", group=None):
+    """dist.barrier() under the watchdog: gloo groups use monitored_barrier (names the ranks that did not arrive), RCCL groups rely
+    on the process-group timeout plus the watchdog."""
+    if not dist.is_initialized():
+        return
+    if watchdog is not None:
+        watchdog.feed(phase)
+    if dist.get_backend(group) == "gloo":
+        dist.monitored_barrier(group=group, timeout=datetime.timedelta(seconds=(watchdog.timeout_s if watchdog and watchdog.timeout_s > 0
+                                                                                  else DEFAULT_TIMEOUT_S)))
+    else:
+        dist.barrier(group=group)
 
 
 def shard_batch(global_batch, rank, world):

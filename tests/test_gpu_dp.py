@@ -196,6 +196,23 @@ def test_bench_two_ranks_gloo_prints_the_comm_fields(hip):
     assert all(b["allreduce_ms"] > 0 and b["handover_to_done_ms"] >= b["allreduce_ms"] * 0.5 for b in c["buckets"])
 
 
+def test_bench_with_a_stalled_rank_exits_nonzero_with_a_stack_dump(hip):
+    """a rank that never reaches the timed steps (DETR_BENCH_STALL_RANK: it sleeps behind the barrier that opens the
+    timed region) must cost the watchdog timeout, not the lease: the healthy rank's watchdog (parallel.Watchdog, --dp-timeout 20)
+    dumps every thread's stack and exits 1, torchrun tears the job down and returns non-zero -- well inside 120 s."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                    str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "1", "--height", "64",
+                    "--width", "96", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-kernel-events", "--launch", "eager",
+                    "--dp-timeout", "20"], env_extra={"DETR_BENCH_STALL_RANK": "1"}, timeout=300)
+    took = time.time() - t0
+    assert r.returncode != 0, "a stalled rank must not look like a finished benchmark"
+    assert not any(l.startswith("{") for l in r.stdout.splitlines()), "no result line may be printed"
+    assert "most recent call first" in r.stderr, r.stderr[-3000:]          # faulthandler's stack dump
+    assert took < 120.0, f"took {took:.0f} s"
+
+
 def test_bench_refuses_rank_count_mismatch(hip):
     """`python bench.py --gpus 2` spawns two ranks itself; on a 1-GPU box that must fail loudly, never print a 1-GPU number
     labelled n_gpus = 2."""

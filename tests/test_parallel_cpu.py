@@ -1,4 +1,4 @@
-"""CPU tests of the multi-process data-parallel path (gloo, world_size 2) and of the host logic
+"""CPU tests of the multi-process data-parallel path (gloo, world_size 2 / 4 / 8) and of the host logic
 that does not need a GPU (parameter store layout, buckets, config, positional encoding)."""
 import os
 import socket
@@ -67,6 +67,106 @@ def test_bucketed_allreduce_and_shards_gloo():
         assert np.array_equal(g, expect)
         assert np.allclose(s, [3.0, 4.0, 3.0])
         assert shard == (r * 32, (r + 1) * 32)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bucketed_allreduce_and_shards_at_4_and_8_ranks(world):
+    """SURVEY 4 planned 2-8 ranks: the same four-bucket exchange (one bucket empty), the normaliser all-reduce and the batch
+    shards at world sizes 4 and 8; every replica ends with the same bits."""
+    out = _run(_bucket_job, world)
+    k = world * (world + 1) // 2                                   # sum of (rank + 1)
+    expect = np.arange(1000, dtype=np.float32) * k
+    for r in range(world):
+        g, s, shard = out[r]
+        assert np.array_equal(g, expect)
+        assert np.allclose(s, [k, 2.0 * world, 3.0 * world * (world - 1) / 2])
+        assert shard == (r * (64 // world), (r + 1) * (64 // world))
+        assert np.array_equal(g, out[0][0]) and np.array_equal(s, out[0][1])
+
+
+def _replica_job(rank, world):
+    """Three steps of bucketed exchange + the oracle's Adam on every rank: replicas must stay bit-identical (fp32 and bf16 buckets)."""
+    from detr_tf import parallel
+    from oracle import optim_ref as O
+    n = 2048
+    res = {}
+    for dt in ("fp32", "bf16"):
+        w = {"w": np.linspace(-1.0, 1.0, n).astype(np.float32)}
+        opt = O.Adam(1e-3, clipnorm=0.1)
+        for step in range(3):
+            gen = torch.Generator().manual_seed(1000 * step + rank)
+            grad = torch.randn(n, generator=gen)
+            dp = parallel.DataParallel(grad, [(0, 700), (700, 1500), (1500, 1500), (1500, n)], bucket_dtype=dt)
+            for i in range(4):
+                dp.on_bucket(i)
+            dp.finish()
+            opt.apply({"w": grad.numpy()}, w)
+        res[dt] = w["w"].copy()
+    return res["fp32"], res["bf16"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_replicas_stay_bit_identical_over_steps_at_4_and_8_ranks(world):
+    out = _run(_replica_job, world)
+    for r in range(1, world):
+        assert np.array_equal(out[r][0], out[0][0]), f"fp32 buckets: rank {r} drifted"
+        assert np.array_equal(out[r][1], out[0][1]), f"bf16 buckets: rank {r} drifted"
+    assert not np.array_equal(out[0][0], out[0][1])                # (the bf16 exchange is a different, coarser sum)
+
+
+def _stall_worker(rank, world, port, timeout_s):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "detr-tensorflow_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from detr_tf import parallel
+    wd = parallel.Watchdog(timeout_s)
+    wd.feed("rendezvous")
+    parallel.init_distributed(backend="gloo", timeout_s=timeout_s)
+    parallel.checked_barrier(wd, "first barrier")
+    if rank == 1:
+        time.sleep(60)                    # the stalled rank
+    parallel.checked_barrier(wd, "second barrier")
+    wd.stop()
+
+
+def test_a_stalled_rank_is_detected_within_the_timeout():
+    """parallel.Watchdog + the process-group timeout: rank 1 of 2 sleeps in front of a barrier; rank 0 must give up within the
+    timeout (monitored_barrier names the missing rank, or the watchdog dumps the stacks and exits 1) instead of waiting forever."""
+    import subprocess
+    import sys
+    import time
+    code = ("import sys; sys.path.insert(0, %r); import tests.test_parallel_cpu as t; "
+            "t._stall_worker(int(sys.argv[1]), 2, int(sys.argv[2]), 5.0)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port)], stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    try:
+        _, err0 = procs[0].communicate(timeout=45)
+    finally:
+        for p in procs:
+            p.kill()
+    took = time.time() - t0
+    assert procs[0].returncode not in (0, None), "the healthy rank must fail, not hang or succeed"
+    assert took < 45.0
+    assert ("most recent call first" in err0) or ("Rank 1" in err0) or ("rank 1" in err0), err0[-2000:]
+
+
+def test_free_port_and_single_rank_group_without_master_port():
+    """parallel.free_port() returns a bindable port; a forced single-rank group picks one by itself (no fixed 29500)."""
+    import socket
+    import subprocess
+    import sys
+    from_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['DETR_DP_FORCE'] = '1'; os.environ.pop('MASTER_PORT', None); "
+            "from detr_tf import parallel; p = parallel.free_port(); import socket; s = socket.socket(); s.bind(('127.0.0.1', p)); s.close(); "
+            "r, w = parallel.init_distributed(backend='gloo'); assert (r, w) == (0, 1); assert os.environ['MASTER_PORT'] != '29500'; "
+            "import torch.distributed as d; d.destroy_process_group(); print('ok')") % os.path.join(from_root, "detr-tensorflow_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
 
 
 def _bf16_bucket_job(rank, world):
