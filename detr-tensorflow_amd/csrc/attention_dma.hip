@@ -724,22 +724,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // One lane per (query, key tile): 16 pair hashes give its word.  All three kernels read this layout (the forward / dQ kernels one
 // word per lane and tile, the dK / dV kernel -- whose lanes own keys -- the words of its 16 queries with the lane's key as the bit index).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn2_dropmask_kernel(uint32_t *mask, int BH, int T, int S, uint32_t thresh16, uint32_t site,
-                                                             const uint32_t *step) {
-    const int nkt = (S + 31) / 32, Tp = ((T + 31) / 32) * 32;
-    const int q = blockIdx.x * 256 + threadIdx.x, kt = blockIdx.y, bh = blockIdx.z;
-    if (q >= Tp) return;
-    const uint32_t key = drop_key(site, step);
-    const unsigned long long Sp = (unsigned long long)((S + 1) & ~1);
-    const unsigned long long pb = (((unsigned long long)bh * T + q) * Sp + (unsigned)(kt * 32)) >> 1;
+constexpr int A2_MASK_SITES = 32;        // attention sites one keep-bit launch covers (a DETR step has 18)
+struct A2MaskSite {
+    uint32_t *mask;
+    int T, S, nkt, Tp, xblocks;          // xblocks = ceil(Tp / 256)
+    uint32_t site;
+    long long block0;                    // first workgroup of this site in the launch
+};
+struct A2MaskArgs {
+    A2MaskSite s[A2_MASK_SITES];
+    int n, BH;
+    uint32_t thresh16;
+    const uint32_t *step;
+};
+__global__ __launch_bounds__(256) void attn2_dropmask_kernel(A2MaskArgs a) {
+    int si = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n; ++i)
+        if ((long long)blockIdx.x >= a.s[i].block0) si = i;
+    const A2MaskSite &m = a.s[si];
+    const long long lb = (long long)blockIdx.x - m.block0;               // (x block, key tile, problem) of this site
+    const int xb = (int)(lb % m.xblocks);
+    const int kt = (int)((lb / m.xblocks) % m.nkt), bh = (int)(lb / ((long long)m.xblocks * m.nkt));
+    const int q = xb * 256 + threadIdx.x;
+    if (q >= m.Tp) return;
+    const uint32_t key = drop_key(m.site, a.step);
+    const unsigned long long Sp = (unsigned long long)((m.S + 1) & ~1);
+    const unsigned long long pb = (((unsigned long long)bh * m.T + q) * Sp + (unsigned)(kt * 32)) >> 1;
     uint32_t w = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint32_t hsh = drop_hash(key, pb + i);
-        w |= ((hsh & 0xFFFFu) >= thresh16 ? 1u : 0u) << (2 * i);
-        w |= ((hsh >> 16) >= thresh16 ? 1u : 0u) << (2 * i + 1);
+        w |= ((hsh & 0xFFFFu) >= a.thresh16 ? 1u : 0u) << (2 * i);
+        w |= ((hsh >> 16) >= a.thresh16 ? 1u : 0u) << (2 * i + 1);
     }
-    mask[((long long)bh * nkt + kt) * Tp + q] = w;
+    m.mask[((long long)bh * m.nkt + kt) * m.Tp + q] = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -876,17 +895,39 @@ extern "C" int64_t detr_hip_attention_dropmask_words(int32_t B, int32_t H, int32
     return detr::a2_mask_words(B, H, T, S);
 }
 
-extern "C" int detr_hip_attention_dropmask(const detr_attn_desc *d, void *stream) {
+extern "C" int detr_hip_attention_dropmask_many(const detr_attn_desc *d, int32_t n, void *stream) {
     using namespace detr;
-    DETR_REQUIRE(d, "attention dropmask: null descriptor");
-    DETR_REQUIRE(d->B > 0 && d->H > 0 && d->T > 0 && d->S > 0, "attention dropmask: bad shape B=%d H=%d T=%d S=%d", d->B, d->H, d->T, d->S);
-    DETR_REQUIRE(d->dropmask, "attention dropmask: null output");
-    DETR_REQUIRE(d->dropout_p > 0.0f && d->dropout_p < 1.0f, "attention dropmask: dropout p=%f out of range", d->dropout_p);
-    const int bh = d->B * d->H;
-    DETR_REQUIRE(bh <= 65535 && cdiv(d->S, 32) <= 65535, "attention dropmask: grid too large");
-    const dim3 grid((unsigned)cdiv(cdiv(d->T, 32) * 32, 256), (unsigned)cdiv(d->S, 32), (unsigned)bh);
-    hipLaunchKernelGGL(attn2_dropmask_kernel, grid, dim3(256), 0, (hipStream_t)stream, d->dropmask, bh, d->T, d->S,
-                       drop_thresh16(d->dropout_p), d->dropout_site, d->dropout_step);
-    DETR_LAUNCH_CHECK("attention dropmask");
+    DETR_REQUIRE(d && n >= 1, "attention dropmask: null descriptors");
+    int done = 0;
+    while (done < n) {
+        A2MaskArgs a;
+        a.n = (n - done) < A2_MASK_SITES ? (n - done) : A2_MASK_SITES;
+        long long blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const detr_attn_desc &e = d[done + i];
+            DETR_REQUIRE(e.B > 0 && e.H > 0 && e.T > 0 && e.S > 0, "attention dropmask: bad shape B=%d H=%d T=%d S=%d", e.B, e.H, e.T, e.S);
+            DETR_REQUIRE(e.dropmask, "attention dropmask: null output");
+            DETR_REQUIRE(e.dropout_p > 0.0f && e.dropout_p < 1.0f, "attention dropmask: dropout p=%f out of range", e.dropout_p);
+            DETR_REQUIRE(e.B * e.H == d[done].B * d[done].H && e.dropout_p == d[done].dropout_p && e.dropout_step == d[done].dropout_step,
+                         "attention dropmask: the sites of one call share B*H, the dropout rate and the step seed");
+            A2MaskSite &m = a.s[i];
+            m.mask = e.dropmask; m.T = e.T; m.S = e.S; m.nkt = cdiv(e.S, 32); m.Tp = cdiv(e.T, 32) * 32; m.xblocks = cdiv(m.Tp, 256);
+            m.site = e.dropout_site; m.block0 = blocks;
+            blocks += (long long)m.xblocks * m.nkt * e.B * e.H;
+        }
+        for (int i = a.n; i < A2_MASK_SITES; ++i) a.s[i] = a.s[0];
+        DETR_REQUIRE(blocks < 0x7FFFFFFFll, "attention dropmask: grid too large");
+        a.BH = d[done].B * d[done].H;
+        a.thresh16 = drop_thresh16(d[done].dropout_p);
+        a.step = d[done].dropout_step;
+        hipLaunchKernelGGL(attn2_dropmask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        DETR_LAUNCH_CHECK("attention dropmask");
+        done += a.n;
+    }
     return 0;
+}
+
+extern "C" int detr_hip_attention_dropmask(const detr_attn_desc *d, void *stream) {
+    DETR_REQUIRE(d, "attention dropmask: null descriptor");
+    return detr_hip_attention_dropmask_many(d, 1, stream);
 }

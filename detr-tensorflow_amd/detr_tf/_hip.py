@@ -137,6 +137,7 @@ _SIGNATURES = {
     "detr_hip_attention_fwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_attention_bwd": [POINTER(AttnDesc), c_void_p],
     "detr_hip_attention_dropmask": [POINTER(AttnDesc), c_void_p],
+    "detr_hip_attention_dropmask_many": [POINTER(AttnDesc), c_int32, c_void_p],
     "detr_hip_dropout_f32": [f32p, f32p, c_int64, c_float, ctypes.c_uint32, c_void_p, c_void_p],
     "detr_hip_multi_copy": [c_void_p, c_int32, c_int32, c_void_p],
     "detr_hip_colsum_scaled": [c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p],
@@ -751,6 +752,19 @@ def attention_dropmask(mask, B, H, T, S, *, dropout_p, dropout_site=0, dropout_s
         raise ValueError("attention_dropmask: buffer too small")
     d.dropmask = mask.data_ptr()
     _check(load().detr_hip_attention_dropmask(byref(d), _stream()), "detr_hip_attention_dropmask")
+
+
+def attention_dropmask_many(sites, B, H, *, dropout_p, dropout_step=None):
+    """sites: list of (mask tensor, T, S, site id) -- the keep bits of every attention site of a step from ONE launch."""
+    arr = (AttnDesc * len(sites))()
+    for i, (mask, T, S, site) in enumerate(sites):
+        d = arr[i]
+        d.B, d.H, d.T, d.S = B, H, T, S
+        d.dropout_p, d.dropout_site, d.dropout_step = dropout_p, site & 0xFFFFFFFF, ptr(dropout_step)
+        if mask.numel() * mask.element_size() < 4 * attention_dropmask_words(B, H, T, S):
+            raise ValueError("attention_dropmask_many: buffer too small")
+        d.dropmask = mask.data_ptr()
+    _check(load().detr_hip_attention_dropmask_many(arr, len(sites), _stream()), "detr_hip_attention_dropmask_many")
 
 
 def attention(q, k, v, o, lse, B, H, T, S, *, scale=1.0, dropout_p=0.0, dropout_site=0, dropout_step=None, compute=None,

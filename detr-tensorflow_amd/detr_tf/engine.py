@@ -396,8 +396,7 @@ class DetrEngine:
         bufs = [(site, T, S, self._dropmask(site, B, T, S)) for site, T, S in sites]       # (allocated on the main stream)
         self._mask_stream.wait_stream(main)
         with torch.cuda.stream(self._mask_stream):
-            for site, T, S, m in bufs:
-                hip.attention_dropmask(m, B, HEADS, T, S, dropout_p=dp, dropout_site=site, dropout_step=self._seed_dev)
+            hip.attention_dropmask_many([(m, T, S, site) for site, T, S, m in bufs], B, HEADS, dropout_p=dp, dropout_step=self._seed_dev)
         self._mask_pending = True
 
     def _join_dropmasks(self):

@@ -390,6 +390,8 @@ int detr_hip_attention_bwd(const detr_attn_desc *d, void *stream);
  * dropout_step and dropmask of the descriptor */
 int64_t detr_hip_attention_dropmask_words(int32_t B, int32_t H, int32_t T, int32_t S);
 int detr_hip_attention_dropmask(const detr_attn_desc *d, void *stream);
+/* the same for n sites of one step in ONE launch (they must share B*H, dropout_p and dropout_step; a DETR step has 18 sites) */
+int detr_hip_attention_dropmask_many(const detr_attn_desc *descs, int32_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian set loss (detr_tf/loss/hungarian_matching.py:163-203, detr_tf/loss/loss.py:22-179,

@@ -57,6 +57,19 @@ def test_attention_dropmask_bits_equal_the_oracle_masks(hip, B, T, S, p):
         assert np.array_equal(got_q, keep[bh]), f"keep bits differ (problem {bh})"
 
 
+def test_attention_dropmask_many_sites_in_one_launch(hip):
+    """detr_hip_attention_dropmask_many: the sites of a step (different T, S, site ids) from one launch equal the single-site calls."""
+    B, p, step = 2, 0.1, 0x1234ABCD
+    stepd = torch.tensor([step] + [0] * 7, dtype=torch.int32, device=DEV)
+    shapes = [(96, 96, 0), (96, 96, 16), (37, 96, 512), (37, 37, 514), (300, 40, 7)]
+    many = [torch.zeros(hip.attention_dropmask_words(B, H, T, S), dtype=torch.int32, device=DEV) for T, S, _ in shapes]
+    hip.attention_dropmask_many([(m, T, S, site) for m, (T, S, site) in zip(many, shapes)], B, H, dropout_p=p, dropout_step=stepd)
+    for m, (T, S, site) in zip(many, shapes):
+        one = torch.zeros_like(m)
+        hip.attention_dropmask(one, B, H, T, S, dropout_p=p, dropout_site=site, dropout_step=stepd)
+        assert torch.equal(m, one), f"site {site}"
+
+
 def _reference(q, k, v, do, scale, keep, p):
     B, T = q.shape[0], q.shape[1]
     qh, kh, vh = (t.view(B, -1, H, HD).transpose(1, 2) for t in (q, k, v))
