@@ -49,6 +49,7 @@ LN_FUSE = int(os.environ.get("DETR_HIP_LN_FUSE", "2"))
 # scale * log2(e) as its alpha) and the attention core is csrc/attention_dma.hip (LDS-DMA K / V rings per wave, dropout keep flags as bits
 # generated once per step).  DETR_HIP_ATTN16=0: the round-3 kernels on fp32 tensors (A/B switch)
 ATTN16 = os.environ.get("DETR_HIP_ATTN16", "1") != "0"
+DROPMASK_AHEAD = os.environ.get("DETR_HIP_DROPMASK_AHEAD", "0") == "1"      # the next step's keep bits during this step's decoder / matcher: measured SLOWER (profiles/r06_ab_results.txt #3), default off
 QK_ALPHA = float(HD) ** -0.5 * 1.4426950408889634      # what the stored bf16 query carries: softmax scale (transformer.py:307) * log2(e)
 
 
@@ -144,7 +145,10 @@ class DetrEngine:
         dropout site derives its key from it inside the kernels, so a captured hipGraph sees the new masks on replay."""
         self._step_no += 1
         self._step_seed = step_seed(self.dropout_seed, self._step_no, self.dp_rank)
-        hip.call("detr_hip_set_u32x8", self._seed_dev.data_ptr(), self._step_seed, 0, 0, 0, 0, 0, 0, 0)
+        # slot 1: the seed of the step after this one (the keep bits of the next step's attention sites are generated while this
+        # step's decoder / matcher leave most of the chip idle, _pregen_dropmasks)
+        hip.call("detr_hip_set_u32x8", self._seed_dev.data_ptr(), self._step_seed, step_seed(self.dropout_seed, self._step_no + 1, self.dp_rank),
+                 0, 0, 0, 0, 0, 0)
         self._drop = (float(self.dropout_p), self._step_seed)
         return self._step_seed
 
@@ -374,30 +378,58 @@ class DetrEngine:
     def attn16(self):
         return self.compute == 1 and ATTN16
 
-    def _dropmask(self, site, B, T, S):
-        """Keep bits of the attention-probability dropout of `site` (hip.attention_dropmask): one buffer per site, filled once per
-        step by _gen_dropmasks()."""
-        return self.buf(f"dropmask:{site}", (hip.attention_dropmask_words(B, HEADS, T, S),), torch.int32)
+    def _dropmask(self, site, B, T, S, which=None):
+        """Keep bits of the attention-probability dropout of `site` (hip.attention_dropmask): one buffer per site and step parity,
+        filled once per step by _gen_dropmasks() / one step ahead by _pregen_dropmasks()."""
+        which = getattr(self, "_mask_set", 0) if which is None else which
+        return self.buf(f"dropmask:{which}:{site}", (hip.attention_dropmask_words(B, HEADS, T, S),), torch.int32)
 
-    def _gen_dropmasks(self, B, L):
-        """All keep-bit buffers of this step's attention sites, on a stream of their own behind the seed write (they depend on nothing
-        else); joined in front of the first encoder attention.  Pure integer VALU work next to the backbone's HBM- / MFMA-bound kernels."""
-        dp, _ = self._drop
-        if not (self.attn16 and dp > 0.0):
-            return
+    def _mask_sites(self, L):
         Q = self.Q
         sites = [(16 * i, L, L) for i in range(self.num_enc)]
         for i in range(self.num_dec):
             ds = 16 * (32 + i)
             sites += [(ds, Q, Q), (ds + 2, Q, L)]
+        return sites
+
+    def _launch_dropmasks(self, B, L, which, seed_slot):
+        dp, _ = self._drop
         main = torch.cuda.current_stream()
         if getattr(self, "_mask_stream", None) is None:
             self._mask_stream = torch.cuda.Stream(device=main.device)
-        bufs = [(site, T, S, self._dropmask(site, B, T, S)) for site, T, S in sites]       # (allocated on the main stream)
+        bufs = [(self._dropmask(site, B, T, S, which), T, S, site) for site, T, S in self._mask_sites(L)]      # (allocated on the main stream)
         self._mask_stream.wait_stream(main)
         with torch.cuda.stream(self._mask_stream):
-            hip.attention_dropmask_many([(m, T, S, site) for site, T, S, m in bufs], B, HEADS, dropout_p=dp, dropout_step=self._seed_dev)
+            hip.attention_dropmask_many(bufs, B, HEADS, dropout_p=dp, dropout_step=self._seed_dev[seed_slot:])
+
+    def _gen_dropmasks(self, B, L):
+        """The keep-bit buffers of this step's attention sites: already there when the previous step generated them one step ahead
+        (_pregen_dropmasks; eager launches only), otherwise generated now on a stream of their own behind the seed write (they depend
+        on nothing else) and joined in front of the first encoder attention."""
+        dp, _ = self._drop
+        if not (self.attn16 and dp > 0.0):
+            return
+        if os.environ.get("DETR_HIP_DROPMASK_STALE") == "1" and getattr(self, "_mask_once", False):
+            return          # timing experiment only (profiles/r06_ab_results.txt): the keep bits of the first step are reused -- what their generation costs the step
+        self._mask_once = True
+        self._mask_set = self._step_no & 1
+        tags = self.__dict__.setdefault("_mask_tags", {})
+        key = (self._step_seed, B, L, self.Q, dp)
+        if not (tags.get(self._mask_set) == key and not self._graph_replay):
+            self._launch_dropmasks(B, L, self._mask_set, 0)
+            tags[self._mask_set] = None if self._graph_replay else key
         self._mask_pending = True
+
+    def _pregen_dropmasks(self, B, L):
+        """Called when the decoder forward begins (800-row kernels, then the matcher: most CUs idle for ~1.5 ms): the NEXT step's keep
+        bits, from its seed in slot 1 of the device seed block, into the other buffer set.  Eager launches only (a recorded graph keeps
+        the generation at the head of its own step).  Off by default: measured +0.07 ms per step (DETR_HIP_DROPMASK_AHEAD=1 enables it; profiles/r06_ab_results.txt #3)."""
+        dp, _ = self._drop
+        if not (self.attn16 and dp > 0.0) or self._graph_replay or not DROPMASK_AHEAD or os.environ.get("DETR_HIP_DROPMASK_STALE") == "1":
+            return
+        nxt = (self._step_no + 1) & 1
+        self._launch_dropmasks(B, L, nxt, 1)
+        self._mask_tags[nxt] = (step_seed(self.dropout_seed, self._step_no + 1, self.dp_rank), B, L, self.Q, dp)
 
     def _join_dropmasks(self):
         if getattr(self, "_mask_pending", False):
@@ -698,6 +730,8 @@ class DetrEngine:
         if self.num_enc == 0:
             mem_pos = qk                                          # = src + pos
         self.phase("fwd decoder")
+        if training:
+            self._pregen_dropmasks(B, L)
         # ---------------- decoder (transformer.py:207-234, :104-133) ----------------
         Q, nd = self.Q, self.num_dec
         qpos = V["query_embed/kernel"]
