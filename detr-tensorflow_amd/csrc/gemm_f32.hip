@@ -289,8 +289,11 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
         else if (force == 0 && split > 1 && d->M <= 64) tile = 4;     // 64 output rows: half of a 128-row tile would be padding (M64 N256 K534400: 84 -> 74 us)
         else tile = 1;
         // ring weight gradient (gemm_ring.h) on wider tiles -- experiment hook DETR_HIP_RING_WTILE: 1 = 128 x 256, 2 = 256 x 128
+        // (the FULL predicate of the ring weight gradient in gemm_launch -- ADVICE r5: a tile only that kernel has must not be handed to a
+        //  launch the kernel will not take, nor size the slab scratch for it; the slab form itself is checked again there)
         if (tile == 1 && split > 1 && batch == 1 && d->a_dtype == 1 && d->b_dtype == 1 && !d->a_kcontig && !d->b_kcontig && !d->rowsum_a &&
-            tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3) {
+            tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3 && tune(T_SLAB_TS) != 2 && d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 &&
+            d->ldb % 8 == 0 && aligned16(d->A) && aligned16(d->B) && aligned16(d->C) && d->ldc % 4 == 0 && (!d->scale || aligned16(d->scale))) {
             const int wt = tune(T_RING_WTILE);
             if (wt == 1 && d->N >= 256) tile = 6;
             else if (wt == 2 && d->M >= 256) tile = 7;
@@ -626,7 +629,8 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
     const bool ring_wgrad = p.bf16c && (p.tile == 1 || p.tile == 6 || p.tile == 7) && g.a16 && g.b16 && !ak && !bk && batch == 1 && p.split > 1 &&
                             g.slab_ts && !g.rowsum && d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) &&
                             aligned16(d->B) && tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3;
-    DETR_REQUIRE(ring_wgrad || (p.tile != 6 && p.tile != 7), "gemm: the 128 x 256 / 256 x 128 tiles exist for the ring weight gradient only");
+    DETR_REQUIRE(ring_wgrad || (p.tile != 6 && p.tile != 7), "gemm: the 128 x 256 / 256 x 128 tiles exist for the ring weight gradient only "
+                 "(tile-ordered slabs in a workspace of detr_hip_workspace_bytes_gemm bytes are required)");
     if (ring_wgrad) {
         if (gemm_ring_wgrad_launch(g, p.ts_bm, p.ts_bn, p.split, s)) return -1;
     } else if (p.bf16c) {
@@ -658,6 +662,26 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         DETR_LAUNCH_CHECK("gemm split-k reduce");
     }
     return 0;
+}
+
+// Which kernel family detr_hip_gemm_f32 would launch for this descriptor -- the decision of gemm_launch itself, for callers that bill launches
+// to roofline families (bench.py / scripts/pmc_summary.py through detr_tf/_hip.py; ADVICE r5: the Python copy of these rules had drifted).
+// 0 = tile engine (4-wave), 1 = streaming kernel, 2 = ring kernel (bf16), 3 = ring kernel (fp32), 4 = GEMM + LayerNorm, 5 = ring weight gradient;
+// negative: the descriptor is rejected (detr_hip_last_error).
+extern "C" int detr_hip_gemm_family(const detr_gemm_desc *d) {
+    GemmPlan p;
+    if (gemm_prepare(d, p)) return -1;
+    if (d->ln_y) return 4;
+    RingPlan rp;
+    const bool ring_first = tune(T_GEMM_STREAM) != 3 && gemm_ring_eligible(p, rp);
+    if (!ring_first && gemm_stream_eligible(p)) return 1;
+    if (ring_first) return 2;
+    if (gemm_ring_f32_eligible(p, rp)) return 3;
+    const GemmArgs &g = p.g;
+    const bool ring_wgrad = p.bf16c && (p.tile == 1 || p.tile == 6 || p.tile == 7) && g.a16 && g.b16 && !p.ak && !p.bk && p.batch == 1 && p.split > 1 &&
+                            g.slab_ts && !g.rowsum && d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) &&
+                            aligned16(d->B) && tune(T_GEMM_RING) != 2 && tune(T_GEMM_RING) != 3;
+    return ring_wgrad ? 5 : 0;
 }
 
 extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {

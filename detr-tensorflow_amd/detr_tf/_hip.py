@@ -118,6 +118,7 @@ _SIGNATURES = {
     "detr_hip_memset_zero": [c_void_p, c_size_t, c_void_p],
     "detr_hip_gemm_f32": [POINTER(GemmDesc), c_void_p],
     "detr_hip_gemm_group_f32": [POINTER(GemmDesc), c_int32, c_void_p],
+    "detr_hip_gemm_family": [POINTER(GemmDesc)],
     "detr_hip_gemm_ring_plan": [c_int32, c_int32, c_int32, POINTER(c_int32)],
     "detr_hip_splitk_reduce_many": [POINTER(ReduceDesc), c_int32, c_void_p],
     "detr_hip_conv3x3_f32": [POINTER(Conv3x3Desc), c_int32, c_void_p],
@@ -520,17 +521,10 @@ def _gemm_desc(M, N, K, A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, *, alpha=1
             rd = ReduceDesc()
             d.workspace, d.workspace_bytes = slab
             d.defer_out = ctypes.pointer(rd)
-    # family = the kernel BODY (every template instantiation -- layouts, storage types, tile sizes, grouped launches -- pooled)
+    # family = the kernel BODY (every template instantiation -- layouts, storage types, tile sizes, grouped launches -- pooled): asked from the
+    # library (detr_hip_gemm_family = the decision of the launch itself), only while a profiler is recording
     fam = "gemm_bf16c_kernel" if d.compute == 1 else "gemm_f32_kernel"
-    # mirror of gemm_stream_eligible() in csrc/gemm_f32.hip: the short-K all-bf16 GEMMs run on the streaming kernel
-    if (d.compute == 1 and d.a_dtype and d.b_dtype and d.c_dtype and a_kcontig and batch == 1 and split_k == 1 and rowsum_a is None
-            and K in (64, 128, 256) and N % 64 == 0 and M >= (4096 if (K == 256 and N >= 1024) else 16384) and scale is None
-            and (K == 256 or (alpha == 1.0 and dropout_p == 0.0))
-            and act in (0, 1) and (residual is None or (d.r_dtype and ldr % 8 == 0)) and (mask is None or d.m_dtype == 2 or (d.m_dtype and ldmask % 8 == 0))
-            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and os.environ.get("DETR_HIP_GEMM_STREAM") != "2"
-            # (round 5: the ring kernel -- billed to the tile-GEMM family -- has first call on two K = 256 families, gemm_ring_eligible())
-            and not (K == 256 and N >= 1024 and (M >= 16384 or (M >= 4096 and not b_kcontig))
-                     and os.environ.get("DETR_HIP_GEMM_RING") != "2" and os.environ.get("DETR_HIP_GEMM_STREAM") != "3")):
+    if PROFILER is not None and d.compute == 1 and load().detr_hip_gemm_family(byref(d)) == 1:
         fam = "gemm_stream_bf16_kernel"          # one kernel body; its K / layout / epilogue instantiations are pooled
     sig = (f"M{M} N{N} K{K} b{batch} ak{int(a_kcontig)} bk{int(b_kcontig)} a16{d.a_dtype} b16{d.b_dtype} sk{split_k}"
            f"{' res' if residual is not None else ''}{' mask' if mask is not None else ''}")

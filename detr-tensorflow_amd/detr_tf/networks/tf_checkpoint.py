@@ -326,8 +326,8 @@ def load_tf_checkpoint(prefix, duplicates=None):
     """{variable name: array}.  Object-based checkpoints are renamed through their object graph (attribute VARIABLE_VALUE ->
     the variable's full_name without the ':0' suffix); optimizer slots and bookkeeping entries (save counter) keep their
     checkpoint keys.  Name-based checkpoints are returned unchanged.
-    Eager Keras variable names are not unique (several optimizers may each own `Adam/iter:0`): the first entry of a name
-    keeps it, later ones stay under their checkpoint key, and `duplicates` (a list, optional) receives (name, key) of each
+    Eager Keras variable names are not unique (several optimizers may each own `Adam/iter:0`): a repeated name RAISES unless the caller
+    passes `duplicates` (a list): then the first entry of a name keeps it, later ones stay under their checkpoint key, and the list receives (name, key) of each
     -- the caller decides whether a duplicated name matters (networks.weights.load_tf_checkpoint_params raises when it is
     one of the parameters it was asked for)."""
     bundle = read_bundle(prefix)
@@ -340,8 +340,10 @@ def load_tf_checkpoint(prefix, duplicates=None):
         if name == "VARIABLE_VALUE" and key in bundle and full:
             var = full[:-2] if full.endswith(":0") else full
             if var in out:
-                if duplicates is not None:
-                    duplicates.append((var, key))
+                if duplicates is None:      # the lenient behaviour is opt-in: a caller that did not ask for the list must not map the wrong tensor silently
+                    raise CheckpointFormatError(f"variable name {var!r} occurs more than once in the object graph (second checkpoint key {key!r}); "
+                                                "pass duplicates=[] to keep the first and collect the others")
+                duplicates.append((var, key))
                 continue
             out[var] = bundle[key]
             renamed.add(key)

@@ -242,7 +242,8 @@ class GraphedTrainStep:
             tg, te = (float(v) for v in tt.tolist())
             tg = float("inf") if tg >= big else tg
             te = float("inf") if te >= big else te
-        self.choice = "graph" if (tg <= te and tg != float("inf")) else "eager"
+        # the graph path is only taken on a COMPARISON it won: a window that was spoiled on either side (no time) falls back to eager
+        self.choice = "graph" if (tg != float("inf") and te != float("inf") and tg <= te) else "eager"
         ms = lambda t: None if t == float("inf") else round(t / n * 1e3, 3)
         self.probe = {"graph_ms": ms(tg), "eager_ms": ms(te)}
 
@@ -266,6 +267,11 @@ class GraphedTrainStep:
             if self.launch == "auto" and self.probe is None:
                 self._probe_dirty = True
                 self._probe_skipped = True
+                if self.total_calls - self.eager_steps - 1 == 2 * self.PROBE_STEPS:
+                    # the schedule's last call: the decision is due NOW on every rank (it is a collective under data parallelism) --
+                    # with the eager window spoiled it is "eager", explicitly, and a valid graph time stays in the record
+                    self._probe_t.pop("eager_s", None)
+                    self._decide()
             return train_step(model, images, t_bbox, t_class, self.optimizers, cfg, epoch_step)
         warm = self.calls <= self.eager_steps       # first sighting of a shape: eager (allocates the static memory plan)
         if self.launch != "auto" or self.probe is not None:

@@ -137,6 +137,9 @@ typedef struct {
     uint16_t *ln_y16; float ln_eps;
 } detr_gemm_desc;
 int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream);
+/* the kernel family detr_hip_gemm_f32 would launch for this descriptor (no launch): 0 tile engine, 1 streaming kernel, 2 ring kernel (bf16),
+ * 3 ring kernel (fp32), 4 GEMM + LayerNorm, 5 ring weight gradient; negative = rejected.  For callers that bill launches to roofline families. */
+int detr_hip_gemm_family(const detr_gemm_desc *d);
 int detr_hip_splitk_reduce_many(const detr_reduce_desc *descs, int32_t n, void *stream);
 /* n independent GEMMs in one call.  Consecutive members (up to 4) that share one kernel variant -- 64x64 tiles, same operand
  * layouts / storage types, no batch -- are issued as ONE launch (members on blockIdx.y) and their split-K reductions as one

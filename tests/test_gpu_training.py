@@ -371,5 +371,6 @@ def test_bf16_training_curve_tracks_the_fp32_curve(hip):
     d_bf16, d_self = float(np.abs(h - f)[5:].mean()), float(np.abs(f2 - f)[5:].mean())
     print(f"[train sanity] max window |bf16 - fp32| / fp32 = {rel.max():.4f}; second-half mean |bf16 - fp32| = {d_bf16:.3f}, "
           f"|fp32' - fp32| = {d_self:.3f} at a loss of {float(f[5:].mean()):.2f}")
-    assert rel.max() < 0.10, rel.round(4).tolist()
-    assert d_bf16 <= max(1.5 * d_self, 0.03 * float(f[5:].mean())), (d_bf16, d_self)
+    # (the bounds of the one-batch version of this test, where they still hold -- the measured largest window gap is 3.4 %)
+    assert rel.max() < 0.08, rel.round(4).tolist()
+    assert d_bf16 <= max(1.25 * d_self, 0.02 * float(f[5:].mean())), (d_bf16, d_self)
