@@ -140,7 +140,7 @@ def family_tables(prof, ev_steps, precision):
     rows = {}
     mixed_ms = cov_ms = 0.0
     for k, v in fam.items():
-        f32 = precision == "fp32" or k.startswith("gemm_f32")
+        f32 = precision != "bf16" or k.startswith("gemm_f32")
         peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
         t_mfma = v["flops"] / (peak * 1e12) * 1e3
         t_hbm = v["bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3
@@ -161,7 +161,7 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
     d = fam[dom]
     tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-    f32 = precision == "fp32" or dom.startswith("gemm_f32")
+    f32 = precision != "bf16" or dom.startswith("gemm_f32")
     peak_tf = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
     bound = "mfma" if tflops / peak_tf >= gbs / PEAK_HBM_GBS else "hbm"
     traffic = traffic_src = None
@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--backbone", choices=["resnet50", "resnet101"], default="resnet50", help="BASELINE config C4 uses resnet101 at 1000x1333")
     ap.add_argument("--queries", type=int, default=100, help="object queries (BASELINE config C5: 300 with --batch 16)")
     ap.add_argument("--dropout", type=float, default=0.1, help="transformer dropout of the training step (reference: 0.1)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x3"], default="bf16",
                     help="fp32 = exact-f32 MFMA (parity mode); bf16 = bf16 MFMA with fp32 accumulation (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-parity-mode steps of a bf16 run")
@@ -369,7 +369,7 @@ def main():
     prof = None
     ev_steps = 0 if (args.no_kernel_events or rank != 0 or args.mode != "train") else max(1, min(args.event_steps, args.steps))
     if ev_steps:
-        prof = _hip.KernelProfiler(prealloc=1400 * ev_steps, f32=(args.precision == "fp32"))     # event objects exist before the timed region
+        prof = _hip.KernelProfiler(prealloc=1400 * ev_steps, f32=(args.precision != "bf16"))     # event objects exist before the timed region
     barrier("timed region start")
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -453,6 +453,20 @@ def main():
             fp32["step_roofline"] = {"mixed_ms": round(mix32["mixed_ms"], 3), "frac": round(mix32["mixed_ms"] / (d / n32 * 1e3), 4)}
         if loss_first is not None:
             bf16_loss_dev = abs(float(loss_first) - loss_first_fp32) / abs(loss_first_fp32)
+        # ---- the same fp32 step with its GEMMs / convolutions on the bf16 matrix pipe at fp32 accuracy (precision="fp32x3", round 6:
+        #      detr_gemm_desc.compute = 2, csrc/gemm_core.h mma_ktile_split3): fp32 storage, same parity tests and bounds as the exact mode
+        model = opt = stepper = None
+        torch.cuda.empty_cache()
+        model, opt, stepper = build("fp32x3")
+        loss_first_x3 = float(step(0))
+        for i in range(1, stepper.settle_calls):
+            step(i)
+        d3, _ = timed(n32, first=stepper.settle_calls)
+        fp32["f32x3"] = {"value": round(args.batch * n32 / d3, 3), "unit": "images/sec", "ms_per_step": round(d3 / n32 * 1e3, 3), "steps": n32,
+                         "dtype": "f32 storage, products = 6 bf16 partial products of the exact 3-way bf16 split of both operands "
+                                  "(v_mfma_f32_32x32x16_bf16), f32 accumulate; attention / LayerNorm / heads / loss as in the exact mode",
+                         "launch": ("hipGraph replay" if stepper.choice == "graph" else "eager, 2 HIP streams"),
+                         "first_step_loss_rel_dev_from_exact_fp32": abs(loss_first_x3 - loss_first_fp32) / abs(loss_first_fp32)}
 
     # ---- the other single-GPU configs of BASELINE.json
     configs = None
@@ -460,7 +474,7 @@ def main():
         configs = {}
         model = opt = stepper = None
         torch.cuda.empty_cache()
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "fp32x3", "bf16"):
             m = get_detr_model(cfg, include_top=True, device=str(dev), seed=0, dropout=args.dropout, precision=prec)
             for _ in range(2):
                 get_losses(m(images, training=False), tb, tc, cfg)
@@ -470,11 +484,11 @@ def main():
                 tot = get_losses(m(images, training=False), tb, tc, cfg)[0]
             torch.cuda.synchronize()
             d = (time.perf_counter() - t) / 3
-            key = "c2_forward_loss_fp32" if prec == "fp32" else "c2_forward_loss_bf16"
+            key = f"c2_forward_loss_{prec}"
             configs[key] = {"value": round(args.batch / d, 2), "unit": "images/sec", "ms": round(d * 1e3, 3), "loss": round(float(tot), 5),
                             "workload": f"DETR-R50 {prec} forward (eval) + set loss 6 levels, batch {args.batch}, {args.height}x{args.width}",
                             "frac_of_mfma_peak": round(args.batch / d * FWD_GFLOP_PER_IMAGE / 1e3 /
-                                                       (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS), 4)}
+                                                       (PEAK_F32_MFMA_TFLOPS if prec != "bf16" else PEAK_BF16_MFMA_TFLOPS), 4)}
             if True:                 # C1: one 480x640 image, eval forward + post-processing (eval.py:41-45), both precisions
                 img1 = torch.from_numpy(np.random.default_rng(7).normal(size=(1, 480, 640, 3)).astype(np.float32)).to(dev)
                 for _ in range(2):
@@ -541,7 +555,7 @@ def main():
             "metric": metric_name(args),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "dtype": {"fp32": "f32", "fp32x3": "f32 (bf16x3 split MFMA, fp32-accurate)", "bf16": "bf16"}[args.precision], "data": "synthetic",
             "config": {"workload": f"DETR-{'R101' if args.backbone == 'resnet101' else 'R50'} "
                                    f"{'train step (fwd+set loss 6 levels+bwd+clipnorm+3xAdam)' if args.mode == 'train' else 'forward+set loss'}, "
                                    f"{args.height}x{args.width}, batch {args.batch}/GPU, {args.queries} queries, 92 logits, 6+6 layers, dropout {args.dropout}",

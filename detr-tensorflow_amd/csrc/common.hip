@@ -37,6 +37,8 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_RING_WTILE",
     "DETR_HIP_RING_ABLATE",
     "DETR_HIP_CONV_DMA",
+    "DETR_HIP_SPLIT3_T128",
+    "DETR_HIP_SPLIT3_ALL",
 };
 static int g_tune[T_COUNT];
 static void load_tuning() {

@@ -132,7 +132,8 @@ struct LoaderConvA {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, bool DGRAD>
+// SPLIT3: the K tiles run on the bf16 matrix pipe at fp32 accuracy (gemm_core.h: mma_ktile_split3; detr_conv3x3_desc.compute = 2)
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool SPLIT3 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_kernel(ConvArgs a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1) < nkt;
         if (more) load_ab();
-        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_sel<BM, BN, WGM, WGN, SPLIT3>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
@@ -288,7 +289,7 @@ struct LoaderWgradA {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT3 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradArgs a) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3x3_wgrad_kernel(ConvWgradAr
             la.load(a, m_end, ra);
             lb.load(m_begin + (kt + 1) * GEMM_BK, m_end, rb);
         }
-        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_sel<BM, BN, WGM, WGN, SPLIT3>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             la.store(sm.A[cur ^ 1], ra);
             lb.store(sm.B[cur ^ 1], rb);
@@ -1143,11 +1144,18 @@ static void launch_conv_bf16(const ConvArgs &a0, bool dgrad, hipStream_t s) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s, bool split3 = false) {
     ConvArgs a = a0;
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cd, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if constexpr (BM == BN) {
+        if (split3) {
+            if (dgrad) hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
+            return;
+        }
+    }
     if (dgrad) hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
 }
@@ -1177,7 +1185,7 @@ static int wgrad_fused_split_plan(int units, int tiles, int split, int &ups) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false) {
+static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false, bool split3 = false) {
     ConvWgradArgs a = a0;
     a.tiles_m = cdiv(a.Ci, BM);
     a.tiles_n = cdiv(a.Co, BN);
@@ -1210,6 +1218,7 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
     if (bf16c && a.s16) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
+    else if (split3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s, nullptr, nullptr, 1.0f,
                                       ts ? BM : 0, ts ? BN : 0, a.tiles_n);
@@ -1335,10 +1344,11 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
             return 0;
         }
         const int wforce = tune(T_WGRAD_TILE);
-        if (wforce == 3) launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
-        else if (wforce == 1) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
-        else if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
-        else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s);
+        const bool s3 = d->compute == 2;
+        if (wforce == 3) launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, false, s3);
+        else if (wforce == 1) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, false, s3);
+        else if (d->Ci >= 128 && d->Co >= 128) launch_wgrad<128, 128, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, false, s3);
+        else launch_wgrad<64, 64, 2, 2>(a, d->split, d->workspace, d->workspace_bytes, s, false, s3);
         DETR_LAUNCH_CHECK("conv3x3 wgrad");
         return 0;
     }
@@ -1392,6 +1402,11 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
             if (force == 3 || (force == 0 && (c.Cd < 128 || big < 256)))
                 launch_conv_bf16<64, 64, 2, 2>(c, dgrad, s);
             else launch_conv_bf16<128, 128, 2, 2>(c, dgrad, s);
+        } else if (d->compute == 2) {
+            // f32x3: 64 x 64 wave tiles (128 x 128 workgroup tiles) are matrix-pipe bound, 32 x 32 ones VALU bound (see gemm_pick_tile)
+            const int lim = tune(T_SPLIT3_T128) > 0 ? tune(T_SPLIT3_T128) : 192;
+            if (force == 3 || (force == 0 && (c.Cd < 128 || big < lim))) launch_conv<64, 64, 2, 2>(c, dgrad, s, true);
+            else launch_conv<128, 128, 2, 2>(c, dgrad, s, true);
         } else if (force == 1) launch_conv<128, 128, 2, 2>(c, dgrad, s);
         else if (force == 2) launch_conv<128, 64, 2, 2>(c, dgrad, s);
         else launch_conv<64, 64, 2, 2>(c, dgrad, s);   // 64x64 measured best on every backbone shape (profiles/tune_r1.txt)

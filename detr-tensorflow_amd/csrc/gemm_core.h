@@ -323,6 +323,122 @@ __device__ __forceinline__ void mma_ktile(const float (*As)[BM + GEMM_PAD], cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same K tile on the bf16 matrix pipe at fp32 accuracy ("f32x3", detr_gemm_desc.compute = 2).
+// On gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of v_mfma_f32_32x32x16_bf16.  An fp32 value is EXACTLY the sum of
+// three bf16 values: h = bf16(x), m = bf16(x - h), l = x - h - m (both differences are exact in fp32, |m| <= 2^-8 |x|,
+// |l| <= 2^-16 |x|, and l has at most 8 significant bits left).  A product x*y is then the sum of nine bf16 products, each
+// exact in the fp32 accumulator's input; the three smallest (m*l', l*m', l*l': <= 2^-23 |xy| together, the size of one fp32
+// rounding of the product) are dropped in the 6-term form (NT = 6), kept in the 9-term form (NT = 9).  The terms of one
+// 32x32x16 block enter the fp32 accumulator smallest first: 6 (9) roundings of the accumulator per 16 k where the fp32 MFMA
+// has 8.  6 bf16 MFMAs take 6 x 32 cycles against 8 x 64 for the same 16 k on the fp32 instruction: 2.67x (1.78x) the
+// matrix-pipe rate, paid for with ~4.5 VALU instructions per fragment value (v_cvt_pk_bf16_f32, shift / mask, v_pk_add_f32).
+// The 16-deep fp32 LDS tile of the exact kernels is ONE k-step of the bf16 instruction; a lane gathers its 8 consecutive k of
+// row (lane & 31) with 8 ds_read_b32 (the same conflict-free pattern as mma_ktile: lanes 0..31 on consecutive dwords).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct Split3Frag { bf16x8_t h, m, l; };
+// RNE pair conversion as an opaque instruction: written as two scalar casts the compiler re-derives `pair << 16` from a second,
+// single-value v_cvt_pk_bf16_f32 (7.5 instead of 4.5 VALU instructions per value in the ISA of the first version)
+__device__ __forceinline__ unsigned cvt_pk_bf16_asm(f32x2_t x) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x[0]), "v"(x[1]));
+    return r;
+}
+__device__ __forceinline__ f32x2_t bf16_pair_to_f32(unsigned p) {
+    f32x2_t r;
+    r[0] = __builtin_bit_cast(float, p << 16);
+    r[1] = __builtin_bit_cast(float, p & 0xFFFF0000u);
+    return r;
+}
+// (x[0], x[1]) -> the three bf16 pairs h, m, l with x = h + m + l exactly; 9 VALU instructions per pair (3 conversions, 4 unpack
+// shifts / masks, 2 v_pk_add_f32)
+__device__ __forceinline__ void split3_pair(f32x2_t x, unsigned &h, unsigned &m, unsigned &l) {
+    h = cvt_pk_bf16_asm(x);
+    f32x2_t r = x - bf16_pair_to_f32(h);
+    m = cvt_pk_bf16_asm(r);
+    r = r - bf16_pair_to_f32(m);
+    l = cvt_pk_bf16_asm(r);
+}
+__device__ __forceinline__ Split3Frag split3_frag(const f32x2_t (&f)[4]) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3_pair(f[j], h[j], m[j], l[j]);
+    Split3Frag r;
+    r.h = __builtin_bit_cast(bf16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+    r.m = __builtin_bit_cast(bf16x8_t, make_uint4(m[0], m[1], m[2], m[3]));
+    r.l = __builtin_bit_cast(bf16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+    return r;
+}
+// the product terms of one 32x32x16 block, smallest first
+template <int NT>
+__device__ __forceinline__ f32x16 split3_mma(const Split3Frag &a, const Split3Frag &b, f32x16 c) {
+    static_assert(NT == 6 || NT == 9, "6 or 9 product terms");
+    if constexpr (NT == 9) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.m, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+#ifndef DETR_SPLIT3_TERMS
+#define DETR_SPLIT3_TERMS 6
+#endif
+template <int BM, int BN, int WGM, int WGN, int NT = DETR_SPLIT3_TERMS>
+__device__ __forceinline__ void mma_ktile_split3(const float (*As)[BM + GEMM_PAD], const float (*Bs)[BN + GEMM_PAD],
+                                                 f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                                 int wm, int wn, int lane) {
+    using T = TileCfg<BM, BN, WGM, WGN>;
+    static_assert(GEMM_BK == 16, "one fp32 K tile = one k-step of v_mfma_f32_32x32x16_bf16");
+    const int l31 = lane & 31;
+    const int k8 = (lane >> 5) * 8;
+    // every fragment value is read first (one LDS round trip for the tile), then fragments are split in the order the MFMA blocks
+    // need them: (a0, b0) -> block (0, 0) can issue while the vector pipe splits b1, a1, ...
+    f32x2_t fa[T::TM][4], fb[T::TN][4];
+#pragma unroll
+    for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fa[mi][j][0] = As[k8 + 2 * j][wm * T::WTM + mi * 32 + l31];
+            fa[mi][j][1] = As[k8 + 2 * j + 1][wm * T::WTM + mi * 32 + l31];
+        }
+#pragma unroll
+    for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fb[ni][j][0] = Bs[k8 + 2 * j][wn * T::WTN + ni * 32 + l31];
+            fb[ni][j][1] = Bs[k8 + 2 * j + 1][wn * T::WTN + ni * 32 + l31];
+        }
+    Split3Frag a[T::TM], b[T::TN];
+    a[0] = split3_frag(fa[0]);
+#pragma unroll
+    for (int ni = 0; ni < T::TN; ++ni) {
+        b[ni] = split3_frag(fb[ni]);
+        acc[0][ni] = split3_mma<NT>(a[0], b[ni], acc[0][ni]);
+    }
+#pragma unroll
+    for (int mi = 1; mi < T::TM; ++mi) {
+        a[mi] = split3_frag(fa[mi]);
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni) acc[mi][ni] = split3_mma<NT>(a[mi], b[ni], acc[mi][ni]);
+    }
+}
+// K tile of the fp32-storage kernels: exact fp32 MFMA, or the 3-way bf16 split (SPLIT3)
+template <int BM, int BN, int WGM, int WGN, bool SPLIT3>
+__device__ __forceinline__ void mma_ktile_sel(const float (*As)[BM + GEMM_PAD], const float (*Bs)[BN + GEMM_PAD],
+                                              f32x16 (&acc)[TileCfg<BM, BN, WGM, WGN>::TM][TileCfg<BM, BN, WGM, WGN>::TN],
+                                              int wm, int wn, int lane) {
+    if constexpr (SPLIT3) mma_ktile_split3<BM, BN, WGM, WGN>(As, Bs, acc, wm, wn, lane);
+    else mma_ktile<BM, BN, WGM, WGN>(As, Bs, acc, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Epilogue. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // The accumulators are transposed through LDS (one 32-row strip per wave at a time) so that every
 // lane then owns 4 CONSECUTIVE columns of one row: residual / mask reads and the output store are

@@ -197,12 +197,21 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
+static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk, bool split3 = false) {
     GemmArgs a = g;
     a.tiles_m = cdiv(g.M, BM);
     a.tiles_n = cdiv(g.N, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
     dim3 block(GEMM_THREADS);
+    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 128)) {
+        if (split3) {       // compute = 2: bf16 matrix pipe at fp32 accuracy (gemm_core.h: mma_ktile_split3)
+            if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a);
+            else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false, true>), grid, block, 0, s, a);
+            else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false, true>), grid, block, 0, s, a);
+            return 0;
+        }
+    }
     if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
@@ -251,6 +260,7 @@ struct GemmPlan {
     GemmArgs g;
     int batch, split;
     bool ak, bk, bf16c, partial;
+    bool split3;              // compute = 2: fp32 storage and accuracy on the bf16 matrix pipe (3-way operand split; 64x64 / 128x128 tiles)
     int deep;                 // K-tile depth of the all-bf16 variants: 0 = 32, 1 = 64, 2 = 128 (64x64 tiles only)
     int tile;                 // 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64
     long long part;           // floats per split slab (row-major: M*N; tile-ordered: the padded tile grid)
@@ -261,6 +271,13 @@ struct GemmPlan {
 
 // Tile shape of a GEMM: 0: 64x64, 1: 128x128, 2: 128x64, 3: 128x32, 4: 64x256 (fp32) / 64x128 (bf16), 5: 256x64.  Shared by the
 // launch path and by the scratch-size query (the tile-ordered split-K slabs are padded to whole tiles).
+// compute = 2 (f32x3): the shapes whose products go through the split kernel (gemm_core.h: mma_ktile_split3).  The operand split is VALU work
+// per fragment, so the narrow (N <= 64: 0.77x) and the short-K (K <= 128: 0.92-0.96x) 1x1-convolution GEMMs and the 64-row weight gradients
+// (0.85x) keep the exact kernel (scripts/micro_split3.py, profiles/r06_micro_split3.txt) -- both are fp32-accurate, the mode only decides
+// which matrix instruction computes the products.  DETR_HIP_SPLIT3_ALL=1: every shape (tests).
+static bool gemm_split3_shape(const detr_gemm_desc *d) {
+    return d->compute == 2 && d->N > 32 && (tune(T_SPLIT3_ALL) == 1 || (d->N >= 128 && d->K >= 256 && d->M >= 128));
+}
 static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
     const bool bf16c = d->compute == 1;
     const int force = tune(T_GEMM_TILE);     // tuning hook (scripts/tune_gemm.py); 0 = heuristic
@@ -298,6 +315,13 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
             if (wt == 1 && d->N >= 256) tile = 6;
             else if (wt == 2 && d->M >= 256) tile = 7;
         }
+    } else if (gemm_split3_shape(d)) {
+        // f32x3 (mma_ktile_split3): a wave's operand split costs VALU time per FRAGMENT, its 6 MFMAs per fragment PAIR -- 64 x 64 wave
+        // tiles (128 x 128 workgroup tiles) are matrix-pipe bound where 32 x 32 ones are VALU bound; small grids keep the 64 x 64 tile
+        const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
+        const int lim = tune(T_SPLIT3_T128) > 0 ? tune(T_SPLIT3_T128) : 192;
+        if (force == 1 || (force == 0 && t128 >= lim)) tile = 1;
+        else tile = 0;
     } else if (force == 1) tile = 1;
     else if (force == 2) tile = 2;
     else if (force == 3) tile = 0;
@@ -483,6 +507,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
                   (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)))) ? 1 : 0;
     }
     p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
+    p.split3 = gemm_split3_shape(d) && (tile == 0 || tile == 1);
     p.part = part; p.final_e = final_e; p.d = d;
     return 0;
 }
@@ -587,7 +612,7 @@ static bool gemm_ring_f32_eligible(const GemmPlan &p, RingPlan &rp) {
     const GemmArgs &g = p.g;
     const int mode = tune(T_GEMM_RING);
     if (mode == 2) return false;
-    if (p.bf16c || g.a16 || g.b16 || !p.ak || p.batch != 1 || p.split != 1 || g.rowsum || d->ln_y) return false;
+    if (p.bf16c || p.split3 || g.a16 || g.b16 || !p.ak || p.batch != 1 || p.split != 1 || g.rowsum || d->ln_y) return false;
     if (d->c_dtype || d->r_dtype || d->m_dtype) return false;
     if (!(d->K % 32 == 0 && d->K >= 64 && d->N >= 128 && d->lda % 4 == 0 && d->ldb % 4 == 0 && aligned16(d->A) && aligned16(d->B) &&
           (p.bk || d->N % 4 == 0))) return false;
@@ -638,12 +663,12 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk, p.deep);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk, p.deep);
-    } else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
+    } else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk, p.split3);
     else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 3) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
     else if (p.tile == 4) launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);
     else if (p.tile == 5) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
-    else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
+    else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk, p.split3);
     DETR_LAUNCH_CHECK("gemm");
     if (p.partial && d->defer_out) {      // the caller reduces later, many slabs per launch (detr_hip_splitk_reduce_many)
         detr_reduce_desc *o = d->defer_out;
@@ -692,8 +717,9 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
 
 // ---- grouped launch ------------------------------------------------------------------------------
 template <bool AK, bool BKC>
-static void launch_group_f32(const GemmGroupArgs &G, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC>), grid, dim3(GEMM_THREADS), 0, s, G);
+static void launch_group_f32(const GemmGroupArgs &G, dim3 grid, hipStream_t s, bool split3) {
+    if (split3) hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC, true>), grid, dim3(GEMM_THREADS), 0, s, G);
+    else hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC>), grid, dim3(GEMM_THREADS), 0, s, G);
 }
 template <bool AK, bool BKC, bool A16, bool B16>
 static void launch_group_bf16(const GemmGroupArgs &G, dim3 grid, hipStream_t s) {
@@ -714,7 +740,7 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
         // one launch needs ONE kernel variant: 64x64 tiles, same layouts / storage types, no batch; members may differ in shape
         bool same = m > 1 && tune(T_GEMM_GROUP) != 2;
         for (int i = 0; i < m && same; ++i)
-            same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
+            same = p[i].tile == 0 && p[i].batch == 1 && p[i].bf16c == p[0].bf16c && p[i].split3 == p[0].split3 && p[i].ak == p[0].ak && p[i].bk == p[0].bk &&
                    p[i].g.a16 == p[0].g.a16 && p[i].g.b16 == p[0].g.b16 && (p[i].split == 1 || p[i].partial) &&
                    !gemm_stream_eligible(p[i]);
         if (same) { RingPlan rp; for (int i = 0; i < m && same; ++i) same = !gemm_ring_eligible(p[i], rp) && !gemm_ring_f32_eligible(p[i], rp); }
@@ -748,10 +774,10 @@ extern "C" int detr_hip_gemm_group_f32(const detr_gemm_desc *descs, int32_t n, v
             else if (a16) DETR_GROUP_BF16(true, false);
             else if (b16) DETR_GROUP_BF16(false, true);
             else DETR_GROUP_BF16(false, false);
-        } else if (ak && bk) launch_group_f32<true, true>(G, grid, s);
-        else if (ak) launch_group_f32<true, false>(G, grid, s);
-        else if (bk) launch_group_f32<false, true>(G, grid, s);
-        else launch_group_f32<false, false>(G, grid, s);
+        } else if (ak && bk) launch_group_f32<true, true>(G, grid, s, p[0].split3);
+        else if (ak) launch_group_f32<true, false>(G, grid, s, p[0].split3);
+        else if (bk) launch_group_f32<false, true>(G, grid, s, p[0].split3);
+        else launch_group_f32<false, false>(G, grid, s, p[0].split3);
 #undef DETR_GROUP_BF16
         DETR_LAUNCH_CHECK("gemm group");
         // the members' split-K reductions, again as one launch (or handed back to the caller: detr_gemm_desc.defer_out)

@@ -111,7 +111,7 @@ __device__ __forceinline__ bool gemm_group_item(const GemmGroupArgs &G, int &m, 
     return true;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool SPLIT3 = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, const int zidx) {
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[SmemBytes<BM, BN, WGN>::VALUE];
@@ -175,7 +175,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, c
             la.load((kt + 1) * GEMM_BK, g.K, ra);
             lb.load((kt + 1) * GEMM_BK, g.K, rb);
         }
-        mma_ktile<BM, BN, WGM, WGN>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+        mma_ktile_sel<BM, BN, WGM, WGN, SPLIT3>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
         if (more) {
             if (do_rs) rs_add(ra);
             la.store(sm.A[cur ^ 1], ra);
@@ -194,18 +194,19 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const int id, c
     epilogue<BM, BN, WGM, WGN, false>(acc, reinterpret_cast<float *>(smem_raw), C, g.ldc, g.M, g.N, m0, n0, wm, wn, lane, wave, g.e);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+// SPLIT3: the K tiles run on the bf16 matrix pipe at fp32 accuracy (gemm_core.h: mma_ktile_split3; detr_gemm_desc.compute = 2)
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool SPLIT3 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     int tile, z;
     gemm_work_item(g, tile, z);
-    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC>(g, tile, z);
+    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC, SPLIT3>(g, tile, z);
 }
 // grouped launch: the members share the kernel variant; workgroups past a member's own tile / split count retire
-template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC>
+template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool SPLIT3 = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_group_kernel(GemmGroupArgs G) {
     int m, tile, z;
     if (!gemm_group_item(G, m, tile, z)) return;
-    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC>(G.g[m], tile, z);
+    gemm_f32_body<BM, BN, WGM, WGN, AK, BKC, SPLIT3>(G.g[m], tile, z);
 }
 
 // bf16-compute variant (fp32 storage): same arguments, same epilogue, operands rounded to bf16 into LDS.

@@ -200,8 +200,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void stem_fwd_rows_bf16_kernel(Ste
 // ------------------------------------------------------------------------------------------------
 // forward: y = act((gather(img) @ w) + bias)      tile 64 pixels x 64 channels
 // ------------------------------------------------------------------------------------------------
-template <bool BF>
+// MODE: 0 = exact fp32 MFMA, 1 = bf16 MFMA, 2 = fp32 accuracy on the bf16 matrix pipe (gemm_core.h: mma_ktile_split3)
+template <int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void stem_fwd_kernel(StemArgs a) {
+    constexpr bool BF = MODE == 1;
     constexpr int BM = 64, BN = 64, BK = BF ? BF_BK : GEMM_BK;
     constexpr int SMEM = BF ? BfSmemBytes<BM, BN, 2>::VALUE : SmemBytes<BM, BN, 2>::VALUE;
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM];
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_fwd_kernel(StemArgs a) {
                 load_a(kt + 1);
                 lb.load((kt + 1) * BK, STEM_K, rb);
             }
-            mma_ktile<BM, BN, 2, 2>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+            mma_ktile_sel<BM, BN, 2, 2, MODE == 2>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
             if (more) {
                 store_a(sm.A[cur ^ 1]);
                 lb.store(sm.B[cur ^ 1], rb);
@@ -292,8 +294,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_fwd_kernel(StemArgs a) {
 // weight gradient: dw[k][co] (+)= sum_m gather(img)[m][k] * dy[m][co]
 // grid = (3 tiles of 64 k, 1, row splits); reduction over the output pixels of the split
 // ------------------------------------------------------------------------------------------------
-template <bool BF, bool D16>
+template <int MODE, bool D16>
 __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
+    constexpr bool BF = MODE == 1;
     constexpr int BM = 64, BN = 64, BK = BF ? BF_BK : GEMM_BK;
     constexpr int SMEM = BF ? BfSmemBytes<BM, BN, 2>::VALUE : SmemBytes<BM, BN, 2>::VALUE;
     __shared__ __attribute__((aligned(16))) char smem_raw[SMEM];
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void stem_wgrad_kernel(StemArgs a) {
                 load_a(m_begin + (kt + 1) * BK);
                 lb.load(m_begin + (kt + 1) * BK, m_end, rb);
             }
-            mma_ktile<BM, BN, 2, 2>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
+            mma_ktile_sel<BM, BN, 2, 2, MODE == 2>(sm.A[cur], sm.B[cur], acc, wm, wn, lane);
             if (more) {
                 store_a(sm.A[cur ^ 1]);
                 lb.store(sm.B[cur ^ 1], rb);
@@ -553,8 +556,9 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
             DETR_LAUNCH_CHECK("stem conv forward (staged rows)");
             return 0;
         }
-        if (bf) hipLaunchKernelGGL(stem_fwd_kernel<true>, grid, dim3(GEMM_THREADS), 0, s, a);
-        else hipLaunchKernelGGL(stem_fwd_kernel<false>, grid, dim3(GEMM_THREADS), 0, s, a);
+        if (bf) hipLaunchKernelGGL(stem_fwd_kernel<1>, grid, dim3(GEMM_THREADS), 0, s, a);
+        else if (d->compute == 2) hipLaunchKernelGGL(stem_fwd_kernel<2>, grid, dim3(GEMM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(stem_fwd_kernel<0>, grid, dim3(GEMM_THREADS), 0, s, a);
         DETR_LAUNCH_CHECK("stem conv forward");
         return 0;
     }
@@ -595,9 +599,10 @@ extern "C" int detr_hip_stem_conv7x7_f32(const detr_stem_desc *d, int32_t mode, 
     a.e = e;
     dim3 grid(3, 1, (unsigned)split);
     DETR_REQUIRE(d->w_dtype == 0 || bf, "stem conv wgrad: a bf16 dy needs compute = bf16");
-    if (bf && d->w_dtype == 1) hipLaunchKernelGGL((stem_wgrad_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
-    else if (bf) hipLaunchKernelGGL((stem_wgrad_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((stem_wgrad_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, s, a);
+    if (bf && d->w_dtype == 1) hipLaunchKernelGGL((stem_wgrad_kernel<1, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else if (bf) hipLaunchKernelGGL((stem_wgrad_kernel<1, false>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else if (d->compute == 2) hipLaunchKernelGGL((stem_wgrad_kernel<2, false>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<0, false>), grid, dim3(GEMM_THREADS), 0, s, a);
     DETR_LAUNCH_CHECK("stem conv wgrad");
     if (partial) {
         launch_splitk_reduce(d->workspace, split, part, STEM_K, 64, d->y, 64, fin.alpha, fin.scale, s);

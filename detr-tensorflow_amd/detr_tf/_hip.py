@@ -179,7 +179,7 @@ _SIGNATURES_I64 = {
     "detr_hip_workspace_bytes_layernorm": [POINTER(LayerNormDesc)],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SIGNATURES_I64) + ["detr_hip_last_error"])
-ABI_VERSION = 8
+ABI_VERSION = 9
 # order of detr_hip_struct_layout's `which`
 LAYOUT_STRUCTS = (ReduceDesc, GemmDesc, Conv3x3Desc, StemDesc, LayerNormDesc, AttnDesc, SetLossDesc, InputDesc, PostprocessDesc)
 
@@ -248,7 +248,7 @@ DEFER = None
 DEFER_WS = None
 _defer_top = 0
 _defer_outs = set()
-COMPUTE_BF16 = 0      # default compute mode of gemm / conv3x3: 0 = exact fp32 MFMA, 1 = bf16 MFMA (fp32 storage)
+COMPUTE_BF16 = 0      # default compute mode of gemm / conv3x3: 0 = exact fp32 MFMA, 1 = bf16 MFMA (fp32 storage), 2 = f32x3 (fp32 accuracy on the bf16 pipe)
 WORKSPACE = None      # fp32 scratch tensor for the deterministic split-K reductions (set by the engine)
 
 
@@ -573,7 +573,7 @@ SPLIT_TARGET_64 = int(os.environ.get("DETR_HIP_SPLIT_TARGET64", "1024"))
 
 def pick_split_k(M, N, K, max_split=1024):
     """Reduction-heavy GEMMs (weight gradients): split K so that enough workgroups exist to fill 256 CUs."""
-    if COMPUTE_BF16 and ((N >= 128 and K >= 16384) or (M >= 512 and N >= 512 and K >= 4096) or
+    if COMPUTE_BF16 == 1 and ((N >= 128 and K >= 16384) or (M >= 512 and N >= 512 and K >= 4096) or
                          (K >= 4096 and ((M >= 256 and N >= 2048) or (M >= 2048 and N >= 256)))):   # 128x128 tiles (gemm_f32.hip: gemm_pick_tile)
         tiles = -(-M // 128) * -(-N // 128)
         ktiles = -(-K // 32)
@@ -581,7 +581,7 @@ def pick_split_k(M, N, K, max_split=1024):
     # 64x64 tiles (fp32 always; bf16 for small outputs, see gemm_f32.hip): ~1024 workgroups measured best
     tiles = -(-M // 64) * -(-N // 64)
     want = max(1, SPLIT_TARGET_64 // max(tiles, 1))
-    ktiles = -(-K // (32 if COMPUTE_BF16 else 16))
+    ktiles = -(-K // (32 if COMPUTE_BF16 == 1 else 16))
     cap = ktiles // 8 if ktiles >= 64 else ktiles // 4      # short reductions: 4 k-tiles per split are enough
     return int(max(1, min(want, max_split, cap)))
 

@@ -115,6 +115,9 @@ class DetrEngine:
         self.P.on_change = self._params_changed   # ParamStore.load / load_dict: refold the frozen BN, bump the weights version
         self.fold_bn()
         self.compute = 0                 # 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA, fp32 storage (config C3)
+        # fp32 storage mode only: the GEMMs / convolutions / stem run on the bf16 matrix pipe at fp32 accuracy (detr_gemm_desc.compute = 2,
+        # csrc/gemm_core.h: mma_ktile_split3) instead of on v_mfma_f32_32x32x2_f32; everything else of the fp32 mode is unchanged
+        self.f32_split = False
         self.dropout_p = 0.1             # Transformer(dropout=0.1) transformer.py:9 -- active when training=True
         self.dropout_seed = 0x5EED       # base seed; mixed with the step counter and the data-parallel rank
         self.dp_rank = 0                 # parallel.DataParallel sets it: every rank draws its own masks
@@ -131,6 +134,11 @@ class DetrEngine:
     # apply, fold_bn, and ParamStore.load / load_dict themselves (through the store's on_change hook), so a direct
     # `engine.P.load(...)` cannot leave a recorded eval graph or a bf16 shadow stale -- and a copy is rebuilt exactly when
     # it is next needed, also when fp32 and bf16 passes are interleaved.
+    @property
+    def gemm_mode(self):
+        """detr_gemm_desc.compute of this pass's GEMM / conv / stem launches: 1 = bf16 MFMA, 0 = exact fp32 MFMA, 2 = f32x3."""
+        return 1 if self.compute == 1 else (2 if self.f32_split else 0)
+
     def bump_weights_version(self):
         self._weights_version += 1
 
@@ -220,7 +228,7 @@ class DetrEngine:
     def _w(self, name):
         """Weight OPERAND of a GEMM: the fp32 tensor, or -- while the bf16-compute kernels are active -- its bf16 shadow
         (half the bytes, no conversion in the kernel).  Biases, LayerNorm vectors and gradients stay fp32."""
-        if hip.COMPUTE_BF16 and self.P.views16 is not None:
+        if hip.COMPUTE_BF16 == 1 and self.P.views16 is not None:
             return self.P.views16[name]
         return self.P.views[name]
 
@@ -563,7 +571,7 @@ class DetrEngine:
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, images, training=False):
         """See _forward_impl.  GEMM / conv compute mode: self.compute (0 = exact fp32, 1 = bf16 MFMA)."""
-        hip.COMPUTE_BF16 = self.compute
+        hip.COMPUTE_BF16 = self.gemm_mode
         if self.compute == 1 and (self._stale("shadow16") or self.P.views16 is None):
             self._refresh_shadow()
         if self.tf_backbone and self._stale("bias_shift"):
@@ -579,7 +587,7 @@ class DetrEngine:
                 hip.COMPUTE_BF16 = 0
 
     def backward(self, d_logits, d_boxes, backbone=True, on_bucket=None):
-        hip.COMPUTE_BF16 = self.compute
+        hip.COMPUTE_BF16 = self.gemm_mode
         cb = on_bucket
         if DEFER_REDUCE:
             # the weight gradients are only read by the bucket exchange / the optimiser: their split-K reductions are queued
@@ -864,7 +872,7 @@ class DetrEngine:
             dense_bwd(dt_a, hs2, "pos_layer/dense_0", d_hs)
             dense_bwd(dl, hs2, "cls_layer", d_hs, residual=d_hs)
         d_hs3 = d_hs.view(Lv, B * Q, D)
-        hip.COMPUTE_BF16 = self.compute
+        hip.COMPUTE_BF16 = self.gemm_mode
         self.phase("bwd decoder")
         # ---------------- decoder ----------------
         feat, Hf, Wf, L = self._feat_meta

@@ -43,9 +43,11 @@ class DetrModel:
         self.eval_graph, self._eval_graph, self._eval_seen = True, None, None     # hipGraph replay of the eval forward (_eval_forward)
         self.engine = DetrEngine(device, blocks, num_encoder_layers, num_decoder_layers, num_queries, 92, nb_class, seed,
                                  tf_backbone=tf_backbone)
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (exact, parity mode) or 'bf16' (bf16 MFMA, fp32 storage/accumulate)")
+        if precision not in ("fp32", "bf16", "fp32x3"):
+            raise ValueError("precision must be 'fp32' (exact fp32 MFMA, parity mode), 'fp32x3' (fp32 storage and accuracy on the bf16 matrix "
+                             "pipe: 3-way operand split, detr_gemm_desc.compute = 2) or 'bf16' (bf16 MFMA, fp32 accumulate)")
         self.engine.compute = 1 if precision == "bf16" else 0
+        self.engine.f32_split = precision == "fp32x3"
         self.precision = precision
         self.engine.dropout_p = float(dropout)  # Transformer(dropout=0.1), applied when called with training=True
         self.dp = None                        # parallel.DataParallel when training on several GPUs

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DETR_HIP_ABI_VERSION 8
+#define DETR_HIP_ABI_VERSION 9
 
 const char *detr_hip_last_error(void);
 int detr_hip_abi_version(void);
@@ -101,7 +101,12 @@ typedef struct {
      * (NULL = 0): a hipGraph replay of a captured step reads a fresh seed. */
     float dropout_p; uint32_t dropout_seed;
     /* 0 = exact fp32 MFMA (parity mode); 1 = bf16 MFMA with fp32 storage / accumulation (BASELINE config C3:
-     * operands are rounded to bf16 on their way into LDS) */
+     * operands are rounded to bf16 on their way into LDS); 2 (ABI 9, "f32x3") = fp32 storage AND fp32 accuracy on the bf16
+     * matrix pipe: every fp32 operand value is split exactly into three bf16 values (x = h + m + l) and a product is the sum
+     * of the six largest of the nine bf16 partial products, accumulated in fp32 (relative error of a product <= 2^-23, the
+     * size of one fp32 rounding; csrc/gemm_core.h: mma_ktile_split3) -- 6 bf16 MFMAs instead of 8 fp32 MFMAs per 32x32x16
+     * block at 16x the instruction rate.  Operands, C, residual and mask must be fp32 (the *_dtype fields 0); tiles other
+     * than 64x64 / 128x128 (N <= 32) run the exact kernel. */
     int32_t compute;
     /* optional fused bias gradient of a weight-gradient GEMM (dW = dy^T x): rowsum_a[m] += rowsum_alpha * sum_k A[m][k]
      * (A must be MN-contiguous, a_kcontig = 0; batch == 1; with split_k > 1 the deterministic workspace path is
@@ -171,7 +176,7 @@ typedef struct {
     int32_t act;
     int32_t split;       /* wgrad: number of row splits (0 = auto) */
     float *workspace; int64_t workspace_bytes;   /* wgrad: scratch for deterministic split reduction (see detr_gemm_desc) */
-    int32_t compute;     /* 0 = exact fp32 MFMA, 1 = bf16 MFMA (see detr_gemm_desc) */
+    int32_t compute;     /* 0 = exact fp32 MFMA, 1 = bf16 MFMA, 2 = fp32 accuracy on the bf16 matrix pipe (see detr_gemm_desc) */
     int32_t w_dtype;     /* modes 0/1 with compute = 1: 1 = `w` points to bf16 data (weight shadow, see detr_gemm_desc.b_dtype) */
     /* bf16 storage of the activation tensors (see detr_gemm_desc.a_dtype): x = the tensor passed as `x`, y = the one passed as `y`
      * (mode 2: x = input activations, `w` = dy whose dtype is w_dtype, y = dw always fp32), r = residual, m = mask */
@@ -220,7 +225,7 @@ typedef struct {
     int32_t act;
     int32_t split;
     float *workspace; int64_t workspace_bytes;
-    int32_t compute;        /* 0 = exact fp32 MFMA, 1 = bf16 MFMA */
+    int32_t compute;        /* 0 = exact fp32 MFMA, 1 = bf16 MFMA, 2 = fp32 accuracy on the bf16 matrix pipe (see detr_gemm_desc) */
     int32_t w_dtype;        /* mode 2: 1 = dy is bf16 in memory (bf16 activation storage) */
     int32_t y_dtype;        /* mode 0: 1 = the output is stored as bf16 */
 } detr_stem_desc;

@@ -50,14 +50,15 @@ def _grad_report(engine, P_ref, rtol=2e-3):
     return rows
 
 
-@pytest.fixture(scope="module")
-def small():
-    """R50 6+6 at 2 x 128x160 with the seeded oracle weights."""
+@pytest.fixture(scope="module", params=["fp32", "fp32x3"])
+def small(request):
+    """R50 6+6 at 2 x 128x160 with the seeded oracle weights -- in the exact-fp32 mode and in "fp32x3" (round 6: fp32 storage and accuracy
+    on the bf16 matrix pipe, detr_gemm_desc.compute = 2); every test of this fixture holds BOTH to the same fp32 bounds."""
     from detr_tf.networks.detr import get_detr_model
     from oracle import detr_ref as R, set_loss_ref as L
     cfg = _cfg()
     params = R.make_params(3)
-    model = get_detr_model(cfg, include_top=True, dropout=0.0)
+    model = get_detr_model(cfg, include_top=True, dropout=0.0, precision=request.param)
     missing = model.load_weights(params)
     assert not missing, missing
     rng = np.random.default_rng(11)
@@ -247,7 +248,8 @@ def test_backward_small_shapes_vs_oracle(hip):
     assert not bad, f"gradient mismatch (err/tol, tensor, abs err, ref scale): {bad[:12]}"
 
 
-def test_training_mode_dropout_vs_oracle_with_same_masks(hip):
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_training_mode_dropout_vs_oracle_with_same_masks(hip, precision):
     """model(images, training=True) applies the reference's Dropout(0.1) sites (transformer.py:169-176,216-232,341)
     with counter-hash masks; the oracle, given the same masks (oracle/dropout_ref.py), must produce the same
     loss and gradients."""
@@ -257,7 +259,7 @@ def test_training_mode_dropout_vs_oracle_with_same_masks(hip):
     from oracle import detr_ref as R, dropout_ref as DR, set_loss_ref as L
     cfg = _cfg()
     params = R.make_params(8, num_enc=2, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=2, num_decoder_layers=2)       # dropout = 0.1
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=2, num_decoder_layers=2, precision=precision)       # dropout = 0.1
     assert model.engine.dropout_p == pytest.approx(0.1)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
@@ -356,7 +358,8 @@ def test_interleaved_fp32_and_bf16_passes_rebuild_their_weight_copies(hip):
     assert not torch.equal(a16, before16) and not torch.equal(a32, before32)
 
 
-def test_train_steps_vs_oracle_adam(hip):
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_train_steps_vs_oracle_adam(hip, precision):
     """Two full train steps (forward, set loss, backward, per-tensor clipnorm, 3x Adam) on a reduced
     depth model vs the oracle optimiser; also the accumulate/apply cadence with target_batch."""
     from detr_tf import training
@@ -367,7 +370,7 @@ def test_train_steps_vs_oracle_adam(hip):
     cfg.backbone_lr.assign(1e-4)
     cfg.transformers_lr.assign(1e-3)
     params = R.make_params(5, num_enc=1, num_dec=2)
-    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0)
+    model = get_detr_model(cfg, include_top=True, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0, precision=precision)
     model.load_weights(params)
     opt = setup_optimizers(model, cfg)
     rng = np.random.default_rng(2)
@@ -487,12 +490,14 @@ def c2_ref():
     return dict(params=params, images=images, t_bbox=t_bbox, t_class=t_class, ref=ref, ref_total=float(ref_total), ref_log=ref_log)
 
 
-def test_c2_full_size_forward_loss_parity(hip, c2_ref):
-    """BASELINE config C2: R50 fp32 forward + set loss at B=8, 800x1333, Q=100, 92 logits."""
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_c2_full_size_forward_loss_parity(hip, c2_ref, precision):
+    """BASELINE config C2: R50 fp32 forward + set loss at B=8, 800x1333, Q=100, 92 logits -- on the exact fp32 MFMA and on the bf16 matrix
+    pipe at fp32 accuracy ("fp32x3"), same bounds."""
     from detr_tf.loss.loss import get_losses
     from detr_tf.networks.detr import get_detr_model
     cfg = _cfg(train=False)
-    model = get_detr_model(cfg, include_top=True, dropout=0.0)
+    model = get_detr_model(cfg, include_top=True, dropout=0.0, precision=precision)
     model.load_weights(c2_ref["params"])
     out = model(c2_ref["images"])
     total, log = get_losses(out, c2_ref["t_bbox"], c2_ref["t_class"], cfg)
@@ -500,7 +505,7 @@ def test_c2_full_size_forward_loss_parity(hip, c2_ref):
     assert tuple(out["pred_logits"].shape) == (8, 100, 92)
     e_logits, e_boxes = _rel(out["pred_logits"], ref["pred_logits"]), _rel(out["pred_boxes"], ref["pred_boxes"])
     e_loss = abs(float(total) - ref_total) / abs(ref_total)
-    print(f"[c2 parity] logits {e_logits:.2e} boxes {e_boxes:.2e} loss {e_loss:.2e}")
+    print(f"[c2 parity {precision}] logits {e_logits:.2e} boxes {e_boxes:.2e} loss {e_loss:.2e}")
     # exact-f32 MFMA against the oracle's CPU kernels: the only difference is the summation order.  SURVEY 4 allows 1e-4; the bound is
     # 15x the measured level, 50x tighter than round 3's 1e-3
     assert e_logits < C2_TOL and e_boxes < C2_TOL, (e_logits, e_boxes)
@@ -553,7 +558,7 @@ def test_model_surface_summary_layers_save_load(hip, small, capsys, tmp_path):
     path = str(tmp_path / "w")
     model.save_weights(path)
     from detr_tf.networks.detr import get_detr_model
-    twin = get_detr_model(small["cfg"], include_top=True, dropout=0.0, weights=path + ".npz", seed=123)
+    twin = get_detr_model(small["cfg"], include_top=True, dropout=0.0, weights=path + ".npz", seed=123, precision=model.precision)
     for a, b in zip(model.trainable_variables, twin.trainable_variables):
         assert torch.equal(a, b)
     x = torch.from_numpy(small["images"]).cuda()

@@ -178,7 +178,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in detr_hip.h but not exported"
     assert sorted(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.detr_hip_abi_version() == _hip.ABI_VERSION == 8
+    assert lib.detr_hip_abi_version() == _hip.ABI_VERSION == 9
 
 
 def _hip_lib():
