@@ -353,7 +353,11 @@ __device__ __forceinline__ f32x2_t bf16_pair_to_f32(unsigned p) {
 }
 // (x[0], x[1]) -> the three bf16 pairs h, m, l with x = h + m + l exactly; 9 VALU instructions per pair (3 conversions, 4 unpack
 // shifts / masks, 2 v_pk_add_f32)
+#ifndef DETR_X3_ABLATE
+#define DETR_X3_ABLATE 0         // timing experiments (results wrong): 1 = one MFMA term of six, 2 = no split arithmetic, 4 = no loop requests
+#endif
 __device__ __forceinline__ void split3_pair(f32x2_t x, unsigned &h, unsigned &m, unsigned &l) {
+    if constexpr ((DETR_X3_ABLATE & 2) != 0) { h = cvt_pk_bf16_asm(x); m = h; l = h; return; }
     h = cvt_pk_bf16_asm(x);
     f32x2_t r = x - bf16_pair_to_f32(h);
     m = cvt_pk_bf16_asm(r);
@@ -374,6 +378,7 @@ __device__ __forceinline__ Split3Frag split3_frag(const f32x2_t (&f)[4]) {
 template <int NT>
 __device__ __forceinline__ f32x16 split3_mma(const Split3Frag &a, const Split3Frag &b, f32x16 c) {
     static_assert(NT == 6 || NT == 9, "6 or 9 product terms");
+    if constexpr ((DETR_X3_ABLATE & 1) != 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
     if constexpr (NT == 9) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.l, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.l, c, 0, 0, 0);

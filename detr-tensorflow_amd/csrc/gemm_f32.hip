@@ -6,6 +6,7 @@
 #include "gemm_stream.h"
 
 #include "gemm_kernels.h"
+#include "gemm_x3.h"
 #include "gemm_ring.h"
 
 namespace detr {
@@ -197,25 +198,41 @@ void launch_splitk_reduce(const float *ws, int splits, long long part_stride, in
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk, bool split3 = false) {
+static int launch_cfg(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
     GemmArgs a = g;
     a.tiles_m = cdiv(g.M, BM);
     a.tiles_n = cdiv(g.N, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
     dim3 block(GEMM_THREADS);
-    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 128)) {
-        if (split3) {       // compute = 2: bf16 matrix pipe at fp32 accuracy (gemm_core.h: mma_ktile_split3)
-            if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a);
-            else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false, true>), grid, block, 0, s, a);
-            else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false, true>), grid, block, 0, s, a);
-            return 0;
-        }
-    }
     if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, block, 0, s, a);
+    return 0;
+}
+
+// compute = 2 on the shapes of gemm_split3_shape: the f32x3 kernel (gemm_x3.h)
+template <int BM, int BN>
+static int launch_x3(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool bk) {
+    GemmArgs a = g;
+    a.tiles_m = cdiv(g.M, BM);
+    a.tiles_n = cdiv(g.N, BN);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)(batch * g.split_k));
+    dim3 block(GEMM_THREADS);
+    // DETR_HIP_X3_DB: 1 = double-buffered LDS (in-wave overlap); 0 / 2 = single-buffered, which measured faster on every shape of the step
+    // (profiles/r06_micro_split3.txt: two workgroups per CU overlap better than one with two buffers)
+    const bool db = tune(T_X3_DB) == 1;
+#define DETR_X3_LAUNCH(DB_)                                                                                              \
+    do {                                                                                                                 \
+        if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true, DB_>), grid, block, 0, s, a);               \
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, false, DB_>), grid, block, 0, s, a);        \
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, true, DB_>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, false, DB_>), grid, block, 0, s, a);                      \
+    } while (0)
+    if (db) {
+        DETR_X3_LAUNCH(true);
+    } else DETR_X3_LAUNCH(false);
+#undef DETR_X3_LAUNCH
     return 0;
 }
 
@@ -356,7 +373,7 @@ static bool gemm_slab_ts(const detr_gemm_desc *d, int split, int batch, int tile
 static int gemm_effective_split(const detr_gemm_desc *d) {
     int split = d->split_k > 1 ? d->split_k : 1;
     if (split > 1) {
-        const int nkt = cdiv(d->K, d->compute == 1 ? BF_BK : GEMM_BK);
+        const int nkt = cdiv(d->K, (d->compute == 1 || gemm_split3_shape(d)) ? BF_BK : GEMM_BK);      // (the f32x3 kernel walks 32-deep K tiles)
         const int per = cdiv(nkt, split);
         split = cdiv(nkt, per);
     }
@@ -663,12 +680,14 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk, p.deep);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk, p.deep);
-    } else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk, p.split3);
+    } else if (p.split3 && p.tile == 1) launch_x3<128, 128>(g, batch, s, ak, bk);
+    else if (p.split3) launch_x3<64, 64>(g, batch, s, ak, bk);
+    else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 3) launch_cfg<128, 32, 4, 1>(g, batch, s, ak, bk);
     else if (p.tile == 4) launch_cfg<64, 256, 1, 4>(g, batch, s, ak, bk);
     else if (p.tile == 5) launch_cfg<256, 64, 4, 1>(g, batch, s, ak, bk);
-    else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk, p.split3);
+    else launch_cfg<64, 64, 2, 2>(g, batch, s, ak, bk);
     DETR_LAUNCH_CHECK("gemm");
     if (p.partial && d->defer_out) {      // the caller reduces later, many slabs per launch (detr_hip_splitk_reduce_many)
         detr_reduce_desc *o = d->defer_out;
@@ -718,7 +737,7 @@ extern "C" int detr_hip_gemm_f32(const detr_gemm_desc *d, void *stream) {
 // ---- grouped launch ------------------------------------------------------------------------------
 template <bool AK, bool BKC>
 static void launch_group_f32(const GemmGroupArgs &G, dim3 grid, hipStream_t s, bool split3) {
-    if (split3) hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC, true>), grid, dim3(GEMM_THREADS), 0, s, G);
+    if (split3) hipLaunchKernelGGL((gemm_x3_group_kernel<64, 64, AK, BKC>), grid, dim3(GEMM_THREADS), 0, s, G);
     else hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, 2, 2, AK, BKC>), grid, dim3(GEMM_THREADS), 0, s, G);
 }
 template <bool AK, bool BKC, bool A16, bool B16>
