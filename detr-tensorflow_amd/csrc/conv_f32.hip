@@ -218,6 +218,10 @@ struct ConvWgradArgs {
     int slab_ts;             // partial slabs in tile order (gemm_core.h: store_slab_ts; tile = (tap * tiles_m + tm) * tiles_n + tn)
 };
 
+}  // namespace detr
+#include "conv_x3.h"
+namespace detr {
+
 template <int BM>
 struct LoaderWgradA {
     static constexpr int VPR = BM / 4;
@@ -1150,6 +1154,14 @@ static void launch_conv(const ConvArgs &a0, bool dgrad, hipStream_t s, bool spli
     a.tiles_n = cdiv(a.Cd, BN);
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
     if constexpr (BM == BN) {
+        // split once into LDS (conv_x3.h): 1.0-1.25x the per-wave split below on the stride-1 / forward shapes, 0.92x on the parity classes of the
+        // stride-2 input gradient (1-4 taps: short K loops), which keep the first form (profiles/r06_micro_split3.txt).  DETR_HIP_X3_CONV=2: first
+        // form everywhere, =1: second form everywhere
+        if (split3 && a.Cs % 32 == 0 && tune(T_X3_CONV) != 2 && (!a.par_on || tune(T_X3_CONV) == 1)) {
+            if (dgrad) hipLaunchKernelGGL((conv3x3_x3_kernel<BM, BN, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_x3_kernel<BM, BN, false>), grid, block, 0, s, a);
+            return;
+        }
         if (split3) {
             if (dgrad) hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((conv3x3_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a);
@@ -1218,7 +1230,9 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     dim3 grid((unsigned)tiles, 9, (unsigned)split), block(GEMM_THREADS);
     if (bf16c && a.s16) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else if (bf16c) hipLaunchKernelGGL((conv3x3_wgrad_bf16c_kernel<BM, BN, WGM, WGN, false>), grid, block, 0, s, a);
-    else if (split3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
+    else if (split3 && BM == BN && WGM == 2 && WGN == 2 && tune(T_X3_CONV) != 2) {
+        if constexpr (BM == BN && WGM == 2 && WGN == 2) hipLaunchKernelGGL((conv3x3_wgrad_x3_kernel<BM, BN>), grid, block, 0, s, a);
+    } else if (split3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN, WGM, WGN>), grid, block, 0, s, a);
     if (partial) launch_splitk_reduce(ws, split, part, 9 * a.Ci, a.Co, dw_final, a.Co, final_e.alpha, final_e.scale, s, nullptr, nullptr, 1.0f,
                                       ts ? BM : 0, ts ? BN : 0, a.tiles_n);

@@ -49,7 +49,10 @@ LN_FUSE = int(os.environ.get("DETR_HIP_LN_FUSE", "2"))
 # scale * log2(e) as its alpha) and the attention core is csrc/attention_dma.hip (LDS-DMA K / V rings per wave, dropout keep flags as bits
 # generated once per step).  DETR_HIP_ATTN16=0: the round-3 kernels on fp32 tensors (A/B switch)
 ATTN16 = os.environ.get("DETR_HIP_ATTN16", "1") != "0"
-DROPMASK_AHEAD = os.environ.get("DETR_HIP_DROPMASK_AHEAD", "0") == "1"      # the next step's keep bits during this step's decoder / matcher: measured SLOWER (profiles/r06_ab_results.txt #3), default off
+# the NEXT step's keep bits generated during this step (eager launches): 2 (default) = next to the assignment kernel alone, behind the matcher's
+# cost kernel (pregen_dropmasks_at_matcher: -0.05 ms per step, profiles/r06_ab_results.txt #5); 1 = from the start of the decoder forward
+# (measured SLOWER, #3); 0 = at the head of their own step
+DROPMASK_AHEAD = int(os.environ.get("DETR_HIP_DROPMASK_AHEAD", "2") or 0)
 QK_ALPHA = float(HD) ** -0.5 * 1.4426950408889634      # what the stored bf16 query carries: softmax scale (transformer.py:307) * log2(e)
 
 
@@ -428,16 +431,26 @@ class DetrEngine:
             tags[self._mask_set] = None if self._graph_replay else key
         self._mask_pending = True
 
-    def _pregen_dropmasks(self, B, L):
+    def _pregen_dropmasks(self, B, L, now=False):
         """Called when the decoder forward begins (800-row kernels, then the matcher: most CUs idle for ~1.5 ms): the NEXT step's keep
         bits, from its seed in slot 1 of the device seed block, into the other buffer set.  Eager launches only (a recorded graph keeps
         the generation at the head of its own step).  Off by default: measured +0.07 ms per step (DETR_HIP_DROPMASK_AHEAD=1 enables it; profiles/r06_ab_results.txt #3)."""
         dp, _ = self._drop
         if not (self.attn16 and dp > 0.0) or self._graph_replay or not DROPMASK_AHEAD or os.environ.get("DETR_HIP_DROPMASK_STALE") == "1":
             return
+        if DROPMASK_AHEAD == 2 and not now:
+            self._pregen_args = (B, L)          # launched by the set loss between its cost and assignment kernels
+            return
         nxt = (self._step_no + 1) & 1
         self._launch_dropmasks(B, L, nxt, 1)
         self._mask_tags[nxt] = (step_seed(self.dropout_seed, self._step_no + 1, self.dp_rank), B, L, self.Q, dp)
+
+    def pregen_dropmasks_at_matcher(self):
+        """DETR_HIP_DROPMASK_AHEAD=2: the next step's keep bits next to the assignment kernel alone (one wave per problem, ~50 CUs for
+        ~0.7 ms), not next to the decoder's chain of short launches (which the co-running generator slowed: profiles/r06_ab_results.txt #3)."""
+        args, self._pregen_args = getattr(self, "_pregen_args", None), None
+        if args is not None:
+            self._pregen_dropmasks(*args, now=True)
 
     def _join_dropmasks(self):
         if getattr(self, "_mask_pending", False):

@@ -27,6 +27,9 @@ def make_desc(logits, boxes, t_bbox, t_class, background_class):
     return d
 
 
+before_assign = None     # hook of the training step (training.run_train_step): called between the cost and the assignment launches
+
+
 class Matcher:
     """Persistent device buffers of the matcher for one (levels, B, Q, R) shape."""
 
@@ -39,6 +42,8 @@ class Matcher:
 
     def run(self, desc, t_bbox):
         hip.call("detr_hip_match_cost_f32", byref(desc), self.cost.data_ptr())
+        if before_assign is not None:       # work of another stream queued behind the cost matrix: the assignment keeps ~50 CUs busy
+            before_assign()
         hip.call("detr_hip_assign_f32", self.cost.data_ptr(), self.P, self.Q, self.R - 1, t_bbox.data_ptr(), self.B,
                  self.R, self.tgt_for_pred.data_ptr(), self.pred_for_tgt.data_ptr(), self.status.data_ptr())
         return self.tgt_for_pred

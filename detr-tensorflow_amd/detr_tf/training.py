@@ -12,6 +12,7 @@ import time
 import torch
 
 from . import _hip as hip
+from .loss import hungarian_matching as _matching
 from .loss.loss import get_losses, log_from_losses
 from .optimizers import GROUPS, aggregate_grad_and_apply, gather_gradient
 
@@ -30,7 +31,11 @@ def run_train_step(model, images, t_bbox, t_class, optimizers, config):
     gradient_aggregate = _gradient_aggregate(config)
     optimizers["_engine"] = model.engine
     m_outputs = model(images, training=True)
-    total_loss, log = get_losses(m_outputs, t_bbox, t_class, config)
+    _matching.before_assign = model.engine.pregen_dropmasks_at_matcher
+    try:
+        total_loss, log = get_losses(m_outputs, t_bbox, t_class, config)
+    finally:
+        _matching.before_assign = None
     total_loss = total_loss / gradient_aggregate
     gradient_steps = gather_gradient(model, optimizers, total_loss, m_outputs, config, log,
                                      loss_scale=1.0 / gradient_aggregate)
