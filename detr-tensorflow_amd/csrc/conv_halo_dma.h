@@ -32,7 +32,7 @@
 // (profiles/r05_ab_results.txt): MFMAs one step BEHIND the fragment reads (two fragment sets; 52.9 vs 52.7 us) and a six-slot tile ring at two
 // workgroups per CU (tiles requested five steps ahead; 59.8 vs 51.5 us, the second round of a 624-workgroup grid on 512 slots).  What would
 // help is fewer kernel-tile bytes per MFMA (a 256-pixel tile halves them) without the tile-count losses of 8-row tiles (conv_halo.h) --
-// DESIGN.md section 7a.
+// NOTEBOOK.md section 7a.
 #pragma once
 #include "conv_halo.h"
 #include "gemm_ring.h"

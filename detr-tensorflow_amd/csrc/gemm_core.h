@@ -1,7 +1,7 @@
 // gemm_core.h -- the fp32 MFMA tile engine shared by the plain GEMM and the implicit-GEMM
 // 3x3 convolution kernels (gfx950 / CDNA4).
 //
-// Design (MI355X-first, see DESIGN.md "K2 GEMM"):
+// Design (MI355X-first):
 //   * v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain) at 157 TF peak; one f32 VGPR per
 //     operand per lane, 16 accumulator registers per 32x32 tile.
 //   * 256 threads = 4 waves arranged WGM x WGN; each wave owns TM x TN tiles of 32x32.

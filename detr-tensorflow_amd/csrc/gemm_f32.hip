@@ -635,7 +635,7 @@ static bool gemm_ring_f32_eligible(const GemmPlan &p, RingPlan &rp) {
           (p.bk || d->N % 4 == 0))) return false;
     // measured (scripts/micro_ring.py, RING_F32=1, second-pass columns -- the first timings of a process run at a lower clock): -3 .. -9 % on
     // the backbone's M >= 33600 shapes, +-0 .. +3 % on the M = 8400 ones: the fp32 MFMA kernels sit at ~0.6 of the nominal peak whatever
-    // the structure
+    // the structure (NOTEBOOK 4c)
     if (mode != 1 && !(d->M >= 16384)) return false;
     return gemm_ring_f32_plan(d->M, d->N, d->K, rp);
 }

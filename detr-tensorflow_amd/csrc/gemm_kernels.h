@@ -290,7 +290,7 @@ __device__ __forceinline__ void gemm_bf16c_body(const GemmArgs &g, const int id,
     // was one HBM / L2 round trip however deep the register pipeline.
     // (Round 4 measured FOUR register sets on the 64x64 tiles -- twice the bytes in flight: M800 N256 K2048 23 -> 19 us, every short-K
     //  shape 5-8 % slower (longer prologue), M8400 N256 K2048 unchanged, step +0.08 ms: not kept.  The launches are not bound by
-    //  the request depth either)
+    //  the request depth either; see NOTEBOOK 7c.)
     constexpr int DEPTH = 2;
     typename LA::Reg ra0[NRA], ra1[NRA];
     typename LB::Reg rb0[NRB], rb1[NRB];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16c_ln_kernel(GemmArgs
 }
 // (Round 4 measured a 128-deep K tile for the 64x64-tile launches with K >= 1024 -- half the barrier-separated iterations, 70 KB of
 //  LDS, 2 workgroups per CU; bit-identical: M8400 N256 K2048 34.7 -> 40.2 us, M8400 N512 K2048 42.3 -> 50.3 us.  Not kept: these
-//  launches are bound by the bytes their tiles pull out of L2, not by the number of iterations -- DESIGN 7c.)
+//  launches are bound by the bytes their tiles pull out of L2, not by the number of iterations -- NOTEBOOK 7c.)
 template <int BM, int BN, int WGM, int WGN, bool AK, bool BKC, bool A16, bool B16>
 __global__ __launch_bounds__(GEMM_THREADS, (BM * BN == 64 * 64) ? DETR_GEMM64_MINW : 1) void gemm_bf16c_group_kernel(GemmGroupArgs G) {
     int m, tile, z;

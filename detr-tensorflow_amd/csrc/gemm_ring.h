@@ -3,7 +3,7 @@
 // `s_barrier`, and a ROW-BALANCED tile grid.  Same arithmetic as gemm_bf16c_body (v_mfma_f32_32x32x16_bf16, every accumulator
 // sees its k-steps in ascending order): results are bit-identical to the 4-wave engine; same epilogue (gemm_core.h).
 //
-// Why.  The 4-wave engine pulls its tiles out of L2 at 13-16 B/clk/CU: 128x128 tiles read A twice
+// Why (NOTEBOOK 4b / 7c).  The 4-wave engine pulls its tiles out of L2 at 13-16 B/clk/CU: 128x128 tiles read A twice
 // and B 263 times (M = 33600), two workgroups per CU alternate short dependent phases (request -> wait -> ds_write -> barrier ->
 // fragments -> MFMA), the 526 tiles of DETR's "just past a power of two" row counts cost a second partial round (+21 %), and a
 // workgroup's epilogue overlaps nothing of its own.  Here:
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(RING_THREADS) void gemm_ring_kernel(RingArgs ra) {
 // fp32 form of the ring (the exact-f32 parity mode: v_mfma_f32_32x32x2_f32, the reference's own arithmetic).  Same pipeline, same
 // tile grid; a stage is 32 k deep (128-byte rows again).  fp32 GEMMs are MFMA-bound (the f32 MFMA runs at 1/16 of the bf16 rate),
 // and the 4-wave engine sat at 0.50 of that peak: one 32x32 accumulator per wave -- eight dependent MFMAs per K tile back to back,
-// issue stalls 52 % of the cycles.  Here a wave owns TM x TN independent accumulators and consecutive MFMAs never
+// issue stalls 52 % of the cycles (NOTEBOOK 7c).  Here a wave owns TM x TN independent accumulators and consecutive MFMAs never
 // touch the same one.
 //   * K-contiguous operand ([rows][k]): the same XOR-swizzled 128-byte-row image; a lane reads the 16-byte chunk of 4 consecutive k of
 //     its row ONCE per two MFMA steps (both lane halves the same address: broadcast) and picks element 2 j + h for step j -- the
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(RING_THREADS) void gemm_ring_f32_kernel(RingArgs ra
 // MN-contiguous (the 1x1-convolution weight gradients of the backbone: x^T dy over B*H*W pixels).  Same tile (64 TM x 128 TN), same
 // split ranges, same MFMA order per accumulator and the same tile-ordered slabs as gemm_bf16c_k64_kernel<BM, BN, 2, 2, false, false>
 // (bit-identical; the reduce launch is unchanged) -- but 8 waves per workgroup instead of 4 (the split-K launches run ONE
-// workgroup per CU: the 4-wave engine leaves one wave per SIMD, whose K tile cost ~2500 cycles for 512 of MFMA), both
+// workgroup per CU: the 4-wave engine leaves one wave per SIMD, whose K tile cost ~2500 cycles for 512 of MFMA, NOTEBOOK 4b), both
 // operands by LDS-DMA into transpose-read images, NS - 1 stages in flight.
 // The 2 x 4 wave grid stores its accumulator blocks at the slab positions a 2 x 2 grid would use (gemm_core.h slab_ts_unit):
 // block (wm, wn, mi, ni) is block (w' = 2 wm + (wn >> 1), mi, ni' = (wn & 1) TN + ni) of the 2 x 2 layout with TN' = 2 TN.

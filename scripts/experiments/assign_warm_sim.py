@@ -5,7 +5,7 @@
 
 The shortest-augmenting-path solver below is SciPy's / the kernel's algorithm (rows = targets, columns = queries; `steps` = scanned rows,
 the unit the kernel's time is made of: ~640 cycles each).  Warm start for level l+1: column prices v of level l, u_i = min_j(c_ij - v_j),
-empty matching.  Two findings:
+empty matching.  Two findings (NOTEBOOK 4c):
   * the transferred prices are not dual-feasible for a RECTANGULAR problem: a column that ends unmatched needs v_j = 0, the previous level's
     price is generally < 0 there -- the warm-started solver returns assignments that are NOT optimal (column `opt gap` > 0) unless the problem is
     squared with dummy rows;
