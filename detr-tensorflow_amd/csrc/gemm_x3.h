@@ -15,6 +15,10 @@
 //   * K tile 32.  ONE LDS buffer (3 x (BM + BN) x 80 B = 60 KB at 128 x 128: two workgroups per CU) and one register set:
 //     loop = [split + store tile t from registers] [request tile t+1] barrier [2 k-steps x 6 x TM x TN MFMAs] barrier --
 //     a workgroup's split phase (VALU, LDS writes) runs under the co-resident workgroup's MFMA phase.
+//   * (measured and NOT kept, scripts/experiments/gemm_x3pp.h: one 8-wave workgroup whose two 4-wave groups are held in anti-phase by the
+//     workgroup barrier -- one splits while the other multiplies.  Bit-identical, 1.3-1.6x SLOWER (M33600 N256 K1024: 154 -> 246 us): two
+//     independent workgroups drift into whatever interleaving the SIMD arbitration finds; the barrier pins every half-iteration to the slower
+//     of the two phases.  profiles/r06_ab_results.txt #7)
 //   * epilogue, split-K slabs, fused row sums (from the fp32 registers, before any rounding), XCD remap: the tile engine's.
 #pragma once
 #include "gemm_kernels.h"
