@@ -754,7 +754,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
             const int pp = S16 ? v >> 3 : v >> 4, c4 = S16 ? 2 * (v & 7) : v & 15;
             if (pp < NPP) {
                 const int kh = pp / PC, c = WG::slot(pp - kh * PC);
-                const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (c & 3) * 16 + (c4 & 3) * 4;
+                // (round 6) pixel (c & 3) of ci block cb sits in row ((c & 3) + cb) & 3 of its [4 px][16 ch] sub-block: the four blocks of one pixel -- the
+                // 8 (bf16) / 16 (fp32) lanes of one store group -- used to land on the same 8 banks of 32, a 4-way conflict on every patch store
+                // (SQ_LDS_BANK_CONFLICT 0.16 of the CU's cycles, rounds 3-5); the transpose read only cares which LANE hands in which chunk
+                const int o = kh * WF_ROW + ((c >> 2) * 4 + (c4 >> 2)) * 64 + (((c & 3) + (c4 >> 2)) & 3) * 16 + (c4 & 3) * 4;
                 if constexpr (S16) *reinterpret_cast<uint4 *>(&sm.X[buf][o]) = rx[i];
                 else *reinterpret_cast<uint2 *>(&sm.X[buf][o]) = make_uint2(pack_bf16(rx[i].x, rx[i].y), pack_bf16(rx[i].z, rx[i].w));
             }
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv3x3_wgrad_fused_bf16_kern
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = STR == 1 ? jbase + kw + 4 * h : (kw & 1) * 33 + jbase + (kw >> 1) + 4 * h;
-                xo[s2][kw][h] = ((c >> 2) * 4 + cib) * 64 + (c & 3) * 16 + (t16 & 3) * 4;
+                xo[s2][kw][h] = ((c >> 2) * 4 + cib) * 64 + (((c & 3) + cib) & 3) * 16 + (t16 & 3) * 4;      // (rotated rows: see store_unit)
             }
         dofs[s2] = ((4 * s2 + 2 * (g >> 1)) * 4 + 2 * wn + (g & 1)) * 64 + t16 * 4;
     }

@@ -270,3 +270,71 @@ def test_stride2_class_round_robin_covers_every_tile_once():
             assert (k, idx) not in seen, (nk, wid)
             seen.add((k, idx))
         assert len(seen) == sum(nk)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# csrc/conv_f32.hip: conv3x3_wgrad_fused_bf16_kernel -- the haloed input patch image (round 6: rows of a sub-block rotated by the ci block)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+WRITE_B128_GROUPS = [list(range(8 * g, 8 * g + 8)) for g in range(8)]       # ds_write_b128: 8 contiguous lanes per LDS cycle, 32 banks
+WRITE_B64_GROUPS = [list(range(16 * g, 16 * g + 16)) for g in range(4)]     # ds_write_b64: 16 contiguous lanes, 32 banks
+
+
+def wgrad_patch_offset(c, cb, q, rotate=True):
+    """shorts offset inside one patch row of (pixel slot c, 16-channel block cb, channel quad q)"""
+    row = ((c & 3) + cb) & 3 if rotate else c & 3
+    return ((c >> 2) * 4 + cb) * 64 + row * 16 + q * 4
+
+
+def _write_conflicts(rotate, s16):
+    """extra LDS cycles of one patch store instruction of wave 0 (register i = 0): lanes of a service group on the same bank, distinct addresses"""
+    groups = WRITE_B128_GROUPS if s16 else WRITE_B64_GROUPS
+    worst = 0
+    for grp in groups:
+        use = {}
+        for lane in grp:
+            v = lane
+            pp, c4 = (v >> 3, 2 * (v & 7)) if s16 else (v >> 4, v & 15)
+            o = wgrad_patch_offset(pp, c4 >> 2, c4 & 3, rotate)               # (stride 1, patch row 0: slot = pp)
+            for d in range(4 if s16 else 2):                                   # dwords of the store
+                use.setdefault((o // 2 + d) % 32, set()).add(o // 2 + d)
+        worst = max(worst, max(len(a) for a in use.values()))
+    return worst
+
+
+def test_wgrad_fused_patch_stores_are_conflict_free_since_round_6():
+    assert _write_conflicts(rotate=False, s16=True) == 4 and _write_conflicts(rotate=False, s16=False) == 4      # what rounds 3-5 ran
+    assert _write_conflicts(rotate=True, s16=True) == 1 and _write_conflicts(rotate=True, s16=False) == 1
+
+
+def test_wgrad_fused_patch_fragments_read_the_right_pixels_without_conflicts():
+    """the A fragment of tap kw, pixel half s2: lane (g, t16) hands in (pixel 16 s2 + 8 (g >> 1) + (t16 >> 2) + kw + 4 h, ci block 2 wm + (g & 1),
+    quad t16 & 3); after the transpose read lane l of the MFMA holds ci = 32 wm + (l & 31), k = 8 (l >> 5) + 4 h .. + 4 = consecutive output pixels"""
+    rng = np.random.default_rng(11)
+    PC = 34
+    X = rng.integers(1, 2 ** 40, size=(PC, 64), dtype=np.int64)               # [patch pixel][ci]
+    img = np.zeros(((PC + 3) // 4) * 4 * 64, dtype=np.int64)
+    for c in range(PC):
+        for cb in range(4):
+            for q in range(4):
+                o = wgrad_patch_offset(c, cb, q)
+                img[o:o + 4] = X[c, 16 * cb + 4 * q:16 * cb + 4 * q + 4]
+    for wm in range(2):
+        for s2 in range(2):
+            for kw in range(3):
+                for h in range(2):
+                    banks = {0: [], 1: []}
+                    for g in range(4):
+                        cib = 2 * wm + (g & 1)
+
+                        def addr(t, g=g, cib=cib):
+                            c = 16 * s2 + 8 * (g >> 1) + (t >> 2) + kw + 4 * h
+                            return 2 * wgrad_patch_offset(c, cib, t & 3)
+                        got = tr_fragment(img, addr)
+                        for t in range(16):
+                            ci = 16 * cib + t
+                            pix0 = 16 * s2 + 8 * (g >> 1) + kw + 4 * h
+                            assert np.array_equal(got[t], X[pix0:pix0 + 4, ci]), (wm, s2, kw, h, g, t)
+                            a = addr(t)
+                            banks[g >> 1] += [(a // 4) % 64, (a // 4 + 1) % 64]
+                    for half in (0, 1):                                        # ds_read_b64_tr_b16: two service groups of 32 lanes, 64 banks
+                        assert len(set(banks[half])) == 64, (wm, s2, kw, h, half)
