@@ -204,16 +204,16 @@ def metric_name(args):
 
 
 def attention_valu_bound(B, L, heads=8, p_drop=0.1):
-    """VALU-issue floor of the encoder self-attention FORWARD at d_head = 32 (north_star's 80 % MFMA target): per score
-    the softmax + dropout costs a fixed number of VALU instructions whatever the MFMA does.  Counted from the ISA of
-    attn_fwd_bf16_kernel's key loop (scripts/isa/sched.py): `valu_per_tile` VALU instructions per 32x32 score tile and wave
-    (16 scores per lane: exp2, max3 / add trees, the pair-hash dropout flags, bf16 packing; round 4: ~295 of the ~360 instructions of a
-    tile), 2 issue cycles each on a SIMD-32
-    (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cyc), 1024 SIMDs at 2.4 GHz; the MFMA floor of the same tile is 4 x
-    v_mfma_f32_32x32x16_bf16 = 128 cycles -- with ~295 x 2 = 590 VALU cycles per tile the kernel is VALU-bound by construction:
-    the MFMA pipe cannot be busier than 128 / 590 = 22 % even if the VALU work of one wave hides entirely under another wave's MFMAs
-    (the north_star's 80 % is out of reach at d_head = 32 with softmax + dropout in the loop)."""
-    valu_per_tile, cyc_per_valu, mfma_cyc_per_tile = 295, 2, 4 * 32
+    """VALU-issue floor of the encoder self-attention FORWARD at d_head = 32 (north_star's 80 % MFMA target): per score the softmax +
+    dropout costs a fixed number of VALU instructions whatever the MFMA does.  Round 6, re-published from the NEW kernel's count
+    (csrc/attention_dma.hip; profiles/r06_attn2_counters.txt: SQ_INSTS_VALU 8.27 M over 4352 waves = 1900 VALU instructions per wave,
+    a wave = 64 queries x a quarter of the keys = 16.4 score tiles of 32 x 32): `valu_per_tile` = 116 VALU instructions per 32 x 32 tile
+    and wave, prologue / merge included (rounds 3-5: 295 in the key loop alone), 2 issue cycles each at the guide's throughput
+    (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cyc; the kernel measures 4.6 cycles per VALU instruction, dependent chains included),
+    1024 SIMDs at 2.4 GHz; the MFMA floor of the same tile is 4 x v_mfma_f32_32x32x16_bf16 = 128 cycles.  With 232 VALU cycles per tile
+    the MFMA pipe cannot be busier than 128 / 232 = 55 % under perfect overlap, and not busier than 128 / (116 x 4.6) = 24 % at the
+    measured VALU issue rate (measured: 0.146) -- the north_star's 80 % stays out of reach at d_head = 32 with softmax + dropout in the loop."""
+    valu_per_tile, cyc_per_valu, mfma_cyc_per_tile = 116, 2, 4 * 32
     tiles = B * heads * ((L + 31) // 32) ** 2            # 32-query x 32-key score tiles
     simds, clk = 1024, 2.4e9
     valu_ms = tiles * valu_per_tile * cyc_per_valu / simds / clk * 1e3

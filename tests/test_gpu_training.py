@@ -374,3 +374,27 @@ def test_bf16_training_curve_tracks_the_fp32_curve(hip):
     # (the bounds of the one-batch version of this test, where they still hold -- the measured largest window gap is 3.4 %)
     assert rel.max() < 0.08, rel.round(4).tolist()
     assert d_bf16 <= max(1.25 * d_self, 0.02 * float(f[5:].mean())), (d_bf16, d_self)
+
+
+def test_keep_bits_generated_one_step_ahead_are_the_bits_of_their_own_step(hip, monkeypatch):
+    """Round 6: in bf16 mode the attention sites' dropout keep BITS of step t + 1 are generated during step t, next to the matcher
+    (engine.DROPMASK_AHEAD = 2, eager launches).  They must be the bits the step would have generated for itself (= 0): same logits and
+    same loss, bit for bit, over steps that include a change of the batch shape (the bits generated ahead for the old shape must be dropped)."""
+    from detr_tf import engine as engine_mod, training
+    from detr_tf.optimizers import setup_optimizers
+    data = _batches(2, seed=9) + _batches(2, seed=10, H=64, W=96) + _batches(1, seed=11)
+    runs = {}
+    for mode in (0, 2):
+        monkeypatch.setattr(engine_mod, "DROPMASK_AHEAD", mode)
+        cfg = _cfg()
+        model = _model(cfg, precision="bf16")
+        opt = setup_optimizers(model, cfg)
+        got = []
+        for i, (im, tb, tc) in enumerate(data):
+            out, tot, _ = training.train_step(model, im, tb, tc, opt, cfg, i)
+            got.append((out["pred_logits"].clone(), float(tot)))
+        assert model.engine.attn16 and model.engine._drop[0] == pytest.approx(0.1)
+        runs[mode] = got
+    for (lg0, t0), (lg2, t2) in zip(runs[0], runs[2]):
+        assert torch.equal(lg0, lg2) and t0 == t2
+    assert len({t for _, t in runs[2]}) == len(data)
