@@ -396,5 +396,5 @@ def test_keep_bits_generated_one_step_ahead_are_the_bits_of_their_own_step(hip, 
         assert model.engine.attn16 and model.engine._drop[0] == pytest.approx(0.1)
         runs[mode] = got
     for (lg0, t0), (lg2, t2) in zip(runs[0], runs[2]):
-        assert torch.equal(lg0, lg2) and t0 == t2
+        assert torch.equal(lg0, lg2) and t0 == pytest.approx(t2, rel=1e-6)      # (the loss sums use fp32 atomics: last-ulp freedom)
     assert len({t for _, t in runs[2]}) == len(data)
