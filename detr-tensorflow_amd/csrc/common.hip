@@ -39,6 +39,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_CONV_DMA",
     "DETR_HIP_SPLIT3_T128",
     "DETR_HIP_X3_DB",
+    "DETR_HIP_X3_T192",
     "DETR_HIP_X3_CONV",
     "DETR_HIP_SPLIT3_ALL",
 };

@@ -222,6 +222,10 @@ static int launch_x3(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool 
     // DETR_HIP_X3_DB: 1 = double-buffered LDS (in-wave overlap); 0 / 2 = single-buffered, which measured faster on every shape of the step
     // (profiles/r06_micro_split3.txt: two workgroups per CU overlap better than one with two buffers)
     const bool db = tune(T_X3_DB) == 1;
+    if constexpr (BM == 192) {       // (K-contiguous A only: the transpose-read image of an MN-contiguous operand needs a power-of-two block count)
+        if (bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, false, false>), grid, block, 0, s, a);
+    } else {
 #define DETR_X3_LAUNCH(DB_)                                                                                              \
     do {                                                                                                                 \
         if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true, DB_>), grid, block, 0, s, a);               \
@@ -229,9 +233,10 @@ static int launch_x3(const GemmArgs &g, int batch, hipStream_t s, bool ak, bool 
         else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, true, DB_>), grid, block, 0, s, a);        \
         else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, false, DB_>), grid, block, 0, s, a);                      \
     } while (0)
-    if (db) {
-        DETR_X3_LAUNCH(true);
-    } else DETR_X3_LAUNCH(false);
+        if (db) {
+            DETR_X3_LAUNCH(true);
+        } else DETR_X3_LAUNCH(false);
+    }
 #undef DETR_X3_LAUNCH
     return 0;
 }
@@ -339,6 +344,15 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
         const int lim = tune(T_SPLIT3_T128) > 0 ? tune(T_SPLIT3_T128) : 192;
         if (force == 1 || (force == 0 && t128 >= lim)) tile = 1;
         else tile = 0;
+        // Tile-count quantisation (profiles/r06_ab_results.txt #9): two 128 x 128 workgroups fit a CU = 512 slots, and M33600 N256 is 526 tiles -- two
+        // rounds, the second with 14 workgroups.  192 x 128 tiles (tile id 8: 1.5 x the work per workgroup, the same two per CU; K-contiguous A,
+        // unsplit, no fused row sums) take the GEMM when they need fewer rounds x 1.5.  DETR_HIP_X3_T192 = 2: never, 1: wherever eligible.
+        if (tile == 1 && force == 0 && split == 1 && batch == 1 && d->a_kcontig && !d->rowsum_a && tune(T_X3_T192) != 2) {
+            const long long slots = 512;
+            const long long t192 = (long long)cdiv(d->M, 192) * cdiv(d->N, 128);
+            const long long r128 = (t128 + slots - 1) / slots, r192 = (t192 + slots - 1) / slots;
+            if (tune(T_X3_T192) == 1 || 3 * r192 < 2 * r128) tile = 8;
+        }
     } else if (force == 1) tile = 1;
     else if (force == 2) tile = 2;
     else if (force == 3) tile = 0;
@@ -353,6 +367,7 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
 static void gemm_tile_dims(bool bf16c, int tile, int &bm, int &bn, bool &ts_ok) {
     ts_ok = true;
     if (tile == 1) { bm = 128; bn = 128; }
+    else if (tile == 8 && !bf16c) { bm = 192; bn = 128; }         // (f32x3, unsplit only)
     else if (tile == 6 && bf16c) { bm = 128; bn = 256; }         // (ring weight gradient only)
     else if (tile == 7 && bf16c) { bm = 256; bn = 128; }
     else if (tile == 2) { bm = 128; bn = 64; }
@@ -524,7 +539,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
                   (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)))) ? 1 : 0;
     }
     p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
-    p.split3 = gemm_split3_shape(d) && (tile == 0 || tile == 1);
+    p.split3 = gemm_split3_shape(d) && (tile == 0 || tile == 1 || tile == 8);
     p.part = part; p.final_e = final_e; p.d = d;
     return 0;
 }
@@ -680,7 +695,8 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         else if (p.tile == 4) launch_cfg_bf16<64, 128, 2, 2>(g, batch, s, ak, bk);
         else if (p.tile == 0) launch_cfg_bf16<64, 64, 2, 2>(g, batch, s, ak, bk, p.deep);
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk, p.deep);
-    } else if (p.split3 && p.tile == 1) launch_x3<128, 128>(g, batch, s, ak, bk);
+    } else if (p.split3 && p.tile == 8) launch_x3<192, 128>(g, batch, s, ak, bk);
+    else if (p.split3 && p.tile == 1) launch_x3<128, 128>(g, batch, s, ak, bk);
     else if (p.split3) launch_x3<64, 64>(g, batch, s, ak, bk);
     else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);

@@ -21,7 +21,7 @@ def _split_every_shape(hip):
     the tests force the split kernel onto every 64x64 / 128x128 launch unless they say otherwise."""
     hip.set_tuning("DETR_HIP_SPLIT3_ALL", 1)
     yield
-    for k in ("DETR_HIP_SPLIT3_ALL", "DETR_HIP_SPLIT3_T128", "DETR_HIP_GEMM_TILE", "DETR_HIP_CONV_TILE", "DETR_HIP_WGRAD_TILE"):
+    for k in ("DETR_HIP_SPLIT3_ALL", "DETR_HIP_SPLIT3_T128", "DETR_HIP_GEMM_TILE", "DETR_HIP_CONV_TILE", "DETR_HIP_WGRAD_TILE", "DETR_HIP_X3_T192"):
         hip.set_tuning(k, None)
 
 
@@ -30,6 +30,29 @@ def close(a, b, rtol=2e-5, what=""):
     scale = float(b.abs().max()) + 1e-30
     err = float((a - b).abs().max())
     assert err <= rtol * scale, f"{what}: max abs err {err:.3e} > {rtol * scale:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("M,N,K,bk,epi", [(33600, 256, 1024, 1, False), (1000, 300, 147, 0, True), (33600, 256, 128, 0, True), (190, 128, 64, 1, False)])
+def test_gemm_f32x3_192_row_tiles_equal_the_128_row_tiles(hip, M, N, K, bk, epi):
+    """The 192 x 128 tile of the f32x3 GEMM (round 6: fewer rounds where 128 x 128 tiles overflow the chip's 512 workgroup slots by a few; K-contiguous A,
+    unsplit) sums the same products in the same order: bit-identical to the 128 x 128 tiles, with ragged edges and a residual + ReLU epilogue.  The rule
+    picks it for M33600 N256 (526 tiles of 128 x 128) by itself."""
+    torch.manual_seed(M + N + K)
+    A, B = g(torch.randn(M, K)), g(torch.randn(N, K) if bk else torch.randn(K, N))
+    R = g(torch.randn(M, N)) if epi else None
+    bias = g(torch.randn(N)) if epi else None
+    outs = {}
+    for mode in (2, 1, 0):                # never / wherever eligible / the rule
+        hip.set_tuning("DETR_HIP_X3_T192", mode if mode else None)
+        C = torch.full((M, N), 3.0, device=DEV)
+        hip.gemm(M, N, K, A, K, 1, B, K if bk else N, bk, C, N, compute=2, **(dict(residual=R, ldr=N, bias=bias, act=1) if epi else {}))
+        torch.cuda.synchronize()
+        outs[mode] = C
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[2])
+    ref = A.double() @ (B.double().t() if bk else B.double())
+    if epi:
+        ref = torch.relu(ref + bias.double() + R.double())
+    close(outs[1], ref, what=f"f32x3 gemm 192-row tiles {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("tile", [None, 1, 3])          # the dispatch's choice, 128x128 forced, 64x64 forced
