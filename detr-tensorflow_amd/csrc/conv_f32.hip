@@ -1199,6 +1199,16 @@ static int wgrad_fused_split_plan(int units, int tiles, int split, int &ups) {
     return cdiv(units, ups);
 }
 
+// f32x3 forward / input gradient on 192 x 128 tiles (conv_x3.h; the rule is in detr_hip_conv3x3_f32)
+static void launch_conv_x3_192(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+    ConvArgs a = a0;
+    a.tiles_m = cdiv(a.M, 192);
+    a.tiles_n = cdiv(a.Cd, 128);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_x3_kernel<192, 128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<192, 128, false>), grid, block, 0, s, a);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false, bool split3 = false) {
     ConvWgradArgs a = a0;
@@ -1422,7 +1432,13 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
         } else if (d->compute == 2) {
             // f32x3: 64 x 64 wave tiles (128 x 128 workgroup tiles) are matrix-pipe bound, 32 x 32 ones VALU bound (see gemm_pick_tile)
             const int lim = tune(T_SPLIT3_T128) > 0 ? tune(T_SPLIT3_T128) : 192;
+            // 192 x 128 tiles where 128 x 128 ones overflow the 512 workgroup slots (two per CU) by a few: 256 channels at 50 x 84 are 526 tiles = two
+            // rounds, 350 tiles of 192 rows one round of 1.5 x the work (the rule of gemm_pick_tile's tile 8; DETR_HIP_X3_T192 = 2: never, 1: always)
+            const long long t192 = (long long)cdiv(c.M, 192) * cdiv(c.Cd, 128);
+            const long long r128 = (big + 511) / 512, r192 = (t192 + 511) / 512;
+            const bool x3form = c.Cs % 32 == 0 && tune(T_X3_CONV) != 2 && (!c.par_on || tune(T_X3_CONV) == 1);
             if (force == 3 || (force == 0 && (c.Cd < 128 || big < lim))) launch_conv<64, 64, 2, 2>(c, dgrad, s, true);
+            else if (force == 0 && x3form && tune(T_X3_T192) != 2 && (tune(T_X3_T192) == 1 || 3 * r192 < 2 * r128)) launch_conv_x3_192(c, dgrad, s);
             else launch_conv<128, 128, 2, 2>(c, dgrad, s, true);
         } else if (force == 1) launch_conv<128, 128, 2, 2>(c, dgrad, s);
         else if (force == 2) launch_conv<128, 64, 2, 2>(c, dgrad, s);
