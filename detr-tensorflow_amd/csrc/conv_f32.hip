@@ -1209,6 +1209,16 @@ static void launch_conv_x3_192(const ConvArgs &a0, bool dgrad, hipStream_t s) {
     else hipLaunchKernelGGL((conv3x3_x3_kernel<192, 128, false>), grid, block, 0, s, a);
 }
 
+// f32x3 forward / input gradient on 128 x 64 tiles, three workgroups per CU
+static void launch_conv_x3_128x64(const ConvArgs &a0, bool dgrad, hipStream_t s) {
+    ConvArgs a = a0;
+    a.tiles_m = cdiv(a.M, 128);
+    a.tiles_n = cdiv(a.Cd, 64);
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(GEMM_THREADS);
+    if (dgrad) hipLaunchKernelGGL((conv3x3_x3_kernel<128, 64, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_x3_kernel<128, 64, false>), grid, block, 0, s, a);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long long ws_bytes, hipStream_t s, bool bf16c = false, bool split3 = false) {
     ConvWgradArgs a = a0;
@@ -1438,7 +1448,10 @@ extern "C" int detr_hip_conv3x3_f32(const detr_conv3x3_desc *d, int32_t mode, vo
             const long long r128 = (big + 511) / 512, r192 = (t192 + 511) / 512;
             const bool x3form = c.Cs % 32 == 0 && tune(T_X3_CONV) != 2 && (!c.par_on || tune(T_X3_CONV) == 1);
             if (force == 3 || (force == 0 && (c.Cd < 128 || big < lim))) launch_conv<64, 64, 2, 2>(c, dgrad, s, true);
-            else if (force == 0 && x3form && tune(T_X3_T192) != 2 && (tune(T_X3_T192) == 1 || 3 * r192 < 2 * r128)) launch_conv_x3_192(c, dgrad, s);
+            else if (force == 0 && x3form && tune(T_X3_T192) != 2 && tune(T_X3_T192) != 3 && (tune(T_X3_T192) == 1 || 3 * r192 < 2 * r128)) launch_conv_x3_192(c, dgrad, s);
+            // 128 x 64 tiles, three workgroups per CU: one 128-channel panel (layer2: 1044 tiles of 128 x 128 = 2.04 rounds -> 290 vs 275 us) and grids
+            // that leave CUs with a single 128 x 128 workgroup (layer4: 264 tiles -> 357 vs 338 us); DETR_HIP_X3_T192 = 3: wherever 128 x 128 would run
+            else if (force == 0 && x3form && tune(T_X3_T192) != 2 && (tune(T_X3_T192) == 3 || c.Cd == 128 || big <= 384)) launch_conv_x3_128x64(c, dgrad, s);
             else launch_conv<128, 128, 2, 2>(c, dgrad, s, true);
         } else if (force == 1) launch_conv<128, 128, 2, 2>(c, dgrad, s);
         else if (force == 2) launch_conv<128, 64, 2, 2>(c, dgrad, s);

@@ -76,7 +76,7 @@ struct X3LoaderConvA {
 };
 
 template <int BM, int BN, bool DGRAD>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 2 : 4) void conv3x3_x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? 2 : (BM * BN >= 128 * 64 ? 3 : 4)) void conv3x3_x3_kernel(ConvArgs a) {
     constexpr int WGM = 2, WGN = 2;
     using T = TileCfg<BM, BN, WGM, WGN>;
     __shared__ __attribute__((aligned(16))) char smem_raw[X3SmemBytes<BM, BN, 1>::VALUE];

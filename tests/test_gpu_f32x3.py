@@ -199,14 +199,15 @@ def test_conv3x3_all_modes_f32x3(hip, tile, N, H, W, Ci, Co, stride):
 
 @pytest.mark.parametrize("N,H,W,C", [(8, 50, 84, 256), (2, 21, 37, 128)])
 def test_conv3x3_f32x3_192_row_tiles_equal_the_128_row_tiles(hip, N, H, W, C):
-    """The 192 x 128 tile of the f32x3 3x3 convolution (forward and input gradient; the rule takes it at 8 x 50 x 84 x 256, where 128 x 128 tiles
-    are 526 workgroups on 512 slots): same products in the same order, bit-identical to the 128 x 128 tiles."""
+    """The 192 x 128 and 128 x 64 tiles of the f32x3 3x3 convolution (forward and input gradient; the rule takes 192 rows at 8 x 50 x 84 x 256, where
+    128 x 128 tiles are 526 workgroups on 512 slots, and 128 x 64 for a single 128-channel panel): same products in the same order, bit-identical
+    to the 128 x 128 tiles."""
     torch.manual_seed(N + H + W + C)
     x, w = g(torch.randn(N, H, W, C)), g(torch.randn(3, 3, C, C) / (3 * C ** 0.5))
     shift, mask = g(torch.randn(C)), g(torch.randn(N, H, W, C))
     hip.set_tuning("DETR_HIP_CONV_TILE", None)
     outs = {}
-    for mode in (2, 1, 0):                # never / wherever eligible / the rule
+    for mode in (2, 1, 3, 0):             # 128 x 128 / 192 x 128 / 128 x 64 tiles / the rule
         hip.set_tuning("DETR_HIP_X3_T192", mode if mode else None)
         hip.set_tuning("DETR_HIP_SPLIT3_T128", 1)          # (128-row tiles from one tile on, so that the small case compares the two tile heights too)
         y, dx = torch.zeros(N, H, W, C, device=DEV), torch.zeros(N, H, W, C, device=DEV)
@@ -215,7 +216,7 @@ def test_conv3x3_f32x3_192_row_tiles_equal_the_128_row_tiles(hip, N, H, W, C):
         torch.cuda.synchronize()
         outs[mode] = (y, dx)
     for k in (0, 1):
-        assert torch.equal(outs[1][k], outs[2][k]) and torch.equal(outs[0][k], outs[2][k])
+        assert torch.equal(outs[1][k], outs[2][k]) and torch.equal(outs[0][k], outs[2][k]) and torch.equal(outs[3][k], outs[2][k])
     ref = torch.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1) + shift.double())
     close(outs[1][0], ref, what="f32x3 conv3x3 fwd, 192-row tiles")
 
