@@ -343,6 +343,7 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
         const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128) * batch * split;
         const int lim = tune(T_SPLIT3_T128) > 0 ? tune(T_SPLIT3_T128) : 192;
         if (force == 1 || (force == 0 && t128 >= lim)) tile = 1;
+        else if (force == 2) tile = 2;        // (128 x 64: three workgroups per CU)
         else tile = 0;
         // Tile-count quantisation (profiles/r06_ab_results.txt #9): two 128 x 128 workgroups fit a CU = 512 slots, and M33600 N256 is 526 tiles -- two
         // rounds, the second with 14 workgroups.  192 x 128 tiles (tile id 8: 1.5 x the work per workgroup, the same two per CU; K-contiguous A,
@@ -352,6 +353,12 @@ static int gemm_pick_tile(const detr_gemm_desc *d, int split, int batch) {
             const long long t192 = (long long)cdiv(d->M, 192) * cdiv(d->N, 128);
             const long long r128 = (t128 + slots - 1) / slots, r192 = (t192 + slots - 1) / slots;
             if (tune(T_X3_T192) == 1 || 3 * r192 < 2 * r128) tile = 8;
+        }
+        // 128 x 64 tiles (three workgroups per CU = 768 slots) where the 128 x 128 grid is just over a whole number of rounds (M8400 N2048: 1056 tiles = 2.06
+        // rounds: 142 -> 135 us, 88.7 -> 77.9 us at K = 256) or a short-K grid fills half the chip (M8400 N512 K256: 34.7 -> 30.4 us)
+        if (tile == 1 && force == 0 && split == 1 && batch == 1 && tune(T_X3_T192) != 2 && d->M >= 4096) {
+            const long long over = t128 % 512;
+            if ((t128 > 512 && over > 0 && over <= 128) || (t128 <= 384 && d->K <= 512)) tile = 2;
         }
     } else if (force == 1) tile = 1;
     else if (force == 2) tile = 2;
@@ -539,7 +546,7 @@ static int gemm_prepare(const detr_gemm_desc *d, GemmPlan &p) {
                   (k64 == 1 || (per_split >= 512 && (tile == 0 || split > 1)))) ? 1 : 0;
     }
     p.batch = batch; p.split = split; p.ak = ak; p.bk = bk; p.bf16c = bf16c; p.partial = partial; p.tile = tile;
-    p.split3 = gemm_split3_shape(d) && (tile == 0 || tile == 1 || tile == 8);
+    p.split3 = gemm_split3_shape(d) && (tile == 0 || tile == 1 || tile == 2 || tile == 8);
     p.part = part; p.final_e = final_e; p.d = d;
     return 0;
 }
@@ -697,6 +704,7 @@ static int gemm_launch(const GemmPlan &p, hipStream_t s) {
         else launch_cfg_bf16<128, 128, 2, 2>(g, batch, s, ak, bk, p.deep);
     } else if (p.split3 && p.tile == 8) launch_x3<192, 128>(g, batch, s, ak, bk);
     else if (p.split3 && p.tile == 1) launch_x3<128, 128>(g, batch, s, ak, bk);
+    else if (p.split3 && p.tile == 2) launch_x3<128, 64>(g, batch, s, ak, bk);
     else if (p.split3) launch_x3<64, 64>(g, batch, s, ak, bk);
     else if (p.tile == 1) launch_cfg<128, 128, 2, 2>(g, batch, s, ak, bk);
     else if (p.tile == 2) launch_cfg<128, 64, 2, 2>(g, batch, s, ak, bk);

@@ -337,7 +337,7 @@ __device__ __forceinline__ void gemm_x3_body(const GemmArgs &g, const int id, co
 }
 
 template <int BM, int BN, bool AK, bool BKC, bool DB>
-__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? (DB ? 1 : 2) : (DB ? 2 : 4)) void gemm_x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (BM * BN >= 128 * 128) ? (DB ? 1 : 2) : (BM * BN >= 128 * 64 ? (DB ? 1 : 3) : (DB ? 2 : 4))) void gemm_x3_kernel(GemmArgs g) {
     int tile, z;
     gemm_work_item(g, tile, z);
     gemm_x3_body<BM, BN, AK, BKC, DB>(g, tile, z);

@@ -55,7 +55,7 @@ def test_gemm_f32x3_192_row_tiles_equal_the_128_row_tiles(hip, M, N, K, bk, epi)
     close(outs[1], ref, what=f"f32x3 gemm 192-row tiles {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [None, 1, 3])          # the dispatch's choice, 128x128 forced, 64x64 forced
+@pytest.mark.parametrize("tile", [None, 1, 2, 3])       # the dispatch's choice, 128x128 / 128x64 / 64x64 forced
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 92, 256), (1000, 256, 147), (77, 40, 33), (8400, 64, 64), (520, 2048, 256), (130, 32, 100)])
 @pytest.mark.parametrize("ak,bk", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_layouts_f32x3(hip, tile, M, N, K, ak, bk):
