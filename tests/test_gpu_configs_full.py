@@ -47,7 +47,13 @@ def _step(precision, params, images, t_bbox, t_class, *, backbone="resnet50", nu
     return res
 
 
-def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_max, p90_max):
+# bounds of the fp32x3-vs-exact-fp32 comparison (measured values in the test's docstring / printed report)
+# measured at this shape: loss equal to the last printed digit, 0 of 954 matched pairs differ, per-tensor gradient rel-L2 <= 2e-4 except the stem kernel
+# (9e-4: the end of the longest chain, cancellation-dominated)
+X3_LOSS_TOL, X3_FLIP_MAX, X3_MEDIAN_MAX, X3_P90_MAX, X3_WORST_MAX = 1e-6, 0.0, 1e-4, 5e-4, 5e-3
+
+
+def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_max, p90_max, what="bf16", worst_max=None):
     """bf16 step `b16` against the fp32 step `a32` of the same path.  Returns the report dict (also printed)."""
     B = t_bbox.shape[0]
     n = t_bbox[:, 0, 0].astype(int)
@@ -73,8 +79,8 @@ def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_m
     vals = np.array([v for v, _ in l2])
     rep = dict(tag=tag, loss_fp32=a32["total"], loss_bf16=b16["total"], loss_rel=dloss, flips=flips, matched=matched,
                grad_median=float(np.median(vals)), grad_p90=float(np.quantile(vals, 0.9)), grad_worst=l2[:6])
-    print(f"[{tag}] bf16 vs fp32 HIP step: loss {a32['total']:.5f} / {b16['total']:.5f} (rel {dloss:.2e}); matching flips {flips} of "
-          f"{matched}; gradient rel-L2 median {rep['grad_median']:.3f} p90 {rep['grad_p90']:.3f}; worst {l2[:6]}")
+    print(f"[{tag}] {what} vs fp32 HIP step: loss {a32['total']:.5f} / {b16['total']:.5f} (rel {dloss:.2e}); matching flips {flips} of "
+          f"{matched}; gradient rel-L2 median {rep['grad_median']:.3g} p90 {rep['grad_p90']:.3g}; worst {l2[:6]}")
     assert np.isfinite(b16["total"]) and dloss <= loss_tol, rep
     assert flips <= flip_frac_max * matched, rep
     assert rep["grad_median"] <= median_max and rep["grad_p90"] <= p90_max, rep
@@ -82,6 +88,9 @@ def _compare(a32, b16, t_bbox, levels, tag, *, loss_tol, flip_frac_max, median_m
     # attention (its true gradient is ~0: tgt is the zero target, every query sees the same keys), query_embed (a sum of
     # nearly cancelling terms over layers), and the stem kernel (the end of the longest bf16 chain).  Everything else <= 12 %.
     loose = ("transformer/decoder/layer_0/self_attn/in_proj", "query_embed/kernel", "backbone/conv1/kernel")
+    if worst_max is not None:             # (an fp32-accuracy mode: one bound for every tensor)
+        assert l2[0][0] <= worst_max, (l2[0], rep)
+        return rep
     for v, name in l2:
         assert v <= (0.40 if any(name.startswith(t) for t in loose) else 0.12), (name, v, rep)
     return rep
@@ -97,7 +106,21 @@ def test_c3_bf16_train_step_vs_fp32_step_at_b8_800x1333(hip):
     b16 = _step("bf16", params, images, t_bbox, t_class)
     # exceptions named by test_bf16_compute_mode_deviation_from_fp32_oracle: cancellation-dominated tensors (query_embed, the
     # zero-gradient q / k projections of decoder layer 0) sit far above the median; they are in the report, not in the bounds
-    _compare(a32, b16, t_bbox, 6, "C3 R50 B8 800x1333", loss_tol=1e-3, flip_frac_max=0.12, median_max=0.05, p90_max=0.10)
+    # (round 6, measured: loss 6.2e-4, 65 of 954 matched pairs differ = 6.8 %, gradient rel-L2 median 0.024, p90 0.029)
+    _compare(a32, b16, t_bbox, 6, "C3 R50 B8 800x1333", loss_tol=1e-3, flip_frac_max=0.10, median_max=0.04, p90_max=0.06)
+
+
+def test_c3_fp32x3_train_step_vs_exact_fp32_step_at_b8_800x1333(hip):
+    """Round 6: the fp32x3 step (fp32 storage, bf16 matrix pipe, six exact partial products per product) against the exact-fp32 step at C3's own
+    shape -- the same comparison as the bf16 test above with bounds three orders of magnitude tighter: fp32x3 is an fp32-accuracy mode."""
+    from oracle import detr_ref as R, set_loss_ref as L
+    params = R.make_params(0)
+    images = np.random.default_rng(1234).normal(size=(8, 800, 1333, 3)).astype(np.float32)
+    t_bbox, t_class = L.make_targets(8, seed=1235)
+    a32 = _step("fp32", params, images, t_bbox, t_class)
+    x3 = _step("fp32x3", params, images, t_bbox, t_class)
+    _compare(a32, x3, t_bbox, 6, "C3 R50 B8 800x1333 fp32x3", loss_tol=X3_LOSS_TOL, flip_frac_max=X3_FLIP_MAX, median_max=X3_MEDIAN_MAX, p90_max=X3_P90_MAX,
+             what="fp32x3", worst_max=X3_WORST_MAX)
 
 
 def test_c4_r101_bf16_forward_loss_vs_fp32_oracle_at_1000x1333(hip):
