@@ -115,6 +115,7 @@ enum TuneKey {
     T_X3_DB,             // f32x3 GEMM (gemm_x3.h): 1 = double-buffered LDS form for every tile, 2 = single-buffered for every tile, 0 = rule
     T_X3_T192,           // f32x3 GEMM / 3x3 convolution: 2 = 64 x 64 and 128 x 128 tiles only, 1 = 192 x 128 wherever eligible, 3 = (convolution) 128 x 64 wherever
                          // 128 x 128 would run, 0 = the round-count rules (gemm_pick_tile, detr_hip_conv3x3_f32)
+    T_X3_WG_ROUNDS,      // f32x3 3x3 weight gradient: rounds of workgroups the split plan aims at (0 = 2)
     T_X3_CONV,           // f32x3 3x3 convolutions: 2 = the per-wave split of the first form (conv3x3_kernel<.., SPLIT3>) everywhere, 1 = split once into LDS (conv_x3.h) everywhere, 0 = rule
     T_SPLIT3_ALL,        // compute = 2: 1 = every 64x64 / 128x128 GEMM launch takes the split kernel (tests), 0 = where it is faster
     T_COUNT

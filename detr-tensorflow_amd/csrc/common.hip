@@ -40,6 +40,7 @@ static const char *const g_tune_names[T_COUNT] = {
     "DETR_HIP_SPLIT3_T128",
     "DETR_HIP_X3_DB",
     "DETR_HIP_X3_T192",
+    "DETR_HIP_X3_WG_ROUNDS",
     "DETR_HIP_X3_CONV",
     "DETR_HIP_SPLIT3_ALL",
 };

@@ -1187,6 +1187,18 @@ static int wgrad_split_plan(int M, int tiles, int split, int &rps) {
     rps = ((rps + BF_BK - 1) / BF_BK) * BF_BK;       // multiple of both K tiles (16 and 32)
     return cdiv(M, rps);
 }
+// f32x3 nine-tap-per-launch weight gradient (conv3x3_wgrad_x3_kernel): 512 (128 x 128 tiles, two workgroups per CU) or 1024 (64 x 64 tiles, four) slots.
+// The exact kernel's plan above (1536 workgroups, rounded UP) lands just over three rounds of 512 -- 1548 / 1539 / 1584 workgroups for 256 / 128 / 512
+// channels.  Whole rounds, rounded DOWN; two rounds measured best over the five 3x3 shapes (1 / 2 / 3: within 5 % of each other; DETR_HIP_X3_WG_ROUNDS)
+static int wgrad_x3_split(int M, int tiles, int bm) {
+    const int rounds = tune(T_X3_WG_ROUNDS) > 0 ? tune(T_X3_WG_ROUNDS) : 2;
+    const int slots = bm >= 128 ? 512 : 1024;
+    int split = (rounds * slots) / (tiles * 9);
+    const int max_split = cdiv(M, 256);
+    if (split > max_split) split = max_split;
+    return split < 1 ? 1 : split;
+}
+
 static int wgrad_fused_split_plan(int units, int tiles, int split, int &ups) {
     if (split <= 0) {
         int wgs = tune(T_WGRAD_FUSED_WGS);      // tuning hook: target workgroup count (512 measured best: 2 per CU)
@@ -1226,6 +1238,7 @@ static void launch_wgrad(const ConvWgradArgs &a0, int split, float *ws, long lon
     a.tiles_n = cdiv(a.Co, BN);
     const int tiles = a.tiles_m * a.tiles_n;
     int rps;
+    if (split3 && split <= 0 && BM == BN && tune(T_X3_CONV) != 2) split = wgrad_x3_split(a.M, tiles, BM);
     split = wgrad_split_plan(a.M, tiles, split, rps);
     a.rows_per_split = rps;
     const long long part = 9LL * a.Ci * a.Co;
@@ -1323,7 +1336,9 @@ extern "C" int64_t detr_hip_workspace_bytes_conv3x3(const detr_conv3x3_desc *d, 
         const bool bf = d->compute == 1 && d->Ci % 32 == 0 && d->Co % 32 == 0;
         const int wforce = bf ? 0 : tune(T_WGRAD_TILE);
         const int t = (wforce == 3) ? 64 : ((wforce == 1 || (d->Ci >= 128 && d->Co >= 128)) ? 128 : 64);
-        split = wgrad_split_plan(d->N * d->Ho * d->Wo, cdiv(d->Ci, t) * cdiv(d->Co, t), d->split, aux);
+        int ask = d->split;
+        if (d->compute == 2 && ask <= 0 && tune(T_X3_CONV) != 2) ask = wgrad_x3_split(d->N * d->Ho * d->Wo, cdiv(d->Ci, t) * cdiv(d->Co, t), t);      // (the launch's plan)
+        split = wgrad_split_plan(d->N * d->Ho * d->Wo, cdiv(d->Ci, t) * cdiv(d->Co, t), ask, aux);
     }
     return split > 1 ? (int64_t)split * part * 4 : 0;
 }

@@ -569,6 +569,7 @@ def gemm_group(calls):
 # the partial slabs to write and reduce; scripts/micro_wgrad.py shows the same 3-7 % per launch with cold caches)
 SPLIT_TARGET_128 = int(os.environ.get("DETR_HIP_SPLIT_TARGET", "256"))
 SPLIT_TARGET_64 = int(os.environ.get("DETR_HIP_SPLIT_TARGET64", "1024"))
+X3_SPLIT_TARGET = int(os.environ.get("DETR_HIP_X3_SPLIT_TARGET", "512"))      # workgroups a split-K f32x3 GEMM on 128 x 128 tiles aims at
 
 
 def pick_split_k(M, N, K, max_split=1024):
@@ -578,6 +579,15 @@ def pick_split_k(M, N, K, max_split=1024):
         tiles = -(-M // 128) * -(-N // 128)
         ktiles = -(-K // 32)
         return int(max(1, min(max(1, SPLIT_TARGET_128 // tiles), max_split, ktiles // 8 if ktiles >= 16 else 1)))
+    if COMPUTE_BF16 == 2 and X3_SPLIT_TARGET > 0 and N >= 128 and K >= 256 and M >= 128:
+        # f32x3 (gemm_x3.h): 128 x 128 tiles, two workgroups per CU = 512 slots; the 64 x 64 plan below left e.g. the 256 x 1024 weight gradient of layer3
+        # with 16 tiles x 16 splits = 256 workgroups, half a round of single workgroups per CU (round 6; DETR_HIP_X3_SPLIT_TARGET=0: the old plan)
+        t128 = -(-M // 128) * -(-N // 128)
+        ktiles = -(-K // 32)
+        cap = ktiles // 8 if ktiles >= 64 else max(1, ktiles // 4)
+        s128 = int(max(1, min(X3_SPLIT_TARGET // t128, max_split, cap)))
+        if t128 * s128 >= 192:                      # (gemm_pick_tile: 128 x 128 tiles from 192 of them on)
+            return s128
     # 64x64 tiles (fp32 always; bf16 for small outputs, see gemm_f32.hip): ~1024 workgroups measured best
     tiles = -(-M // 64) * -(-N // 64)
     want = max(1, SPLIT_TARGET_64 // max(tiles, 1))
