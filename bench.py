@@ -166,7 +166,7 @@ def roofline_entry(fam, dom, rows, ev_steps, precision, traffic_file):
     bound = "mfma" if tflops / peak_tf >= gbs / PEAK_HBM_GBS else "hbm"
     traffic = traffic_src = None
     # (the newest committed PMC summary of this precision: profiles/rNN_traffic[_bf16].json)
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         cand = traffic_file.replace("r03", rnd)
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             traffic_file = cand
